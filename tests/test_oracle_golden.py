@@ -1,0 +1,155 @@
+"""Pins the CPU oracle (oracle/*.py) against golden vectors captured from the reference's
+own MLP / cast_hook / training_step / rescale_noise_cfg (oracle/make_golden.py)."""
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle.step_ref import AdapterRef, kd_losses, rescale_noise_cfg_ref, training_step_ref
+from oracle.unet_ref import (UNet2DConditionRef, UNetConfig, cast_hook_ref, count_params_analytic, sd15_config,
+                             sdxl_config, tap_names, tiny_config)
+
+T = lambda a: torch.from_numpy(np.asarray(a))
+
+
+def _wsum(sd):
+    return float(sum(v.double().abs().sum().item() for v in sd.values()))
+
+
+def _adapter_from(args):
+    args = [int(a) for a in args]
+    if len(args) == 3:
+        return AdapterRef(args[0], args[1], args[2], None)
+    return AdapterRef(args[0], args[1], args[2], args[3], bool(args[4]))
+
+
+@pytest.mark.parametrize("tag", ["sdxl_small", "sdxl_small_residual", "test_small", "sd_small"])
+def test_adapter_small_fwd_bwd(golden_dir, tag):
+    g = np.load(os.path.join(golden_dir, f"mlp_{tag}.npz"))
+    m = _adapter_from(g["args"])
+    m.load_state_dict({k[2:]: T(g[k]) for k in g.files if k.startswith("w.")})   # same state-dict keys
+    x = T(g["x"]).clone().requires_grad_(True)
+    out = m(x)
+    outs = out if isinstance(out, tuple) else (out,)
+    for i, o in enumerate(outs):
+        torch.testing.assert_close(o, T(g[f"out{i}"]), rtol=1e-6, atol=1e-6)
+    torch.autograd.backward(outs, [T(g[f"gout{i}"]) for i in range(len(outs))])
+    torch.testing.assert_close(x.grad, T(g["dx"]), rtol=1e-5, atol=1e-6)
+    for k, p in m.named_parameters():
+        torch.testing.assert_close(p.grad, T(g["g." + k]), rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("tag", ["sdxl_6M", "sdxl_11M", "sdxl_in2048", "sdxl_in768", "sd15_full"])
+def test_adapter_full_size(golden_dir, tag):
+    g = np.load(os.path.join(golden_dir, f"mlp_{tag}.npz"))
+    torch.manual_seed(int(g["seed"]))
+    m = _adapter_from(list(g["args"]) if len(g["args"]) == 3 else list(g["args"]))
+    assert sum(p.numel() for p in m.parameters()) == int(g["nparam"])
+    assert list(m.state_dict().keys()) == [str(k) for k in g["keys"]]
+    assert abs(_wsum(m.state_dict()) - float(g["wsum"])) < 1e-6 * float(g["wsum"]), "seeded weights drifted"
+    with torch.no_grad():
+        out = m(T(g["x"]))
+    outs = out if isinstance(out, tuple) else (out,)
+    for i, o in enumerate(outs):
+        torch.testing.assert_close(o, T(g[f"out{i}"]), rtol=1e-5, atol=1e-6)
+
+
+def test_adapter_param_counts():
+    n = lambda *a: sum(p.numel() for p in AdapterRef(*a).parameters())
+    assert n(1024, 1280, 1024, 2048) == 6_033_408          # README.md:11 "6M"
+    assert n(1024, 1280, 2048, 2048) == 11_538_432
+    assert n(2048, 1280, 2048, 2048) == 13_637_632
+    assert n(768, 1280, 2048, 2048) == 11_013_632
+    assert n(1024, 768, 2048, None) == 7_866_368
+
+
+def _cfg_from(g, which):
+    boc = tuple(int(v) for v in g["cfg_boc"])
+    heads = tuple(int(v) for v in g["cfg_heads"])
+    if which == "sdxl":
+        return UNetConfig(sample_size=int(g["cfg_sample"]), block_out_channels=boc,
+                          transformer_layers_per_block=(1,) * len(boc), num_attention_heads=heads,
+                          cross_attention_dim=int(g["cfg_cross"]), addition_time_embed_dim=int(g["cfg_add_dim"]),
+                          projection_class_embeddings_input_dim=int(g["cfg_proj_in"]), name="toy")
+    b = sd15_config()
+    return UNetConfig(sample_size=int(g["cfg_sample"]), block_out_channels=boc, down_block_types=b.down_block_types,
+                      up_block_types=b.up_block_types, transformer_layers_per_block=(1,) * len(boc),
+                      num_attention_heads=heads, cross_attention_dim=int(g["cfg_cross"]),
+                      use_linear_projection=False, addition_embed_type=None, addition_time_embed_dim=0,
+                      projection_class_embeddings_input_dim=0, name="toy15")
+
+
+@pytest.mark.parametrize("tag", ["sdxl_mixed", "sdxl_all_en", "sdxl_all_zh", "sd15_mixed"])
+def test_training_step_vs_reference(golden_dir, tag):
+    g = np.load(os.path.join(golden_dir, f"step_{tag}.npz"))
+    which = "sdxl" if tag.startswith("sdxl") else "sd15"
+    cfg = _cfg_from(g, which)
+    torch.manual_seed(int(g["seed_model"]))
+    us, ut = UNet2DConditionRef(cfg), UNet2DConditionRef(cfg)
+    assert abs(_wsum(us.state_dict()) + _wsum(ut.state_dict()) - float(g["wsum_unets"])) < 1e-6 * float(g["wsum_unets"])
+    ad = _adapter_from(g["mlp_args"])
+    ad.load_state_dict({k[2:]: T(g[k]) for k in g.files if k.startswith("w.")})
+    for p in us.parameters():
+        p.requires_grad_(False)         # the build freezes the student UNet (adapter-only backward)
+    batch = {k: T(g[k]) for k in ["latents", "noise", "timesteps", "enc", "enc_uncond", "prompt_mask", "zh_or_not",
+                                  "teacher_ehs", "teacher_neg", "teacher_pooled", "time_ids"]}
+    out = training_step_ref(ad, us, ut, batch, cast_hook_ref, nan_guard=(which == "sd15"))
+    assert list(out["taps_s"].keys()) == [str(k) for k in g["tap_keys"]] == tap_names(cfg)
+    for k in ["loss", "train_loss", "train_loss_logits", "train_loss_features"]:
+        assert abs(float(out[k]) - float(g[k])) <= 2e-5 * max(1.0, abs(float(g[k]))), k
+    out["loss"].backward()
+    for k, p in ad.named_parameters():
+        torch.testing.assert_close(p.grad, T(g["g." + k]), rtol=2e-4, atol=2e-6)
+    assert int(g["unet_wgrad_populated"]) == 1   # documented reference quirk
+
+
+def test_rescale_noise_cfg(golden_dir):
+    g = np.load(os.path.join(golden_dir, "rescale_noise_cfg.npz"))
+    for gr in (0.0, 0.3, 0.7):
+        out = rescale_noise_cfg_ref(T(g["noise_cfg"]), T(g["noise_pred_text"]), gr)
+        torch.testing.assert_close(out, T(g[f"out_{gr}"]), rtol=1e-6, atol=1e-6)
+
+
+def test_unet_known_answers():
+    assert count_params_analytic(sdxl_config()) == 2_567_463_684
+    assert count_params_analytic(sd15_config()) == 859_520_964
+    with torch.device("meta"):
+        m = UNet2DConditionRef(sdxl_config())
+    pc = lambda mod: sum(p.numel() for p in mod.parameters())
+    blocks = [pc(b) for b in m.down_blocks] + [pc(m.mid_block)] + [pc(b) for b in m.up_blocks]
+    want = [5.4, 60.1, 757.4, 413.1, 1206.6, 106.3, 11.2]            # SURVEY 8(c), M params
+    for got, w in zip(blocks, want):
+        assert abs(got / 1e6 - w) < 0.06, (got, w)
+
+
+def test_tap_shapes_tiny():
+    cfg = tiny_config()
+    torch.manual_seed(0)
+    m = UNet2DConditionRef(cfg)
+    st = {}
+    cast_hook_ref(m, st)
+    B = 2
+    with torch.no_grad():
+        m(torch.randn(B, 4, 16, 16), torch.tensor([1, 999]), torch.randn(B, 5, cfg.cross_attention_dim),
+          added_cond_kwargs={"text_embeds": torch.randn(B, cfg.pooled_dim),
+                             "time_ids": torch.tensor([[128, 128, 0, 0, 128, 128]] * B)})
+    assert list(st.keys()) == tap_names(cfg)
+    assert st["d0"].shape == (B, 64, 8, 8) and st["m"].shape == (B, 128, 4, 4) and st["u2"].shape == (B, 64, 16, 16)
+
+
+def test_kd_loss_nan_guard_and_masks():
+    torch.manual_seed(0)
+    a, b, c = torch.randn(3, 4, 4, 4), torch.randn(3, 4, 4, 4), torch.randn(3, 4, 4, 4)
+    fs, ft = [torch.randn(3, 8, 2, 2), torch.randn(3, 8, 2, 2)], [torch.randn(3, 8, 2, 2), torch.randn(3, 8, 2, 2)]
+    zh = torch.tensor([1, 0, 0])
+    tot, l0, l1, l2 = kd_losses(a, b, c, fs, ft, zh)
+    # masks are NOT renormalised: mean over all B samples (train_sdxl_zh.py:405,417,429)
+    assert abs(float(l0) - float(((a - b) ** 2)[0].mean() / 3)) < 1e-6
+    assert abs(float(l1) - float((((a - c) ** 2)[1:].mean([1, 2, 3])).sum() / 3)) < 1e-6
+    assert abs(float(tot) - float(l0 + l1 + 0.1 * l2)) < 1e-6
+    ft[1][1, 0, 0, 0] = float("nan")
+    _, _, _, l2g = kd_losses(a, b, c, fs, ft, zh, nan_guard=True)
+    _, _, _, l2_first = kd_losses(a, b, c, fs[:1], ft[:1], zh)
+    assert abs(float(l2g) - float(l2_first)) < 1e-7
