@@ -1,0 +1,104 @@
+"""ctypes loader for libpea_hip.so (the C ABI declared in include/pea_hip.h).
+
+The prototypes are parsed from the header itself so the Python side can never drift from the
+C declarations.  Loading fails loudly when the shared library is missing: there is no CPU
+fallback for the product path.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import re
+import subprocess
+from typing import Dict, List, Tuple
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(_HERE)
+HEADER = os.path.join(ROOT, "include", "pea_hip.h")
+LIB_PATH = os.path.join(_HERE, "libpea_hip.so")
+CSRC = os.path.join(_HERE, "csrc")
+
+
+class PeaError(RuntimeError):
+    pass
+
+
+_CT = {
+    "int": ctypes.c_int, "float": ctypes.c_float, "long long": ctypes.c_longlong, "double": ctypes.c_double,
+    "uint64_t": ctypes.c_uint64, "unsigned long long": ctypes.c_ulonglong,
+}
+
+
+def _ctype(decl: str):
+    d = decl.replace("const", " ").strip()
+    d = re.sub(r"\s+", " ", d)
+    if d.endswith("*"):
+        if d.replace(" ", "") == "char*":
+            return ctypes.c_char_p
+        return ctypes.c_void_p
+    return _CT[d]
+
+
+def parse_header(path: str = HEADER) -> Dict[str, Tuple[object, List[object]]]:
+    """-> {name: (restype, [argtypes])} for every `pea_*` prototype in the header."""
+    src = open(path).read()
+    src = re.sub(r"/\*.*?\*/", " ", src, flags=re.S)
+    src = re.sub(r"//[^\n]*", " ", src)
+    protos = {}
+    for m in re.finditer(r"([A-Za-z_][\w\s\*]*?)\b(pea_\w+)\s*\(([^;{]*?)\)\s*;", src):
+        ret, name, args = m.group(1).strip(), m.group(2), m.group(3).strip()
+        argtypes = []
+        if args and args != "void":
+            for a in args.split(","):
+                a = a.strip()
+                a = re.sub(r"\b[A-Za-z_]\w*$", "", a).strip() if not a.endswith("*") else a   # drop the name
+                argtypes.append(_ctype(a))
+        restype = None if ret == "void" else _ctype(ret)
+        protos[name] = (restype, argtypes)
+    return protos
+
+
+def build(verbose: bool = False) -> str:
+    """Compile every HIP source for gfx950 into pea_diffusion_amd/libpea_hip.so (in-tree)."""
+    r = subprocess.run(["make", "-C", CSRC, "-j8"], capture_output=True, text=True)
+    if verbose or r.returncode != 0:
+        print(r.stdout[-4000:], r.stderr[-4000:])
+    if r.returncode != 0:
+        raise PeaError("building libpea_hip.so failed")
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib() -> ctypes.CDLL:
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise PeaError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                           "(there is no CPU fallback for the HIP path)")
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (restype, argtypes) in parse_header().items():
+            fn = getattr(L, name)          # AttributeError if the library lacks a declared symbol
+            fn.restype = restype
+            fn.argtypes = argtypes
+        _lib = L
+    return _lib
+
+
+def check(rc: int):
+    if rc != 0:
+        raise PeaError(f"pea error {rc}: {lib().pea_last_error().decode()}")
+
+
+def ptr(t):
+    """device pointer of a torch tensor (or None)."""
+    if t is None:
+        return None
+    assert t.is_contiguous() or t.numel() == 0, "non-contiguous tensor passed to the C ABI"
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def stream_ptr():
+    import torch
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)

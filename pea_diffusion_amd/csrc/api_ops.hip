@@ -1,0 +1,186 @@
+// C-ABI, operator level: thin argument marshalling onto the kernel launchers (include/pea_hip.h).
+#include <stdarg.h>
+#include <string.h>
+
+#include "../../include/pea_hip.h"
+#include "pea_kernels.h"
+
+static thread_local char g_err[512] = "";
+void pea_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+static bf16* g_zero_page = nullptr;
+int pea_zero_page(const bf16** out) {
+  if (!g_zero_page) {
+    HIPCHK(hipMalloc((void**)&g_zero_page, 256));
+    HIPCHK(hipMemset(g_zero_page, 0, 256));
+  }
+  *out = g_zero_page;
+  return PEA_OK;
+}
+
+extern "C" {
+
+const char* pea_last_error(void) { return g_err; }
+int pea_version(void) { return 100; }
+int pea_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+int pea_op_gemm(const void* A, int lda, const void* W, int ldw, void* C, int ldc, int M, int N, int K, float alpha,
+                const float* bias, const void* rowvec, int ldrv, int rows_per_batch, int act, void* preact,
+                int ldpre, const void* res, int ldres, int out_f32, int accum_f32, void* stream) {
+  GemmP p;
+  memset(&p, 0, sizeof(p));
+  p.mode = 0;
+  p.A = (const bf16*)A; p.lda = lda; p.W = (const bf16*)W; p.ldw = ldw; p.C = C; p.ldc = ldc;
+  p.M = M; p.N = N; p.K = K; p.alpha = alpha; p.bias = bias;
+  p.rowvec = (const bf16*)rowvec; p.ldrv = ldrv; p.rows_per_batch = rows_per_batch > 0 ? rows_per_batch : 1;
+  p.act = act; p.preact = (bf16*)preact; p.ldpre = ldpre; p.res = (const bf16*)res; p.ldres = ldres;
+  p.out_f32 = out_f32; p.accum_f32 = accum_f32;
+  return launch_gemm(p, (hipStream_t)stream);
+}
+
+int pea_op_conv3x3(const void* x, const void* w, void* y, int B, int Hs, int Ws, int Cin, int Cout, int stride,
+                   int upsample2x, int transposed2, const float* bias, const void* rowvec, int ldrv,
+                   const void* res, void* stream) {
+  GemmP p;
+  memset(&p, 0, sizeof(p));
+  p.mode = 1;
+  p.A = (const bf16*)x; p.W = (const bf16*)w; p.ldw = 9 * Cin; p.C = y; p.ldc = Cout;
+  p.Hs = Hs; p.Ws = Ws; p.Cin = Cin;
+  p.shift = (upsample2x || transposed2) ? 1 : 0;
+  p.parity = transposed2 ? 1 : 0;
+  p.stride = stride;
+  const int Hv = Hs << p.shift, Wv = Ws << p.shift;
+  p.Ho = stride == 2 ? (Hv + 1) / 2 : Hv;
+  p.Wo = stride == 2 ? (Wv + 1) / 2 : Wv;
+  p.M = B * p.Ho * p.Wo; p.N = Cout; p.K = 9 * Cin; p.alpha = 1.f; p.bias = bias;
+  p.rowvec = (const bf16*)rowvec; p.ldrv = ldrv; p.rows_per_batch = p.Ho * p.Wo;
+  p.res = (const bf16*)res; p.ldres = Cout;
+  int rc = pea_zero_page(&p.zeros);
+  if (rc) return rc;
+  return launch_gemm(p, (hipStream_t)stream);
+}
+
+int pea_op_pack_conv(const float* w, void* out, int Co, int Ci, int dgrad, void* stream) {
+  return dgrad ? launch_pack_conv_dgrad(w, (bf16*)out, Co, Ci, (hipStream_t)stream)
+               : launch_pack_conv_fwd(w, (bf16*)out, Co, Ci, (hipStream_t)stream);
+}
+int pea_op_pack_conv_out(const float* w, float* out, int Co, int Ci, void* stream) {
+  return launch_pack_conv_out(w, out, Co, Ci, (hipStream_t)stream);
+}
+int pea_op_conv_in(const float* x, const float* w, const float* bias, void* y, int B, int Cin, int H, int W,
+                   int Cout, void* stream) {
+  return launch_conv_in(x, w, bias, (bf16*)y, B, Cin, H, W, Cout, (hipStream_t)stream);
+}
+int pea_op_conv_out(const void* x, const float* w, const float* bias, float* y, int B, int Cin, int H, int W,
+                    int Cout, void* stream) {
+  return launch_conv_out((const bf16*)x, w, bias, y, B, Cin, H, W, Cout, (hipStream_t)stream);
+}
+int pea_op_conv_out_dgrad(const float* dy, const float* w, void* dx, int B, int Cin, int H, int W, int Cout,
+                          void* stream) {
+  return launch_conv_out_dgrad(dy, w, (bf16*)dx, B, Cin, H, W, Cout, (hipStream_t)stream);
+}
+
+int pea_op_groupnorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* stats, void* scratch,
+                         int B, int HW, int C, int groups, float eps, int silu, void* stream) {
+  return launch_groupnorm_fwd((const bf16*)x, gamma, beta, (bf16*)y, stats, (double*)scratch, B, HW, C, groups, eps,
+                              silu, (hipStream_t)stream);
+}
+int pea_op_groupnorm_bwd(const void* x, const void* dy, const float* gamma, const float* beta, const float* stats,
+                         void* dx, void* scratch, int B, int HW, int C, int groups, int silu, int accum,
+                         void* stream) {
+  return launch_groupnorm_bwd((const bf16*)x, (const bf16*)dy, gamma, beta, stats, (bf16*)dx, (double*)scratch, B, HW,
+                              C, groups, silu, accum, (hipStream_t)stream);
+}
+int pea_op_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* stats, int R, int C,
+                         float eps, void* stream) {
+  return launch_layernorm_fwd((const bf16*)x, gamma, beta, (bf16*)y, stats, R, C, eps, (hipStream_t)stream);
+}
+int pea_op_layernorm_bwd(const void* x, const void* dy, const float* gamma, const float* stats, void* dx,
+                         float* dgamma, float* dbeta, int R, int C, int accum, void* stream) {
+  return launch_layernorm_bwd((const bf16*)x, (const bf16*)dy, gamma, stats, (bf16*)dx, dgamma, dbeta, R, C, accum,
+                              (hipStream_t)stream);
+}
+
+int pea_op_attention_fwd(const void* Q, int ldq, const void* K, int ldk, const void* V, int ldv, void* O, int ldo,
+                         float* lse, int B, int H, int Sq, int Skv, float scale, void* stream) {
+  AttnP p;
+  memset(&p, 0, sizeof(p));
+  p.Q = (const bf16*)Q; p.K = (const bf16*)K; p.V = (const bf16*)V; p.ldq = ldq; p.ldk = ldk; p.ldv = ldv;
+  p.O = (bf16*)O; p.ldo = ldo; p.lse = lse; p.B = B; p.H = H; p.Sq = Sq; p.Skv = Skv; p.scale = scale;
+  return launch_attention_fwd(p, (hipStream_t)stream);
+}
+int pea_op_attention_bwd(const void* Q, int ldq, const void* K, int ldk, const void* V, int ldv, const void* O,
+                         int ldo, const void* dO, int lddo, const float* lse, float* delta, void* dQ, int lddq,
+                         void* dK, int lddk, void* dV, int lddv, int B, int H, int Sq, int Skv, float scale,
+                         int accum_dq, int accum_dkv, void* stream) {
+  AttnP p;
+  memset(&p, 0, sizeof(p));
+  p.Q = (const bf16*)Q; p.K = (const bf16*)K; p.V = (const bf16*)V; p.ldq = ldq; p.ldk = ldk; p.ldv = ldv;
+  p.O = (bf16*)O; p.ldo = ldo; p.lse = (float*)lse; p.B = B; p.H = H; p.Sq = Sq; p.Skv = Skv; p.scale = scale;
+  p.dO = (const bf16*)dO; p.lddo = lddo; p.delta = delta;
+  p.dQ = (bf16*)dQ; p.lddq = lddq; p.dK = (bf16*)dK; p.lddk = lddk; p.dV = (bf16*)dV; p.lddv = lddv;
+  p.accum_dq = accum_dq; p.accum_dkv = accum_dkv;
+  return launch_attention_bwd(p, (hipStream_t)stream);
+}
+
+int pea_op_geglu_fwd(const void* hg, void* y, long long rows, int inner, void* stream) {
+  return launch_geglu_fwd((const bf16*)hg, (bf16*)y, rows, inner, (hipStream_t)stream);
+}
+int pea_op_geglu_bwd(const void* hg, const void* dy, void* dhg, long long rows, int inner, void* stream) {
+  return launch_geglu_bwd((const bf16*)hg, (const bf16*)dy, (bf16*)dhg, rows, inner, (hipStream_t)stream);
+}
+int pea_op_sumpool2(const void* x, void* y, int B, int H, int W, int C, int accum, void* stream) {
+  return launch_sumpool2((const bf16*)x, (bf16*)y, B, H, W, C, accum, (hipStream_t)stream);
+}
+int pea_op_timestep_embed(const float* t, void* y, int n, int dim, void* stream) {
+  return launch_timestep_embed(t, (bf16*)y, n, dim, (hipStream_t)stream);
+}
+int pea_op_add_noise(const float* x0, const float* eps, const long long* t, const float* ac, float* xt, int B,
+                     long long per, void* stream) {
+  return launch_add_noise(x0, eps, t, ac, xt, B, per, (hipStream_t)stream);
+}
+int pea_op_cast_f32_bf16(const float* x, void* y, long long n, void* stream) {
+  return launch_cast_f32_bf16(x, (bf16*)y, n, (hipStream_t)stream);
+}
+int pea_op_cast_bf16_f32(const void* x, float* y, long long n, void* stream) {
+  return launch_cast_bf16_f32((const bf16*)x, y, n, (hipStream_t)stream);
+}
+
+int pea_op_kd_loss(int ntaps, const void* const* taps_s, const void* const* taps_t, void* const* dtaps,
+                   const long long* per, const float* eps_s, const float* eps, const float* eps_t, float* deps_s,
+                   long long per_eps, const long long* zh, int B, float feat_weight, int nan_guard,
+                   float grad_scale, float* losses, void* workspace, void* stream) {
+  if (ntaps < 0 || ntaps > PEA_MAX_TAPS) {
+    pea_set_error("kd_loss: ntaps=%d out of range", ntaps);
+    return PEA_E_SHAPE;
+  }
+  KdLossP p;
+  memset(&p, 0, sizeof(p));
+  p.ntaps = ntaps;
+  for (int k = 0; k < ntaps; ++k) {
+    p.fs[k] = (const bf16*)taps_s[k];
+    p.ft[k] = (const bf16*)taps_t[k];
+    p.dfs[k] = dtaps ? (bf16*)dtaps[k] : nullptr;
+    p.per[k] = per[k];
+  }
+  p.eps_s = eps_s; p.eps = eps; p.eps_t = eps_t; p.deps_s = deps_s; p.per_eps = per_eps; p.zh = zh; p.B = B;
+  p.feat_weight = feat_weight; p.nan_guard = nan_guard; p.grad_scale = grad_scale; p.losses = losses;
+  p.partial = (float*)workspace;
+  return launch_kd_loss(p, (hipStream_t)stream);
+}
+
+int pea_op_adamw(float* w, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2,
+                 float eps, float weight_decay, int step, float grad_scale, void* stream) {
+  return launch_adamw(w, g, m, v, n, lr, beta1, beta2, eps, weight_decay, step, grad_scale, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,437 @@
+// Flash-style fused attention for head_dim 64 (SDXL: 10 heads x 4096 tokens, 20 heads x 1024
+// tokens, cross-attention with <= 77 keys), forward + data-gradient backward.
+//
+// Replaces diffusers' AttnProcessor2_0 -> F.scaled_dot_product_attention inside the
+// UNet calls of train_sdxl_zh.py:397,415 and its autograd backward.
+//
+// Forward / dQ kernels: a workgroup = 4 waves = 128 queries, each wave owns 32 queries.  The
+// scores are computed TRANSPOSED, S^T = K . Q^T (v_mfma_f32_32x32x16_bf16 with K rows as the A
+// operand), so a lane holds one query column and 32 keys in registers: the softmax row
+// reduction is in-lane plus one cross-half shuffle, and the bf16-packed P^T accumulator is
+// directly the B operand of O^T = V^T . P^T (no LDS round trip for P).  V^T fragments come from
+// the row-major V tile in LDS through ds_read_b64_tr_b16 (hardware transpose read).
+// dK/dV kernel: a wave owns 32 keys (key on the lane), loops over query tiles; P and dS
+// accumulators feed dV^T = dO^T . P and dK^T = Q^T . dS directly; Q / dO tiles are read
+// row-wise for S / dP and through the transpose read for the two gradient products.
+// K/V (or Q/dO) tiles are 64 x 64 bf16 (128-byte rows) staged by LDS-DMA into a 2-deep ring
+// with the same source-side XOR swizzle as gemm.hip.
+#include "pea_kernels.h"
+
+#define TILE_BYTES 8192   // 64 rows x 128 bytes
+#define LOG2E 1.4426950408889634f
+
+__device__ __forceinline__ int swz_rc(int row, int col) {   // byte offset of element (row, col) in a tile
+  return row * 128 + ((((col >> 3)) ^ ((row >> 1) & 7)) << 4) + (col & 7) * 2;
+}
+
+// stage a 64x64 tile: rows r0.. (clamped to rmax-1) of `src` (row stride ld elements) -> dst (LDS)
+__device__ __forceinline__ void stage_tile(const bf16* src, int ld, int r0, int rmax, char* dst, int wave, int lane) {
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int piece = wave * 2 + j;
+    const int r = piece * 8 + (lane >> 3);
+    const int chunk = (lane & 7) ^ ((r >> 1) & 7);
+    int gr = r0 + r;
+    gr = gr < rmax ? gr : rmax - 1;
+    __builtin_amdgcn_global_load_lds(PEA_GLB(src + (long long)gr * ld + chunk * 8), PEA_LDS(dst + piece * 1024), 16,
+                                     0, 0);
+  }
+}
+
+// MFMA A-operand fragment of T^T for the k-permuted accumulator-as-operand product:
+// elements j=0..3 <- rows kbase+4h+j, j=4..7 <- rows kbase+8+4h+(j-4) of the LDS tile, column c0 + (lane&31)
+template <bool USE_TR>
+__device__ __forceinline__ bf16x8 read_transposed_frag(const char* tile, int kbase, int c0, int lane) {
+  bf16x8 out;
+  const int h = lane >> 5;
+  if (USE_TR) {
+    const int i = lane & 15;
+    const int col = c0 + 16 * ((lane >> 4) & 1) + 4 * (i & 3);
+    const int row = kbase + 4 * h + (i >> 2);
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+        (__attribute__((address_space(3))) s16x4*)PEA_LDS(tile + swz_rc(row, col)));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+        (__attribute__((address_space(3))) s16x4*)PEA_LDS(tile + swz_rc(row + 8, col)));
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      short a = lo[j], b = hi[j];
+      out[j] = *(bf16*)&a;
+      out[4 + j] = *(bf16*)&b;
+    }
+  } else {
+    const int col = c0 + (lane & 31);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int row = kbase + 8 * (j >> 2) + 4 * h + (j & 3);
+      out[j] = *(const bf16*)(tile + swz_rc(row, col));
+    }
+  }
+  return out;
+}
+
+__device__ __forceinline__ bf16x8 read_row_frag(const char* tile, int row, int s, int h) {
+  return *(const bf16x8*)(tile + row * 128 + ((((2 * s + h)) ^ ((row >> 1) & 7)) << 4));
+}
+
+// ============================================================================= forward / dQ
+// MODE 0: forward (writes O, lse).  MODE 1: dQ (reads dO, lse, delta; writes dQ).
+template <int MODE, bool USE_TR>
+__global__ __launch_bounds__(256) void attn_q_kernel(const AttnP p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 stages][K tile | V tile]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int head = blockIdx.y, b = blockIdx.z;
+  const int q0 = blockIdx.x * 128 + wave * 32;
+  const int frow = lane & 31, fh = lane >> 5;
+  const float c = p.scale * LOG2E;
+
+  const bf16* Qb = p.Q + (long long)b * p.Sq * p.ldq + head * 64;
+  const bf16* Kb = p.K + (long long)b * p.Skv * p.ldk + head * 64;
+  const bf16* Vb = p.V + (long long)b * p.Skv * p.ldv + head * 64;
+
+  int qrow = q0 + frow;
+  const bool qvalid = qrow < p.Sq;
+  qrow = qvalid ? qrow : p.Sq - 1;
+  bf16x8 qf[4], dof[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) qf[s] = *(const bf16x8*)(Qb + (long long)qrow * p.ldq + 16 * s + 8 * fh);
+  float lse2 = 0.f, dlt = 0.f;
+  if (MODE == 1) {
+    const bf16* dOb = p.dO + (long long)b * p.Sq * p.lddo + head * 64;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) dof[s] = *(const bf16x8*)(dOb + (long long)qrow * p.lddo + 16 * s + 8 * fh);
+    const long long li = ((long long)b * p.H + head) * p.Sq + qrow;
+    lse2 = p.lse[li] * LOG2E;
+    dlt = p.delta[li];
+  }
+
+  f32x16 oacc[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) oacc[i][r] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+
+  const int nt = (p.Skv + 63) / 64;
+  stage_tile(Kb, p.ldk, 0, p.Skv, smem, wave, lane);
+  stage_tile(Vb, p.ldv, 0, p.Skv, smem + TILE_BYTES, wave, lane);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  for (int t = 0; t < nt; ++t) {
+    const int cur = t & 1;
+    if (t + 1 < nt) {
+      char* nx = smem + (cur ^ 1) * 2 * TILE_BYTES;
+      stage_tile(Kb, p.ldk, (t + 1) * 64, p.Skv, nx, wave, lane);
+      stage_tile(Vb, p.ldv, (t + 1) * 64, p.Skv, nx + TILE_BYTES, wave, lane);
+    }
+    const char* Ks = smem + cur * 2 * TILE_BYTES;
+    const char* Vs = Ks + TILE_BYTES;
+
+    // S^T[key][q] = K . Q^T
+    f32x16 sacc[2];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sacc[kb][r] = 0.f;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const bf16x8 kf = read_row_frag(Ks, kb * 32 + frow, s, fh);
+        sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], sacc[kb], 0, 0, 0);
+      }
+    }
+    const int kv0 = t * 64;
+    bf16x8 pf[4];   // P^T (fwd) or dS^T (dQ) as B-operand fragments, k-permuted
+    if (MODE == 0) {
+      float mx = -INFINITY;
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = kv0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+          float v = sacc[kb][r] * c;
+          v = key < p.Skv ? v : -INFINITY;
+          sacc[kb][r] = v;
+          mx = fmaxf(mx, v);
+        }
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float m_new = fmaxf(m_run, mx);
+      const float alpha = exp2f(m_run - m_new);
+      m_run = m_new;
+      float ls = 0.f;
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float e = exp2f(sacc[kb][r] - m_new);
+          sacc[kb][r] = e;
+          ls += e;
+        }
+      l_run = l_run * alpha + ls;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[i][r] *= alpha;
+    } else {
+      // P^T = exp2(c S^T - lse2[q]);  dP^T = V . dO^T;  dS^T = P^T (dP^T - delta[q]) scale
+      f32x16 dpacc[2];
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dpacc[kb][r] = 0.f;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          const bf16x8 vf = read_row_frag(Vs, kb * 32 + frow, s, fh);
+          dpacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, dof[s], dpacc[kb], 0, 0, 0);
+        }
+      }
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = kv0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+          const float pr = key < p.Skv ? exp2f(sacc[kb][r] * c - lse2) : 0.f;
+          sacc[kb][r] = pr * (dpacc[kb][r] - dlt) * p.scale;
+        }
+    }
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) pf[ks][j] = (bf16)sacc[ks >> 1][8 * (ks & 1) + j];
+
+    // fwd: O^T[d][q] += V^T[d][key] P^T[key][q];   dQ: dQ^T[d][q] += K^T[d][key] dS^T[key][q]
+    const char* Ts = MODE == 0 ? Vs : Ks;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+      for (int db = 0; db < 2; ++db) {
+        const bf16x8 tf = read_transposed_frag<USE_TR>(Ts, ks * 16, db * 32, lane);
+        oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tf, pf[ks], oacc[db], 0, 0, 0);
+      }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+
+  // epilogue: oacc[db][4g+j] = X^T[d = db*32 + 8g + 4h + j][q = lane&31]
+  float inv = 1.f;
+  if (MODE == 0) {
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    inv = 1.f / l_tot;
+    if (p.lse && qvalid && fh == 0)
+      p.lse[((long long)b * p.H + head) * p.Sq + qrow] = (m_run + log2f(l_tot)) * 0.6931471805599453f;
+  }
+  if (!qvalid) return;
+  bf16* Ob = MODE == 0 ? p.O + (long long)b * p.Sq * p.ldo + head * 64 + (long long)qrow * p.ldo
+                       : p.dQ + (long long)b * p.Sq * p.lddq + head * 64 + (long long)qrow * p.lddq;
+  const bool accum = MODE == 1 && p.accum_dq;
+#pragma unroll
+  for (int db = 0; db < 2; ++db)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      bf16* dst = Ob + db * 32 + 8 * g + 4 * fh;
+      bf16x4 o;
+      if (accum) o = *(const bf16x4*)dst;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) o[j] = (bf16)(oacc[db][4 * g + j] * inv + (accum ? (float)o[j] : 0.f));
+      *(bf16x4*)dst = o;
+    }
+}
+
+// ============================================================================= dK / dV
+// workgroup = 4 waves = 128 keys (wave owns 32, key on the lane); loops over 64-query tiles.
+template <bool USE_TR>
+__global__ __launch_bounds__(256) void attn_dkv_kernel(const AttnP p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 stages][Q tile | dO tile]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int head = blockIdx.y, b = blockIdx.z;
+  const int k0 = blockIdx.x * 128 + wave * 32;
+  const int frow = lane & 31, fh = lane >> 5;
+  const float c = p.scale * LOG2E;
+
+  const bf16* Qb = p.Q + (long long)b * p.Sq * p.ldq + head * 64;
+  const bf16* dOb = p.dO + (long long)b * p.Sq * p.lddo + head * 64;
+  const bf16* Kb = p.K + (long long)b * p.Skv * p.ldk + head * 64;
+  const bf16* Vb = p.V + (long long)b * p.Skv * p.ldv + head * 64;
+  const float* lseb = p.lse + ((long long)b * p.H + head) * p.Sq;
+  const float* dltb = p.delta + ((long long)b * p.H + head) * p.Sq;
+
+  int krow = k0 + frow;
+  const bool kvalid = krow < p.Skv;
+  krow = kvalid ? krow : p.Skv - 1;
+  const bool wave_active = k0 < p.Skv;       // wave-uniform
+  bf16x8 kf[4], vf[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    kf[s] = *(const bf16x8*)(Kb + (long long)krow * p.ldk + 16 * s + 8 * fh);
+    vf[s] = *(const bf16x8*)(Vb + (long long)krow * p.ldv + 16 * s + 8 * fh);
+  }
+  f32x16 dk[2], dv[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dk[i][r] = dv[i][r] = 0.f;
+
+  const int nt = (p.Sq + 63) / 64;
+  stage_tile(Qb, p.ldq, 0, p.Sq, smem, wave, lane);
+  stage_tile(dOb, p.lddo, 0, p.Sq, smem + TILE_BYTES, wave, lane);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  for (int t = 0; t < nt; ++t) {
+    const int cur = t & 1;
+    if (t + 1 < nt) {
+      char* nx = smem + (cur ^ 1) * 2 * TILE_BYTES;
+      stage_tile(Qb, p.ldq, (t + 1) * 64, p.Sq, nx, wave, lane);
+      stage_tile(dOb, p.lddo, (t + 1) * 64, p.Sq, nx + TILE_BYTES, wave, lane);
+    }
+    const char* Qs = smem + cur * 2 * TILE_BYTES;
+    const char* dOs = Qs + TILE_BYTES;
+    if (wave_active) {
+      // S[q][key] = Q . K^T ; dP[q][key] = dO . V^T   (rows q in registers, key on the lane)
+      f32x16 sacc[2], dpacc[2];
+#pragma unroll
+      for (int qb = 0; qb < 2; ++qb) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sacc[qb][r] = dpacc[qb][r] = 0.f;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          const bf16x8 qfr = read_row_frag(Qs, qb * 32 + frow, s, fh);
+          sacc[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qfr, kf[s], sacc[qb], 0, 0, 0);
+          const bf16x8 dfr = read_row_frag(dOs, qb * 32 + frow, s, fh);
+          dpacc[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dfr, vf[s], dpacc[qb], 0, 0, 0);
+        }
+      }
+      bf16x8 pfr[4], dsfr[4];
+#pragma unroll
+      for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int q = t * 64 + qb * 32 + 8 * g + 4 * fh;     // 4 consecutive query rows
+          f32x4 l4, d4;
+          if (q < p.Sq) {                                      // Sq % 4 == 0: all-or-nothing
+            l4 = *(const f32x4*)(lseb + q);
+            d4 = *(const f32x4*)(dltb + q);
+          } else {
+            l4 = (f32x4){INFINITY, INFINITY, INFINITY, INFINITY};
+            d4 = (f32x4){0.f, 0.f, 0.f, 0.f};
+          }
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int r = 4 * g + j;
+            const float pr = kvalid ? exp2f(sacc[qb][r] * c - l4[j] * LOG2E) : 0.f;
+            const float ds = pr * (dpacc[qb][r] - d4[j]) * p.scale;
+            const int ks = qb * 2 + (g >> 1), e = (g & 1) * 4 + j;
+            pfr[ks][e] = (bf16)pr;
+            dsfr[ks][e] = (bf16)ds;
+          }
+        }
+      // dV^T[d][key] += dO^T[d][q] P[q][key] ;  dK^T[d][key] += Q^T[d][q] dS[q][key]
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+        for (int db = 0; db < 2; ++db) {
+          const bf16x8 dot = read_transposed_frag<USE_TR>(dOs, ks * 16, db * 32, lane);
+          dv[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dot, pfr[ks], dv[db], 0, 0, 0);
+          const bf16x8 qt = read_transposed_frag<USE_TR>(Qs, ks * 16, db * 32, lane);
+          dk[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qt, dsfr[ks], dk[db], 0, 0, 0);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+  if (!kvalid) return;
+  bf16* dKr = p.dK + ((long long)b * p.Skv + krow) * p.lddk + head * 64;
+  bf16* dVr = p.dV + ((long long)b * p.Skv + krow) * p.lddv + head * 64;
+#pragma unroll
+  for (int db = 0; db < 2; ++db)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int d = db * 32 + 8 * g + 4 * fh;
+      bf16x4 ok, ov;
+      if (p.accum_dkv) {
+        ok = *(const bf16x4*)(dKr + d);
+        ov = *(const bf16x4*)(dVr + d);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        ok[j] = (bf16)(dk[db][4 * g + j] + (p.accum_dkv ? (float)ok[j] : 0.f));
+        ov[j] = (bf16)(dv[db][4 * g + j] + (p.accum_dkv ? (float)ov[j] : 0.f));
+      }
+      *(bf16x4*)(dKr + d) = ok;
+      *(bf16x4*)(dVr + d) = ov;
+    }
+}
+
+// delta[b][h][q] = sum_d dO[q][h*64+d] * O[q][h*64+d]; one wave per 8 (q,head) rows
+__global__ __launch_bounds__(256) void attn_delta_kernel(const AttnP p) {
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;   // one thread per (b, q, head, 8-chunk)
+  const long long total = (long long)p.B * p.Sq * p.H * 8;
+  const int sub = (int)(idx & 7);
+  float s = 0.f;
+  long long row = idx >> 3;
+  if (idx < total) {
+    const int head = (int)(row % p.H);
+    const long long bq = row / p.H;
+    const bf16x8 a = *(const bf16x8*)(p.dO + bq * p.lddo + head * 64 + sub * 8);
+    const bf16x8 o = *(const bf16x8*)(p.O + bq * p.ldo + head * 64 + sub * 8);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s += (float)a[j] * (float)o[j];
+  }
+  s += __shfl_xor(s, 1, 64);
+  s += __shfl_xor(s, 2, 64);
+  s += __shfl_xor(s, 4, 64);
+  if (idx < total && sub == 0) {
+    const int head = (int)(row % p.H);
+    const long long bq = row / p.H;
+    const int b = (int)(bq / p.Sq), q = (int)(bq % p.Sq);
+    p.delta[((long long)b * p.H + head) * p.Sq + q] = s;
+  }
+}
+
+static int g_attn_use_tr = 1;
+extern "C" void pea_debug_set_attn_tr(int v) { g_attn_use_tr = v; }
+
+static int attn_check(const AttnP& p) {
+  SHAPECHK(p.B > 0 && p.H > 0 && p.Sq > 0 && p.Skv > 0, "attention: empty problem");
+  SHAPECHK(p.Sq % 4 == 0, "attention: Sq=%d must be a multiple of 4", p.Sq);
+  SHAPECHK(p.ldq % 8 == 0 && p.ldk % 8 == 0 && p.ldv % 8 == 0, "attention: leading dims must be multiples of 8");
+  return PEA_OK;
+}
+
+int launch_attention_fwd(const AttnP& p, hipStream_t s) {
+  int rc = attn_check(p);
+  if (rc) return rc;
+  SHAPECHK(p.ldo % 4 == 0, "attention: ldo %% 4");
+  const dim3 grid(cdiv(p.Sq, 128), p.H, p.B);
+  if (g_attn_use_tr)
+    hipLaunchKernelGGL((attn_q_kernel<0, true>), grid, dim3(256), 4 * TILE_BYTES, s, p);
+  else
+    hipLaunchKernelGGL((attn_q_kernel<0, false>), grid, dim3(256), 4 * TILE_BYTES, s, p);
+  HIPCHK(hipGetLastError());
+  return PEA_OK;
+}
+
+int launch_attention_bwd(const AttnP& p, hipStream_t s) {
+  int rc = attn_check(p);
+  if (rc) return rc;
+  SHAPECHK(p.lse && p.delta && p.dO && p.O, "attention bwd: lse/delta/dO/O required");
+  const long long total = (long long)p.B * p.Sq * p.H * 8;
+  hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)cdivl(total, 256)), dim3(256), 0, s, p);
+  if (p.dQ) {
+    const dim3 grid(cdiv(p.Sq, 128), p.H, p.B);
+    if (g_attn_use_tr)
+      hipLaunchKernelGGL((attn_q_kernel<1, true>), grid, dim3(256), 4 * TILE_BYTES, s, p);
+    else
+      hipLaunchKernelGGL((attn_q_kernel<1, false>), grid, dim3(256), 4 * TILE_BYTES, s, p);
+  }
+  if (p.dK && p.dV) {
+    const dim3 grid(cdiv(p.Skv, 128), p.H, p.B);
+    if (g_attn_use_tr)
+      hipLaunchKernelGGL((attn_dkv_kernel<true>), grid, dim3(256), 4 * TILE_BYTES, s, p);
+    else
+      hipLaunchKernelGGL((attn_dkv_kernel<false>), grid, dim3(256), 4 * TILE_BYTES, s, p);
+  }
+  HIPCHK(hipGetLastError());
+  return PEA_OK;
+}

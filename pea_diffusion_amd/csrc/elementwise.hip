@@ -1,0 +1,432 @@
+// HBM-bound glue kernels: GEGLU, SiLU/GELU, residual add, concat/split, 2x2 sum-pool,
+// casts/transposes/weight repacks, timestep embedding, add_noise, CFG-dropout select,
+// token mean, column sums, RNG fill, fused AdamW.  16 bytes per lane everywhere.
+//
+// Reference call sites: GEGLU / residual adds / concat / upsample inside diffusers' UNet
+// (train_sdxl_zh.py:397,415); add_noise train_sdxl_zh.py:322; `torch.where` CFG dropout
+// train_sdxl_zh.py:395,413; `torch.mean(x,1)` train_sdxl_zh.py:66; FusedAdam
+// utils/model_utils.py:64-67.
+#include "pea_kernels.h"
+
+#define EW_GRID(n8) ((int)(cdivl((n8), 256) < 8192 ? cdivl((n8), 256) : 8192))
+#define EW_LOOP(i, n) \
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < (n); i += (long long)gridDim.x * blockDim.x)
+
+// ---- GEGLU: hg [rows][2*inner] = (h | gate);  y = h * gelu(gate)
+__global__ void geglu_fwd_kernel(const bf16* __restrict__ hg, bf16* __restrict__ y, long long rows, int inner) {
+  const int ck = inner / 8;
+  const long long total = rows * ck;
+  EW_LOOP(i, total) {
+    const long long r = i / ck;
+    const int c = (int)(i - r * ck) * 8;
+    const bf16x8 h = *(const bf16x8*)(hg + r * 2 * inner + c);
+    const bf16x8 g = *(const bf16x8*)(hg + r * 2 * inner + inner + c);
+    bf16x8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = (bf16)((float)h[j] * gelu_erf((float)g[j]));
+    *(bf16x8*)(y + r * inner + c) = o;
+  }
+}
+__global__ void geglu_bwd_kernel(const bf16* __restrict__ hg, const bf16* __restrict__ dy, bf16* __restrict__ dhg,
+                                 long long rows, int inner) {
+  const int ck = inner / 8;
+  const long long total = rows * ck;
+  EW_LOOP(i, total) {
+    const long long r = i / ck;
+    const int c = (int)(i - r * ck) * 8;
+    const bf16x8 h = *(const bf16x8*)(hg + r * 2 * inner + c);
+    const bf16x8 g = *(const bf16x8*)(hg + r * 2 * inner + inner + c);
+    const bf16x8 d = *(const bf16x8*)(dy + r * inner + c);
+    bf16x8 dh, dg;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float gf = (float)g[j], df = (float)d[j];
+      dh[j] = (bf16)(df * gelu_erf(gf));
+      dg[j] = (bf16)(df * (float)h[j] * gelu_erf_grad(gf));
+    }
+    *(bf16x8*)(dhg + r * 2 * inner + c) = dh;
+    *(bf16x8*)(dhg + r * 2 * inner + inner + c) = dg;
+  }
+}
+int launch_geglu_fwd(const bf16* hg, bf16* y, long long rows, int inner, hipStream_t s) {
+  SHAPECHK(inner % 8 == 0, "geglu: inner %% 8");
+  hipLaunchKernelGGL(geglu_fwd_kernel, dim3(EW_GRID(rows * (inner / 8))), dim3(256), 0, s, hg, y, rows, inner);
+  HIPCHK(hipGetLastError());
+  return PEA_OK;
+}
+int launch_geglu_bwd(const bf16* hg, const bf16* dy, bf16* dhg, long long rows, int inner, hipStream_t s) {
+  SHAPECHK(inner % 8 == 0, "geglu: inner %% 8");
+  hipLaunchKernelGGL(geglu_bwd_kernel, dim3(EW_GRID(rows * (inner / 8))), dim3(256), 0, s, hg, dy, dhg, rows, inner);
+  HIPCHK(hipGetLastError());
+  return PEA_OK;
+}
+
+// ---- unary / binary maps on flat bf16 arrays (n % 8 == 0)
+template <int OP>   // 0 add, 1 silu, 2 silu_bwd, 3 gelu, 4 gelu_bwd
+__global__ void map_kernel(const bf16* __restrict__ a, const bf16* __restrict__ b, bf16* __restrict__ y,
+                           long long n8, int accum) {
+  EW_LOOP(i, n8) {
+    const bf16x8 av = *(const bf16x8*)(a + i * 8);
+    bf16x8 bv, o;
+    if (OP == 0 || OP == 2 || OP == 4) bv = *(const bf16x8*)(b + i * 8);
+    if (accum) o = *(const bf16x8*)(y + i * 8);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float x = (float)av[j];
+      float r;
+      if (OP == 0) r = x + (float)bv[j];
+      else if (OP == 1) r = siluf_(x);
+      else if (OP == 2) r = (float)bv[j] * silu_grad(x);
+      else if (OP == 3) r = gelu_erf(x);
+      else r = (float)bv[j] * gelu_erf_grad(x);
+      if (accum) r += (float)o[j];
+      o[j] = (bf16)r;
+    }
+    *(bf16x8*)(y + i * 8) = o;
+  }
+}
+#define MAP_LAUNCH(OP, a, b, y, n, acc)                                                           \
+  SHAPECHK((n) % 8 == 0, "elementwise: n %% 8");                                                  \
+  hipLaunchKernelGGL(map_kernel<OP>, dim3(EW_GRID((n) / 8)), dim3(256), 0, s, a, b, y, (n) / 8, acc); \
+  HIPCHK(hipGetLastError());                                                                      \
+  return PEA_OK;
+int launch_add(const bf16* a, const bf16* b, bf16* y, long long n, hipStream_t s) { MAP_LAUNCH(0, a, b, y, n, 0) }
+int launch_silu_fwd(const bf16* x, bf16* y, long long n, hipStream_t s) { MAP_LAUNCH(1, x, nullptr, y, n, 0) }
+int launch_silu_bwd(const bf16* x, const bf16* dy, bf16* dx, long long n, int accum, hipStream_t s) {
+  MAP_LAUNCH(2, x, dy, dx, n, accum)
+}
+int launch_gelu_fwd(const bf16* x, bf16* y, long long n, hipStream_t s) { MAP_LAUNCH(3, x, nullptr, y, n, 0) }
+int launch_gelu_bwd(const bf16* x, const bf16* dy, bf16* dx, long long n, int accum, hipStream_t s) {
+  MAP_LAUNCH(4, x, dy, dx, n, accum)
+}
+
+// ---- concat / split along the channel (last) dimension
+__global__ void concat2_kernel(const bf16* __restrict__ a, int C1, const bf16* __restrict__ b, int C2,
+                               bf16* __restrict__ y, long long rows) {
+  const int ck = (C1 + C2) / 8, k1 = C1 / 8;
+  EW_LOOP(i, rows * ck) {
+    const long long r = i / ck;
+    const int c = (int)(i - r * ck);
+    const bf16x8 v = c < k1 ? *(const bf16x8*)(a + r * C1 + c * 8) : *(const bf16x8*)(b + r * C2 + (c - k1) * 8);
+    *(bf16x8*)(y + r * (C1 + C2) + c * 8) = v;
+  }
+}
+__global__ void split2_kernel(const bf16* __restrict__ dy, int C1, int C2, bf16* __restrict__ da, int accum_a,
+                              bf16* __restrict__ db, int accum_b, long long rows) {
+  const int ck = (C1 + C2) / 8, k1 = C1 / 8;
+  EW_LOOP(i, rows * ck) {
+    const long long r = i / ck;
+    const int c = (int)(i - r * ck);
+    bf16x8 v = *(const bf16x8*)(dy + r * (C1 + C2) + c * 8);
+    bf16* dst;
+    int acc;
+    if (c < k1) { dst = da ? da + r * C1 + c * 8 : nullptr; acc = accum_a; }
+    else { dst = db ? db + r * C2 + (c - k1) * 8 : nullptr; acc = accum_b; }
+    if (!dst) continue;
+    if (acc) {
+      const bf16x8 o = *(const bf16x8*)dst;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = (bf16)((float)v[j] + (float)o[j]);
+    }
+    *(bf16x8*)dst = v;
+  }
+}
+int launch_concat2(const bf16* a, int C1, const bf16* b, int C2, bf16* y, long long rows, hipStream_t s) {
+  SHAPECHK(C1 % 8 == 0 && C2 % 8 == 0, "concat: C %% 8");
+  hipLaunchKernelGGL(concat2_kernel, dim3(EW_GRID(rows * ((C1 + C2) / 8))), dim3(256), 0, s, a, C1, b, C2, y, rows);
+  HIPCHK(hipGetLastError());
+  return PEA_OK;
+}
+int launch_split2(const bf16* dy, int C1, int C2, bf16* da, int accum_a, bf16* db, int accum_b, long long rows,
+                  hipStream_t s) {
+  SHAPECHK(C1 % 8 == 0 && C2 % 8 == 0, "split: C %% 8");
+  hipLaunchKernelGGL(split2_kernel, dim3(EW_GRID(rows * ((C1 + C2) / 8))), dim3(256), 0, s, dy, C1, C2, da, accum_a,
+                     db, accum_b, rows);
+  HIPCHK(hipGetLastError());
+  return PEA_OK;
+}
+
+// ---- 2x2 sum pooling (backward of nearest-2x upsample)
+__global__ void sumpool2_kernel(const bf16* __restrict__ x, bf16* __restrict__ y, int B, int H, int W, int C,
+                                int accum) {
+  const int ck = C / 8;
+  const long long total = (long long)B * H * W * ck;
+  EW_LOOP(i, total) {
+    const int c = (int)(i % ck) * 8;
+    const long long pix = i / ck;
+    const int xw = (int)(pix % W), yh = (int)((pix / W) % H), b = (int)(pix / ((long long)W * H));
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+      for (int dx = 0; dx < 2; ++dx) {
+        const bf16x8 v = *(const bf16x8*)(x + (((long long)b * 2 * H + 2 * yh + dy) * 2 * W + 2 * xw + dx) * C + c);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] += (float)v[j];
+      }
+    bf16x8 o;
+    if (accum) o = *(const bf16x8*)(y + pix * C + c);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = (bf16)(acc[j] + (accum ? (float)o[j] : 0.f));
+    *(bf16x8*)(y + pix * C + c) = o;
+  }
+}
+int launch_sumpool2(const bf16* x, bf16* y, int B, int H, int W, int C, int accum, hipStream_t s) {
+  SHAPECHK(C % 8 == 0, "sumpool: C %% 8");
+  hipLaunchKernelGGL(sumpool2_kernel, dim3(EW_GRID((long long)B * H * W * (C / 8))), dim3(256), 0, s, x, y, B, H, W,
+                     C, accum);
+  HIPCHK(hipGetLastError());
+  return PEA_OK;
+}
+
+// ---- casts, transposes, repacks (load-time / boundary; not on the per-step hot path)
+__global__ void cast_f32_bf16_kernel(const float* __restrict__ x, bf16* __restrict__ y, long long n) {
+  EW_LOOP(i, n) y[i] = (bf16)x[i];
+}
+__global__ void cast_bf16_f32_kernel(const bf16* __restrict__ x, float* __restrict__ y, long long n) {
+  EW_LOOP(i, n) y[i] = (float)x[i];
+}
+int launch_cast_f32_bf16(const float* x, bf16* y, long long n, hipStream_t s) {
+  hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3(EW_GRID(n)), dim3(256), 0, s, x, y, n);
+  HIPCHK(hipGetLastError());
+  return PEA_OK;
+}
+int launch_cast_bf16_f32(const bf16* x, float* y, long long n, hipStream_t s) {
+  hipLaunchKernelGGL(cast_bf16_f32_kernel, dim3(EW_GRID(n)), dim3(256), 0, s, x, y, n);
+  HIPCHK(hipGetLastError());
+  return PEA_OK;
+}
+
+template <typename TI>
+__global__ void transpose_kernel(const TI* __restrict__ x, bf16* __restrict__ y, int R, int C, int ldy) {
+  __shared__ float tile[32][33];
+  const int bx = blockIdx.x * 32, by = blockIdx.y * 32;
+  for (int i = threadIdx.y; i < 32; i += 8) {
+    const int r = by + i, c = bx + threadIdx.x;
+    tile[i][threadIdx.x] = (r < R && c < C) ? (float)x[(long long)r * C + c] : 0.f;
+  }
+  __syncthreads();
+  for (int i = threadIdx.y; i < 32; i += 8) {
+    const int c = bx + i, r = by + threadIdx.x;
+    if (c < C && r < R) y[(long long)c * ldy + r] = (bf16)tile[threadIdx.x][i];
+  }
+}
+int launch_transpose_bf16(const bf16* x, bf16* y, int R, int C, int ldy, hipStream_t s) {
+  hipLaunchKernelGGL(transpose_kernel<bf16>, dim3(cdiv(C, 32), cdiv(R, 32)), dim3(32, 8), 0, s, x, y, R, C, ldy);
+  HIPCHK(hipGetLastError());
+  return PEA_OK;
+}
+int launch_transpose_f32_bf16(const float* x, bf16* y, int R, int C, int ldy, hipStream_t s) {
+  hipLaunchKernelGGL(transpose_kernel<float>, dim3(cdiv(C, 32), cdiv(R, 32)), dim3(32, 8), 0, s, x, y, R, C, ldy);
+  HIPCHK(hipGetLastError());
+  return PEA_OK;
+}
+
+__global__ void nhwc_to_nchw_f32_kernel(const bf16* __restrict__ x, float* __restrict__ y, int B, int HW, int C) {
+  const long long total = (long long)B * HW * C;
+  EW_LOOP(i, total) {
+    const int p = (int)(i % HW);
+    const int c = (int)((i / HW) % C);
+    const int b = (int)(i / ((long long)HW * C));
+    y[i] = (float)x[((long long)b * HW + p) * C + c];
+  }
+}
+int launch_nhwc_to_nchw_f32(const bf16* x, float* y, int B, int HW, int C, hipStream_t s) {
+  hipLaunchKernelGGL(nhwc_to_nchw_f32_kernel, dim3(EW_GRID((long long)B * HW * C)), dim3(256), 0, s, x, y, B, HW, C);
+  HIPCHK(hipGetLastError());
+  return PEA_OK;
+}
+
+// w [Co][Ci][3][3] fp32 -> mode 0: y[co][(ky*3+kx)*Ci + ci]; mode 1: y[ci][((2-ky)*3+(2-kx))*Co + co] (bf16)
+// mode 2: y[co][ky][kx][ci] fp32
+__global__ void pack_conv_kernel(const float* __restrict__ w, bf16* __restrict__ yb, float* __restrict__ yf, int Co,
+                                 int Ci, int mode) {
+  const long long total = (long long)Co * Ci * 9;
+  EW_LOOP(i, total) {
+    const int kx = (int)(i % 3), ky = (int)((i / 3) % 3);
+    const int ci = (int)((i / 9) % Ci), co = (int)(i / (9LL * Ci));
+    const float v = w[i];
+    if (mode == 0) yb[(long long)co * 9 * Ci + (ky * 3 + kx) * Ci + ci] = (bf16)v;
+    else if (mode == 1) yb[(long long)ci * 9 * Co + ((2 - ky) * 3 + (2 - kx)) * Co + co] = (bf16)v;
+    else yf[(long long)co * 9 * Ci + (ky * 3 + kx) * Ci + ci] = v;
+  }
+}
+int launch_pack_conv_fwd(const float* w, bf16* y, int Co, int Ci, hipStream_t s) {
+  hipLaunchKernelGGL(pack_conv_kernel, dim3(EW_GRID(9LL * Co * Ci)), dim3(256), 0, s, w, y, nullptr, Co, Ci, 0);
+  HIPCHK(hipGetLastError());
+  return PEA_OK;
+}
+int launch_pack_conv_dgrad(const float* w, bf16* y, int Co, int Ci, hipStream_t s) {
+  hipLaunchKernelGGL(pack_conv_kernel, dim3(EW_GRID(9LL * Co * Ci)), dim3(256), 0, s, w, y, nullptr, Co, Ci, 1);
+  HIPCHK(hipGetLastError());
+  return PEA_OK;
+}
+int launch_pack_conv_out(const float* w, float* y, int Co, int Ci, hipStream_t s) {
+  hipLaunchKernelGGL(pack_conv_kernel, dim3(EW_GRID(9LL * Co * Ci)), dim3(256), 0, s, w, nullptr, y, Co, Ci, 2);
+  HIPCHK(hipGetLastError());
+  return PEA_OK;
+}
+
+// ---- sinusoidal embedding, diffusers get_timestep_embedding(flip_sin_to_cos=True, shift 0): (cos | sin)
+__global__ void timestep_embed_kernel(const float* __restrict__ t, bf16* __restrict__ y, int n, int dim) {
+  const int half = dim / 2;
+  EW_LOOP(i, (long long)n * half) {
+    const int k = (int)(i % half), r = (int)(i / half);
+    const float freq = expf(-9.210340371976184f * (float)k / (float)half);   // ln(10000)
+    const float a = t[r] * freq;
+    y[(long long)r * dim + k] = (bf16)cosf(a);
+    y[(long long)r * dim + half + k] = (bf16)sinf(a);
+  }
+}
+int launch_timestep_embed(const float* t, bf16* y, int n, int dim, hipStream_t s) {
+  hipLaunchKernelGGL(timestep_embed_kernel, dim3(EW_GRID((long long)n * dim / 2)), dim3(256), 0, s, t, y, n, dim);
+  HIPCHK(hipGetLastError());
+  return PEA_OK;
+}
+
+__global__ void add_noise_kernel(const float* __restrict__ x0, const float* __restrict__ eps,
+                                 const long long* __restrict__ t, const float* __restrict__ ac,
+                                 float* __restrict__ xt, int B, long long per) {
+  EW_LOOP(i, (long long)B * per) {
+    const int b = (int)(i / per);
+    const float a = ac[t[b]];
+    xt[i] = sqrtf(a) * x0[i] + sqrtf(1.0f - a) * eps[i];
+  }
+}
+int launch_add_noise(const float* x0, const float* eps, const long long* t, const float* ac, float* xt, int B,
+                     long long per, hipStream_t s) {
+  hipLaunchKernelGGL(add_noise_kernel, dim3(EW_GRID((long long)B * per)), dim3(256), 0, s, x0, eps, t, ac, xt, B, per);
+  HIPCHK(hipGetLastError());
+  return PEA_OK;
+}
+
+// ---- CFG-dropout row select and its backward (train_sdxl_zh.py:395)
+__global__ void select_rows_kernel(const bf16* __restrict__ c, const bf16* __restrict__ u,
+                                   const unsigned char* __restrict__ mask, bf16* __restrict__ y, int B,
+                                   long long per8) {
+  EW_LOOP(i, (long long)B * per8) {
+    const int b = (int)(i / per8);
+    *(bf16x8*)(y + i * 8) = mask[b] ? *(const bf16x8*)(u + i * 8) : *(const bf16x8*)(c + i * 8);
+  }
+}
+__global__ void select_rows_bwd_kernel(const bf16* __restrict__ dy, const unsigned char* __restrict__ mask,
+                                       bf16* __restrict__ dc, bf16* __restrict__ du, int B, long long per8) {
+  EW_LOOP(i, (long long)B * per8) {
+    const int b = (int)(i / per8);
+    const bf16x8 v = *(const bf16x8*)(dy + i * 8);
+    bf16x8 z;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) z[j] = (bf16)0.f;
+    *(bf16x8*)(dc + i * 8) = mask[b] ? z : v;
+    *(bf16x8*)(du + i * 8) = mask[b] ? v : z;
+  }
+}
+int launch_select_rows(const bf16* c, const bf16* u, const unsigned char* mask, bf16* y, int B, long long per,
+                       hipStream_t s) {
+  SHAPECHK(per % 8 == 0, "select: per %% 8");
+  hipLaunchKernelGGL(select_rows_kernel, dim3(EW_GRID(B * per / 8)), dim3(256), 0, s, c, u, mask, y, B, per / 8);
+  HIPCHK(hipGetLastError());
+  return PEA_OK;
+}
+int launch_select_rows_bwd(const bf16* dy, const unsigned char* mask, bf16* dc, bf16* du, int B, long long per,
+                           hipStream_t s) {
+  SHAPECHK(per % 8 == 0, "select: per %% 8");
+  hipLaunchKernelGGL(select_rows_bwd_kernel, dim3(EW_GRID(B * per / 8)), dim3(256), 0, s, dy, mask, dc, du, B,
+                     per / 8);
+  HIPCHK(hipGetLastError());
+  return PEA_OK;
+}
+
+// ---- mean over tokens (adapter pooled branch) and backward
+__global__ void mean_tokens_kernel(const bf16* __restrict__ x, bf16* __restrict__ y, int B, int L, int C) {
+  EW_LOOP(i, (long long)B * C) {
+    const int c = (int)(i % C), b = (int)(i / C);
+    float s = 0.f;
+    for (int l = 0; l < L; ++l) s += (float)x[((long long)b * L + l) * C + c];
+    y[i] = (bf16)(s / (float)L);
+  }
+}
+__global__ void mean_tokens_bwd_kernel(const bf16* __restrict__ dy, bf16* __restrict__ dx, int B, int L, int C,
+                                       int accum) {
+  EW_LOOP(i, (long long)B * L * C) {
+    const int c = (int)(i % C);
+    const int b = (int)(i / ((long long)L * C));
+    float v = (float)dy[(long long)b * C + c] / (float)L;
+    if (accum) v += (float)dx[i];
+    dx[i] = (bf16)v;
+  }
+}
+int launch_mean_tokens(const bf16* x, bf16* y, int B, int L, int C, hipStream_t s) {
+  hipLaunchKernelGGL(mean_tokens_kernel, dim3(EW_GRID((long long)B * C)), dim3(256), 0, s, x, y, B, L, C);
+  HIPCHK(hipGetLastError());
+  return PEA_OK;
+}
+int launch_mean_tokens_bwd(const bf16* dy, bf16* dx, int B, int L, int C, int accum, hipStream_t s) {
+  hipLaunchKernelGGL(mean_tokens_bwd_kernel, dim3(EW_GRID((long long)B * L * C)), dim3(256), 0, s, dy, dx, B, L, C,
+                     accum);
+  HIPCHK(hipGetLastError());
+  return PEA_OK;
+}
+
+__global__ void colsum_kernel(const bf16* __restrict__ x, float* __restrict__ db, int R, int C, int accum) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float s = 0.f;
+  for (int r = 0; r < R; ++r) s += (float)x[(long long)r * C + c];
+  db[c] = accum ? db[c] + s : s;
+}
+int launch_colsum(const bf16* x, float* db, int R, int C, int accum, hipStream_t s) {
+  hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(C, 64)), dim3(64), 0, s, x, db, R, C, accum);
+  HIPCHK(hipGetLastError());
+  return PEA_OK;
+}
+
+// ---- counter-based RNG fill (splitmix64 -> uniform(-1,1) * scale): random-init weights of a given
+// architecture for bench.py (no checkpoints in the image), deterministic in (seed, index).
+__device__ __forceinline__ float rng_uniform(unsigned long long seed, unsigned long long i) {
+  unsigned long long z = seed + (i + 1) * 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z = z ^ (z >> 31);
+  return (float)((z >> 40) & 0xFFFFFF) * (2.0f / 16777216.0f) - 1.0f;
+}
+__global__ void fill_random_bf16_kernel(bf16* p, long long n, unsigned long long seed, float scale) {
+  EW_LOOP(i, n) p[i] = (bf16)(rng_uniform(seed, (unsigned long long)i) * scale);
+}
+__global__ void fill_random_f32_kernel(float* p, long long n, unsigned long long seed, float scale, float offset) {
+  EW_LOOP(i, n) p[i] = rng_uniform(seed, (unsigned long long)i) * scale + offset;
+}
+int launch_fill_random_bf16(bf16* p, long long n, unsigned long long seed, float scale, hipStream_t s) {
+  hipLaunchKernelGGL(fill_random_bf16_kernel, dim3(EW_GRID(n)), dim3(256), 0, s, p, n, seed, scale);
+  HIPCHK(hipGetLastError());
+  return PEA_OK;
+}
+int launch_fill_random_f32(float* p, long long n, unsigned long long seed, float scale, float offset,
+                           hipStream_t s) {
+  hipLaunchKernelGGL(fill_random_f32_kernel, dim3(EW_GRID(n)), dim3(256), 0, s, p, n, seed, scale, offset);
+  HIPCHK(hipGetLastError());
+  return PEA_OK;
+}
+
+// ---- fused AdamW (adam_w_mode=True as FusedAdam in utils/model_utils.py:64-67), fp32 master weights
+__global__ void adamw_kernel(float* __restrict__ w, const float* __restrict__ g, float* __restrict__ m,
+                             float* __restrict__ v, long long n, float lr, float b1, float b2, float eps, float wd,
+                             float bc1, float bc2, float gscale) {
+  EW_LOOP(i, n) {
+    const float gi = g[i] * gscale;
+    const float mi = b1 * m[i] + (1.f - b1) * gi;
+    const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    const float denom = sqrtf(vi / bc2) + eps;
+    w[i] = w[i] * (1.f - lr * wd) - lr * (mi / bc1) / denom;
+  }
+}
+int launch_adamw(float* w, const float* g, float* m, float* v, long long n, float lr, float b1, float b2, float eps,
+                 float wd, int step, float gscale, hipStream_t s) {
+  const float bc1 = 1.f - powf(b1, (float)step), bc2 = 1.f - powf(b2, (float)step);
+  hipLaunchKernelGGL(adamw_kernel, dim3(EW_GRID(n)), dim3(256), 0, s, w, g, m, v, n, lr, b1, b2, eps, wd, bc1, bc2,
+                     gscale);
+  HIPCHK(hipGetLastError());
+  return PEA_OK;
+}

@@ -1,0 +1,367 @@
+// bf16 MFMA GEMM / implicit-GEMM 3x3 convolution for gfx950 (MI355X).
+//
+// Replaces the cuBLAS/cuDNN calls that diffusers' UNet2DConditionModel triggers from
+// train_sdxl_zh.py:397,415 (Linear layers, ResBlock conv3x3, up/down-sample convs) and
+// the adapter Linears of train_sdxl_zh.py:48-55.
+//
+// Structure (round 1): 128x128x64 block tile, 4 waves (2x2), each wave a 64x64 sub-tile as
+// 2x2 v_mfma_f32_32x32x16_bf16; both operands K-contiguous ("NT"), staged global->LDS with
+// global_load_lds_dwordx4 (LDS-DMA, 1 KiB per wave instruction) into a 2-stage ring;
+// the LDS image is linear, the XOR swizzle (chunk ^ ((row>>1)&7)) is applied to the SOURCE
+// address and to the ds_read_b128 address, which makes the 32x32x16 fragment reads of
+// 128-byte rows bank-conflict free.  The MFMA is issued with weights as the A operand
+// and activations as the B operand, so each lane ends with 4 consecutive output columns
+// of one output row -> 8-byte packed bf16 stores and vector bias/residual loads.
+// Workgroup ids are remapped XCD-aware (blocks b, b+8 share an L2) and grouped 8 M-tiles
+// per N-tile so the 64 tiles resident on one XCD share operand panels.
+#include "pea_kernels.h"
+
+#define BM 128
+#define BN 128
+#define BK 64
+#define STAGE_BYTES (BM * BK * 2 + BN * BK * 2)   // 32 KiB
+#define A_BYTES (BM * BK * 2)
+
+__device__ __forceinline__ int swz_off(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
+
+template <int MODE>
+__global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmP p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 1, wc = wave & 1;
+
+  // ---- XCD-aware, grouped tile mapping (bijective for any grid size)
+  const int nbm = (p.M + BM - 1) / BM, nbn = (p.N + BN - 1) / BN;
+  const int nwg = nbm * nbn;
+  int bid = blockIdx.x;
+  {
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int GROUP = 8;
+  const int per_group = GROUP * nbn;
+  const int gid = bid / per_group;
+  const int first_m = gid * GROUP;
+  const int gsize = min(nbm - first_m, GROUP);
+  const int bm = first_m + (bid % per_group) % gsize;
+  const int bn = (bid % per_group) / gsize;
+
+  // ---- per-thread staging descriptors: 4 A rows + 4 W rows, one 16-byte chunk each
+  const int lrow = lane >> 3;              // row within an 8-row glds piece
+  const int cpos = lane & 7;               // chunk position inside the LDS row
+  const bf16* a_src[4];
+  int a_iy0[4], a_ix0[4];                  // conv: virtual-input origin of the 3x3 window
+  const bf16* w_src[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int r = (wave * 4 + j) * 8 + lrow;            // tile row 0..127
+    const int chunk = cpos ^ ((r >> 1) & 7);            // source chunk that lands at position cpos
+    int gm = bm * BM + r;
+    gm = gm < p.M ? gm : p.M - 1;
+    if (MODE == 0) {
+      a_src[j] = p.A + (long long)gm * p.lda + chunk * 8;
+      a_iy0[j] = a_ix0[j] = 0;
+    } else {
+      const int hw = p.Ho * p.Wo;
+      const int b = gm / hw;
+      const int rem = gm - b * hw;
+      const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+      a_iy0[j] = oy * p.stride - 1;
+      a_ix0[j] = ox * p.stride - 1;
+      a_src[j] = p.A + (long long)b * p.Hs * p.Ws * p.Cin + chunk * 8;
+    }
+    int gn = bn * BN + r;
+    gn = gn < p.N ? gn : p.N - 1;
+    w_src[j] = p.W + (long long)gn * p.ldw + chunk * 8;
+  }
+  const int Hv = p.Hs << p.shift, Wv = p.Ws << p.shift;
+
+  auto stage = [&](int st, int k0) {
+    char* base = smem + st * STAGE_BYTES;
+    int ky = 0, kx = 0, c0 = 0;
+    if (MODE == 1) {
+      const int tap = k0 / p.Cin;
+      c0 = k0 - tap * p.Cin;
+      ky = tap / 3;
+      kx = tap - ky * 3;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const bf16* src;
+      if (MODE == 0) {
+        src = a_src[j] + k0;
+      } else {
+        const int iy = a_iy0[j] + ky, ix = a_ix0[j] + kx;
+        bool ok = ((unsigned)iy < (unsigned)Hv) && ((unsigned)ix < (unsigned)Wv);
+        if (p.parity) ok = ok && (((iy | ix) & 1) == 0);
+        const int sy = iy >> p.shift, sx = ix >> p.shift;
+        src = ok ? a_src[j] + ((long long)sy * p.Ws + sx) * p.Cin + c0 : p.zeros;
+      }
+      __builtin_amdgcn_global_load_lds(PEA_GLB(src), PEA_LDS(base + (wave * 4 + j) * 1024), 16, 0, 0);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      __builtin_amdgcn_global_load_lds(PEA_GLB(w_src[j] + k0), PEA_LDS(base + A_BYTES + (wave * 4 + j) * 1024), 16,
+                                       0, 0);
+    }
+  };
+
+  f32x16 acc[2][2];   // [ni][mi]
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int nt = p.K / BK;
+  stage(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  const int frow = lane & 31, fh = lane >> 5;
+  for (int t = 0; t < nt; ++t) {
+    const int cur = t & 1;
+    if (t + 1 < nt) stage(cur ^ 1, (t + 1) * BK);
+    const char* As = smem + cur * STAGE_BYTES;
+    const char* Ws = As + A_BYTES;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      bf16x8 af[2], wf[2];
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi) {
+        const int row = wr * 64 + mi * 32 + frow;
+        af[mi] = *(const bf16x8*)(As + swz_off(row, 2 * s + fh));
+      }
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni) {
+        const int row = wc * 64 + ni * 32 + frow;
+        wf[ni] = *(const bf16x8*)(Ws + swz_off(row, 2 * s + fh));
+      }
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+          acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ni], af[mi], acc[ni][mi], 0, 0, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+
+  // ---- epilogue.  acc[ni][mi][4g+j] = D[n = 8g + 4h + j][m = lane&31]
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi) {
+    const int m = bm * BM + wr * 64 + mi * 32 + frow;
+    if (m >= p.M) continue;
+    const int bidx = p.rowvec ? m / p.rows_per_batch : 0;
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int n = bn * BN + wc * 64 + ni * 32 + 8 * g + 4 * fh;
+        if (n >= p.N) continue;
+        float v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = acc[ni][mi][4 * g + j] * p.alpha;
+        if (p.bias) {
+          const f32x4 b = *(const f32x4*)(p.bias + n);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] += b[j];
+        }
+        if (p.rowvec) {
+          const bf16x4 rv = *(const bf16x4*)(p.rowvec + (long long)bidx * p.ldrv + n);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] += (float)rv[j];
+        }
+        if (p.preact) {
+          bf16x4 o;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) o[j] = (bf16)v[j];
+          *(bf16x4*)(p.preact + (long long)m * p.ldpre + n) = o;
+        }
+        if (p.act == 1) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] = gelu_erf(v[j]);
+        } else if (p.act == 2) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] = siluf_(v[j]);
+        }
+        if (p.res) {
+          const bf16x4 rr = *(const bf16x4*)(p.res + (long long)m * p.ldres + n);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] += (float)rr[j];
+        }
+        if (p.out_f32) {
+          float* cp = (float*)p.C + (long long)m * p.ldc + n;
+          f32x4 o;
+          if (p.accum_f32) {
+            o = *(const f32x4*)cp;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] += v[j];
+          } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] = v[j];
+          }
+          *(f32x4*)cp = o;
+        } else {
+          bf16x4 o;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) o[j] = (bf16)v[j];
+          *(bf16x4*)((bf16*)p.C + (long long)m * p.ldc + n) = o;
+        }
+      }
+    }
+  }
+}
+
+int launch_gemm(const GemmP& p, hipStream_t stream) {
+  SHAPECHK(p.M > 0 && p.N > 0 && p.K > 0, "gemm: empty problem M=%d N=%d K=%d", p.M, p.N, p.K);
+  SHAPECHK(p.K % BK == 0, "gemm: K=%d must be a multiple of %d", p.K, BK);
+  SHAPECHK(p.N % 4 == 0, "gemm: N=%d must be a multiple of 4", p.N);
+  SHAPECHK(p.ldw % 8 == 0 && p.ldc % 4 == 0, "gemm: ldw=%d ldc=%d alignment", p.ldw, p.ldc);
+  if (p.mode == 0) {
+    SHAPECHK(p.lda % 8 == 0, "gemm: lda=%d must be a multiple of 8", p.lda);
+  } else {
+    SHAPECHK(p.Cin % BK == 0 && p.K == 9 * p.Cin, "conv: Cin=%d must be a multiple of %d and K=9*Cin", p.Cin, BK);
+    SHAPECHK(p.zeros != nullptr, "conv: zero page missing");
+    SHAPECHK(p.M % (p.Ho * p.Wo) == 0, "conv: M=%d not a multiple of Ho*Wo", p.M);
+  }
+  static bool attr_set = false;
+  if (!attr_set) {
+    HIPCHK(hipFuncSetAttribute((const void*)gemm_bf16_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                               2 * STAGE_BYTES));
+    HIPCHK(hipFuncSetAttribute((const void*)gemm_bf16_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                               2 * STAGE_BYTES));
+    attr_set = true;
+  }
+  const int grid = cdiv(p.M, BM) * cdiv(p.N, BN);
+  if (p.mode == 0)
+    hipLaunchKernelGGL(gemm_bf16_kernel<0>, dim3(grid), dim3(256), 2 * STAGE_BYTES, stream, p);
+  else
+    hipLaunchKernelGGL(gemm_bf16_kernel<1>, dim3(grid), dim3(256), 2 * STAGE_BYTES, stream, p);
+  HIPCHK(hipGetLastError());
+  return PEA_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// 4-channel ends of the UNet (conv_in: K = 36, conv_out: N = 4): negligible FLOPs, direct form.
+__global__ void conv_in_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                               const float* __restrict__ bias, bf16* __restrict__ y, int B, int Cin, int H, int W,
+                               int Cout) {
+  // one thread per (pixel, 4 output channels)
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int cq = Cout / 4;
+  const long long total = (long long)B * H * W * cq;
+  if (idx >= total) return;
+  const int co = (int)(idx % cq) * 4;
+  const long long pix = idx / cq;
+  const int xw = (int)(pix % W), yh = (int)((pix / W) % H), b = (int)(pix / ((long long)W * H));
+  float acc[4] = {bias[co], bias[co + 1], bias[co + 2], bias[co + 3]};
+  for (int ci = 0; ci < Cin; ++ci)
+    for (int ky = 0; ky < 3; ++ky) {
+      const int iy = yh + ky - 1;
+      if ((unsigned)iy >= (unsigned)H) continue;
+      for (int kx = 0; kx < 3; ++kx) {
+        const int ix = xw + kx - 1;
+        if ((unsigned)ix >= (unsigned)W) continue;
+        const float v = x[(((long long)b * Cin + ci) * H + iy) * W + ix];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[j] += v * w[(((co + j) * Cin + ci) * 3 + ky) * 3 + kx];
+      }
+    }
+  bf16x4 o;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) o[j] = (bf16)acc[j];
+  *(bf16x4*)(y + pix * Cout + co) = o;
+}
+
+int launch_conv_in(const float* x, const float* w, const float* bias, bf16* y, int B, int Cin, int H, int W,
+                   int Cout, hipStream_t s) {
+  SHAPECHK(Cout % 4 == 0, "conv_in: Cout %% 4");
+  const long long total = (long long)B * H * W * (Cout / 4);
+  hipLaunchKernelGGL(conv_in_kernel, dim3((unsigned)cdivl(total, 256)), dim3(256), 0, s, x, w, bias, y, B, Cin, H,
+                     W, Cout);
+  HIPCHK(hipGetLastError());
+  return PEA_OK;
+}
+
+// conv_out: one wave per output pixel; lanes split the (tap, ci) reduction, 16-byte loads.
+__global__ __launch_bounds__(256) void conv_out_kernel(const bf16* __restrict__ x, const float* __restrict__ w,
+                                                       const float* __restrict__ bias, float* __restrict__ y,
+                                                       int B, int Cin, int H, int W, int Cout) {
+  const int lane = threadIdx.x & 63;
+  const long long pix = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (pix >= (long long)B * H * W) return;
+  const int xw = (int)(pix % W), yh = (int)((pix / W) % H), b = (int)(pix / ((long long)W * H));
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};   // Cout <= 4
+  const int cchunks = Cin / 8;
+  for (int i = lane; i < 9 * cchunks; i += 64) {
+    const int tap = i / cchunks, c8 = (i - tap * cchunks) * 8;
+    const int ky = tap / 3, kx = tap - ky * 3;
+    const int iy = yh + ky - 1, ix = xw + kx - 1;
+    if ((unsigned)iy >= (unsigned)H || (unsigned)ix >= (unsigned)W) continue;
+    const bf16x8 v = *(const bf16x8*)(x + (((long long)b * H + iy) * W + ix) * Cin + c8);
+    for (int co = 0; co < Cout; ++co) {
+      const float* wp = w + ((long long)co * 9 + tap) * Cin + c8;
+      float a = 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) a += (float)v[j] * wp[j];
+      acc[co] += a;
+    }
+  }
+  for (int co = 0; co < Cout; ++co) {
+    const float r = wave_sum(acc[co]);
+    if (lane == 0) y[(((long long)b * Cout + co) * H + yh) * W + xw] = r + bias[co];
+  }
+}
+
+int launch_conv_out(const bf16* x, const float* w, const float* bias, float* y, int B, int Cin, int H, int W,
+                    int Cout, hipStream_t s) {
+  SHAPECHK(Cout <= 4 && Cin % 8 == 0, "conv_out: Cout<=4, Cin%%8");
+  const long long pix = (long long)B * H * W;
+  hipLaunchKernelGGL(conv_out_kernel, dim3((unsigned)cdivl(pix, 4)), dim3(256), 0, s, x, w, bias, y, B, Cin, H, W,
+                     Cout);
+  HIPCHK(hipGetLastError());
+  return PEA_OK;
+}
+
+// dgrad of conv_out: dx[b][y][x][ci] = sum_{co,ky,kx} dy[b][co][y+1-ky][x+1-kx] * w[co][ky][kx][ci]
+__global__ void conv_out_dgrad_kernel(const float* __restrict__ dy, const float* __restrict__ w,
+                                      bf16* __restrict__ dx, int B, int Cin, int H, int W, int Cout) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int cq = Cin / 8;
+  const long long total = (long long)B * H * W * cq;
+  if (idx >= total) return;
+  const int c8 = (int)(idx % cq) * 8;
+  const long long pix = idx / cq;
+  const int xw = (int)(pix % W), yh = (int)((pix / W) % H), b = (int)(pix / ((long long)W * H));
+  float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (int co = 0; co < Cout; ++co)
+    for (int ky = 0; ky < 3; ++ky) {
+      const int oy = yh + 1 - ky;
+      if ((unsigned)oy >= (unsigned)H) continue;
+      for (int kx = 0; kx < 3; ++kx) {
+        const int ox = xw + 1 - kx;
+        if ((unsigned)ox >= (unsigned)W) continue;
+        const float g = dy[(((long long)b * Cout + co) * H + oy) * W + ox];
+        const float* wp = w + ((long long)co * 9 + ky * 3 + kx) * Cin + c8;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] += g * wp[j];
+      }
+    }
+  bf16x8 o;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) o[j] = (bf16)acc[j];
+  *(bf16x8*)(dx + pix * Cin + c8) = o;
+}
+
+int launch_conv_out_dgrad(const float* dy, const float* w, bf16* dx, int B, int Cin, int H, int W, int Cout,
+                          hipStream_t s) {
+  const long long total = (long long)B * H * W * (Cin / 8);
+  hipLaunchKernelGGL(conv_out_dgrad_kernel, dim3((unsigned)cdivl(total, 256)), dim3(256), 0, s, dy, w, dx, B, Cin,
+                     H, W, Cout);
+  HIPCHK(hipGetLastError());
+  return PEA_OK;
+}

@@ -1,0 +1,142 @@
+// Fused knowledge-distillation loss: the 7 (SDXL) / 9 (SD1.5) masked feature-MSE terms, the
+// masked noise-MSE and the masked teacher-logit MSE of train_sdxl_zh.py:399-441
+// (train_sd_zh.py:217-276) in ONE launch, which also writes every gradient seed
+// (dL/dF_S^k, dL/d eps_S) so the backward pass starts without another sweep.
+//
+// HBM-bound: per image 2 x 25.56 M tap elements read + 25.56 M written (bf16) for SDXL.
+// 16 bytes per lane, fp32 per-thread accumulation, wave shuffle reduction, one fp64 atomic per
+// block.  Samples whose mask weight is 0 are not read at all (their seeds are zeros).
+#include "pea_kernels.h"
+
+#define KD_CHUNKS_PER_BLOCK 4096   // 16-byte chunks per block (64 KiB of each input)
+
+struct KdSeg {
+  long long blk0;        // first block of this segment
+  long long nchunks;     // chunks in the segment (B * per / 8 for taps, B * per / 4 for eps)
+};
+struct KdSegs {
+  KdSeg s[PEA_MAX_TAPS + 1];
+};
+
+__device__ __forceinline__ void block_accumulate(float v, double* dst) {
+  __shared__ float wsum[4];
+  v = wave_sum(v);
+  if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(dst, (double)(wsum[0] + wsum[1] + wsum[2] + wsum[3]));
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void kd_loss_kernel(const KdLossP p, const KdSegs segs, double* partial) {
+  // find the segment of this block (<= 13 entries; uniform)
+  int k = 0;
+  while (k < p.ntaps && (long long)blockIdx.x >= segs.s[k + 1].blk0) ++k;
+  const long long c0 = ((long long)blockIdx.x - segs.s[k].blk0) * KD_CHUNKS_PER_BLOCK;
+  const long long c1 = min(c0 + KD_CHUNKS_PER_BLOCK, segs.s[k].nchunks);
+  if (k < p.ntaps) {
+    const bf16* fs = p.fs[k];
+    const bf16* ft = p.ft[k];
+    bf16* dfs = p.dfs[k];
+    const long long per8 = p.per[k] / 8;
+    const float gsc = p.grad_scale * p.feat_weight * 2.0f / ((float)p.per[k] * (float)p.B);
+    float acc = 0.f;
+    for (long long c = c0 + threadIdx.x; c < c1; c += 256) {
+      const int b = (int)(c / per8);
+      const bool on = p.zh[b] == 0;          // weight (1 - zh_or_not)
+      bf16x8 g;
+      if (on) {
+        const bf16x8 a = *(const bf16x8*)(fs + c * 8);
+        const bf16x8 t = *(const bf16x8*)(ft + c * 8);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float d = (float)a[j] - (float)t[j];
+          acc += d * d;
+          g[j] = (bf16)(d * gsc);
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) g[j] = (bf16)0.f;
+      }
+      if (dfs) *(bf16x8*)(dfs + c * 8) = g;
+    }
+    block_accumulate(acc, &partial[2 + k]);
+  } else {
+    const long long per4 = p.per_eps / 4;
+    const float gsc = p.grad_scale * 2.0f / ((float)p.per_eps * (float)p.B);
+    float a0 = 0.f, a1 = 0.f;
+    for (long long c = c0 + threadIdx.x; c < c1; c += 256) {
+      const int b = (int)(c / per4);
+      const bool zh = p.zh[b] != 0;
+      const f32x4 es = *(const f32x4*)(p.eps_s + c * 4);
+      const f32x4 other = zh ? *(const f32x4*)(p.eps + c * 4) : *(const f32x4*)(p.eps_t + c * 4);
+      f32x4 g;
+      float acc = 0.f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float d = es[j] - other[j];
+        acc += d * d;
+        g[j] = d * gsc;
+      }
+      if (zh) a0 += acc; else a1 += acc;
+      if (p.deps_s) *(f32x4*)(p.deps_s + c * 4) = g;
+    }
+    block_accumulate(a0, &partial[0]);
+    block_accumulate(a1, &partial[1]);
+  }
+}
+
+// losses[0..3] = total, train_loss, train_loss_logits, train_loss_features; skip[k] = 1 when the SD1.5
+// NaN/Inf guard (train_sd_zh.py:246-268) drops tap k.
+__global__ void kd_finish_kernel(const KdLossP p, const double* partial, float* losses, int* skip) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const double nb = (double)p.per_eps * (double)p.B;
+  const double l0 = partial[0] / nb, l1 = partial[1] / nb;
+  double lf = 0.0;
+  for (int k = 0; k < p.ntaps; ++k) {
+    const double t = partial[2 + k] / ((double)p.per[k] * (double)p.B);
+    const bool bad = p.nan_guard && !isfinite(t);
+    if (skip) skip[k] = bad ? 1 : 0;
+    if (!bad) lf += t;
+  }
+  losses[1] = (float)l0;
+  losses[2] = (float)l1;
+  losses[3] = (float)lf;
+  losses[0] = (float)(l0 + l1 + (double)p.feat_weight * lf);
+}
+
+__global__ void kd_zero_skipped_kernel(const KdLossP p, const int* skip) {
+  const int k = blockIdx.y;
+  if (!skip[k] || !p.dfs[k]) return;
+  const long long n8 = (long long)p.B * p.per[k] / 8;
+  bf16x8 z;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) z[j] = (bf16)0.f;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long long)gridDim.x * blockDim.x)
+    *(bf16x8*)(p.dfs[k] + i * 8) = z;
+}
+
+int launch_kd_loss(const KdLossP& p, hipStream_t s) {
+  SHAPECHK(p.ntaps >= 0 && p.ntaps <= PEA_MAX_TAPS, "kd_loss: ntaps=%d", p.ntaps);
+  SHAPECHK(p.per_eps % 4 == 0, "kd_loss: per_eps %% 4");
+  KdSegs segs;
+  long long blk = 0;
+  for (int k = 0; k < p.ntaps; ++k) {
+    SHAPECHK(p.per[k] % 8 == 0, "kd_loss: tap %d size %% 8", k);
+    segs.s[k].blk0 = blk;
+    segs.s[k].nchunks = (long long)p.B * p.per[k] / 8;
+    blk += cdivl(segs.s[k].nchunks, KD_CHUNKS_PER_BLOCK);
+  }
+  segs.s[p.ntaps].blk0 = blk;
+  segs.s[p.ntaps].nchunks = (long long)p.B * p.per_eps / 4;
+  blk += cdivl(segs.s[p.ntaps].nchunks, KD_CHUNKS_PER_BLOCK);
+  // partial: fp64 [2 + ntaps] followed by int skip[ntaps]; caller provides >= 256 bytes in p.partial
+  double* partial = (double*)p.partial;
+  int* skip = (int*)(partial + 2 + PEA_MAX_TAPS);
+  HIPCHK(hipMemsetAsync(partial, 0, sizeof(double) * (2 + PEA_MAX_TAPS) + sizeof(int) * PEA_MAX_TAPS, s));
+  hipLaunchKernelGGL(kd_loss_kernel, dim3((unsigned)blk), dim3(256), 0, s, p, segs, partial);
+  hipLaunchKernelGGL(kd_finish_kernel, dim3(1), dim3(64), 0, s, p, partial, p.losses, skip);
+  if (p.nan_guard && p.ntaps > 0)
+    hipLaunchKernelGGL(kd_zero_skipped_kernel, dim3(256, p.ntaps), dim3(256), 0, s, p, skip);
+  HIPCHK(hipGetLastError());
+  return PEA_OK;
+}

@@ -1,0 +1,334 @@
+// GroupNorm(+SiLU) and LayerNorm, forward and data-gradient backward, NHWC / token-major bf16.
+//
+// Replaces torch's native_group_norm / native_layer_norm as triggered inside diffusers'
+// ResnetBlock2D / Transformer2DModel / BasicTransformerBlock (called from
+// train_sdxl_zh.py:397,415) and the adapter's nn.LayerNorm (train_sdxl_zh.py:47,60).
+// HBM-bound: every pass moves 16 bytes per lane, statistics are reduced per thread (fp32),
+// per block through LDS, and across blocks with fp64 atomics (one per group per block).
+#include "pea_kernels.h"
+
+#define GN_MAX_GROUPS 64
+
+// thread t -> channel chunk (t % nchunk) [8 channels], pixel lane (t / nchunk)
+// grid: (blocks over pixels, B).  scratch: double [B][groups][2], zeroed by the launcher.
+template <int BWD>
+__global__ void gn_stats_kernel(const bf16* __restrict__ x, const bf16* __restrict__ dy,
+                                const float* __restrict__ gamma, const float* __restrict__ beta,
+                                const float* __restrict__ stats, double* __restrict__ scratch, int HW, int C,
+                                int groups, int pix_per_block, int silu) {
+  __shared__ float red[2 * GN_MAX_GROUPS];
+  const int nchunk = C / 8;
+  const int ppb = blockDim.x / nchunk;
+  const int tid = threadIdx.x;
+  const int b = blockIdx.y;
+  const int cpg = C / groups;
+  if (tid < 2 * GN_MAX_GROUPS) red[tid] = 0.f;
+  __syncthreads();
+  const int ck = tid % nchunk, pl = tid / nchunk;
+  float s1[8], s2[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) s1[j] = s2[j] = 0.f;
+  if (pl < ppb) {
+    const int c0 = ck * 8;
+    float gm[8], bt[8], mean[8], rstd[8];
+    if (BWD) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int g = (c0 + j) / cpg;
+        gm[j] = gamma[c0 + j];
+        bt[j] = beta[c0 + j];
+        mean[j] = stats[((long long)b * groups + g) * 2];
+        rstd[j] = stats[((long long)b * groups + g) * 2 + 1];
+      }
+    }
+    const int p0 = blockIdx.x * pix_per_block;
+    const int p1 = min(p0 + pix_per_block, HW);
+    for (int p = p0 + pl; p < p1; p += ppb) {
+      const long long off = ((long long)b * HW + p) * C + c0;
+      const bf16x8 xv = *(const bf16x8*)(x + off);
+      if (!BWD) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float v = (float)xv[j];
+          s1[j] += v;
+          s2[j] += v * v;
+        }
+      } else {
+        const bf16x8 dv = *(const bf16x8*)(dy + off);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float xh = ((float)xv[j] - mean[j]) * rstd[j];
+          float d = (float)dv[j];
+          if (silu) d *= silu_grad(xh * gm[j] + bt[j]);
+          d *= gm[j];
+          s1[j] += d;
+          s2[j] += d * xh;
+        }
+      }
+    }
+    // merge consecutive channels of the same group before touching LDS
+    int gprev = c0 / cpg;
+    float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int g = (c0 + j) / cpg;
+      if (g != gprev) {
+        atomicAdd(&red[2 * gprev], a1);
+        atomicAdd(&red[2 * gprev + 1], a2);
+        a1 = a2 = 0.f;
+        gprev = g;
+      }
+      a1 += s1[j];
+      a2 += s2[j];
+    }
+    atomicAdd(&red[2 * gprev], a1);
+    atomicAdd(&red[2 * gprev + 1], a2);
+  }
+  __syncthreads();
+  if (tid < 2 * groups) atomicAdd(&scratch[(long long)b * groups * 2 + tid], (double)red[tid]);
+}
+
+__global__ void gn_finalize_kernel(const double* __restrict__ scratch, float* __restrict__ stats, int n_bg,
+                                   double count, float eps) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_bg) return;
+  const double m = scratch[2 * i] / count;
+  double var = scratch[2 * i + 1] / count - m * m;
+  if (var < 0) var = 0;
+  stats[2 * i] = (float)m;
+  stats[2 * i + 1] = (float)(1.0 / sqrt(var + (double)eps));
+}
+
+__global__ void gn_apply_kernel(const bf16* __restrict__ x, const float* __restrict__ gamma,
+                                const float* __restrict__ beta, const float* __restrict__ stats,
+                                bf16* __restrict__ y, int HW, int C, int groups, int silu, long long total_chunks) {
+  const int nchunk = C / 8;
+  const int cpg = C / groups;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total_chunks;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int ck = (int)(i % nchunk);
+    const long long pix = i / nchunk;
+    const int b = (int)(pix / HW);
+    const int c0 = ck * 8;
+    const bf16x8 xv = *(const bf16x8*)(x + pix * C + c0);
+    bf16x8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int g = (c0 + j) / cpg;
+      const float mean = stats[((long long)b * groups + g) * 2];
+      const float rstd = stats[((long long)b * groups + g) * 2 + 1];
+      float v = ((float)xv[j] - mean) * rstd * gamma[c0 + j] + beta[c0 + j];
+      if (silu) v = siluf_(v);
+      o[j] = (bf16)v;
+    }
+    *(bf16x8*)(y + pix * C + c0) = o;
+  }
+}
+
+__global__ void gn_bwd_apply_kernel(const bf16* __restrict__ x, const bf16* __restrict__ dy,
+                                    const float* __restrict__ gamma, const float* __restrict__ beta,
+                                    const float* __restrict__ stats, const double* __restrict__ scratch,
+                                    bf16* __restrict__ dx, int HW, int C, int groups, int silu, int accum,
+                                    long long total_chunks) {
+  const int nchunk = C / 8;
+  const int cpg = C / groups;
+  const float inv_n = 1.0f / ((float)cpg * (float)HW);
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total_chunks;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int ck = (int)(i % nchunk);
+    const long long pix = i / nchunk;
+    const int b = (int)(pix / HW);
+    const int c0 = ck * 8;
+    const bf16x8 xv = *(const bf16x8*)(x + pix * C + c0);
+    const bf16x8 dv = *(const bf16x8*)(dy + pix * C + c0);
+    bf16x8 o;
+    if (accum) o = *(const bf16x8*)(dx + pix * C + c0);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int g = (c0 + j) / cpg;
+      const long long sg = (long long)b * groups + g;
+      const float mean = stats[sg * 2], rstd = stats[sg * 2 + 1];
+      const float S1 = (float)scratch[sg * 2] * inv_n, S2 = (float)scratch[sg * 2 + 1] * inv_n;
+      const float gmm = gamma[c0 + j];
+      const float xh = ((float)xv[j] - mean) * rstd;
+      float d = (float)dv[j];
+      if (silu) d *= silu_grad(xh * gmm + beta[c0 + j]);
+      d *= gmm;
+      float r = rstd * (d - S1 - xh * S2);
+      if (accum) r += (float)o[j];
+      o[j] = (bf16)r;
+    }
+    *(bf16x8*)(dx + pix * C + c0) = o;
+  }
+}
+
+static int gn_geometry(int HW, int C, int* threads, int* ppblk, int* nblk) {
+  const int nchunk = C / 8;
+  if (nchunk > 1024) return -1;
+  int ppb = 256 / nchunk;
+  if (ppb < 1) ppb = 1;
+  *threads = nchunk * ppb;
+  if (*threads < 128) *threads = 128;     // the LDS clear / final atomics need >= 2*GN_MAX_GROUPS threads
+  int per = ppb * 32;
+  if (per > HW) per = HW;
+  *ppblk = per;
+  *nblk = cdiv(HW, per);
+  return 0;
+}
+
+int launch_groupnorm_fwd(const bf16* x, const float* gamma, const float* beta, bf16* y, float* stats,
+                         double* scratch, int B, int HW, int C, int groups, float eps, int silu, hipStream_t s) {
+  SHAPECHK(C % 8 == 0 && C % groups == 0 && groups <= GN_MAX_GROUPS, "groupnorm: C=%d groups=%d", C, groups);
+  int threads, ppblk, nblk;
+  SHAPECHK(gn_geometry(HW, C, &threads, &ppblk, &nblk) == 0, "groupnorm: C=%d too wide", C);
+  HIPCHK(hipMemsetAsync(scratch, 0, sizeof(double) * 2 * B * groups, s));
+  hipLaunchKernelGGL(gn_stats_kernel<0>, dim3(nblk, B), dim3(threads), 0, s, x, nullptr, nullptr, nullptr, nullptr,
+                     scratch, HW, C, groups, ppblk, 0);
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(cdiv(B * groups, 64)), dim3(64), 0, s, scratch, stats, B * groups,
+                     (double)HW * (C / groups), eps);
+  const long long total = (long long)B * HW * (C / 8);
+  const int grid = (int)(cdivl(total, 256) < 4096 ? cdivl(total, 256) : 4096);
+  hipLaunchKernelGGL(gn_apply_kernel, dim3(grid), dim3(256), 0, s, x, gamma, beta, stats, y, HW, C, groups, silu,
+                     total);
+  HIPCHK(hipGetLastError());
+  return PEA_OK;
+}
+
+int launch_groupnorm_bwd(const bf16* x, const bf16* dy, const float* gamma, const float* beta, const float* stats,
+                         bf16* dx, double* scratch, int B, int HW, int C, int groups, int silu, int accum,
+                         hipStream_t s) {
+  SHAPECHK(C % 8 == 0 && C % groups == 0 && groups <= GN_MAX_GROUPS, "groupnorm: C=%d groups=%d", C, groups);
+  int threads, ppblk, nblk;
+  SHAPECHK(gn_geometry(HW, C, &threads, &ppblk, &nblk) == 0, "groupnorm: C=%d too wide", C);
+  HIPCHK(hipMemsetAsync(scratch, 0, sizeof(double) * 2 * B * groups, s));
+  hipLaunchKernelGGL(gn_stats_kernel<1>, dim3(nblk, B), dim3(threads), 0, s, x, dy, gamma, beta, stats, scratch, HW,
+                     C, groups, ppblk, silu);
+  const long long total = (long long)B * HW * (C / 8);
+  const int grid = (int)(cdivl(total, 256) < 4096 ? cdivl(total, 256) : 4096);
+  hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(grid), dim3(256), 0, s, x, dy, gamma, beta, stats, scratch, dx, HW, C,
+                     groups, silu, accum, total);
+  HIPCHK(hipGetLastError());
+  return PEA_OK;
+}
+
+// ------------------------------------------------------------------------------ LayerNorm
+// one wave per row, the whole row lives in registers (C <= 4096 -> <= 8 chunks of 8 per lane)
+#define LN_MAXCH 8
+
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const bf16* __restrict__ x, const float* __restrict__ gamma,
+                                                     const float* __restrict__ beta, bf16* __restrict__ y,
+                                                     float* __restrict__ stats, int R, int C, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= R) return;
+  const int nchunk = C / 8;
+  bf16x8 v[LN_MAXCH];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < LN_MAXCH; ++i) {
+    const int ck = lane + 64 * i;
+    if (ck < nchunk) {
+      v[i] = *(const bf16x8*)(x + (long long)row * C + ck * 8);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s += (float)v[i][j];
+    }
+  }
+  const float mean = wave_sum(s) / (float)C;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < LN_MAXCH; ++i) {
+    const int ck = lane + 64 * i;
+    if (ck < nchunk) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float d = (float)v[i][j] - mean;
+        q += d * d;
+      }
+    }
+  }
+  const float rstd = rsqrtf(wave_sum(q) / (float)C + eps);
+  if (stats && lane == 0) {
+    stats[2 * (long long)row] = mean;
+    stats[2 * (long long)row + 1] = rstd;
+  }
+#pragma unroll
+  for (int i = 0; i < LN_MAXCH; ++i) {
+    const int ck = lane + 64 * i;
+    if (ck < nchunk) {
+      bf16x8 o;
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        o[j] = (bf16)(((float)v[i][j] - mean) * rstd * gamma[ck * 8 + j] + beta[ck * 8 + j]);
+      *(bf16x8*)(y + (long long)row * C + ck * 8) = o;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16* __restrict__ x, const bf16* __restrict__ dy,
+                                                     const float* __restrict__ gamma,
+                                                     const float* __restrict__ stats, bf16* __restrict__ dx,
+                                                     float* __restrict__ dgamma, float* __restrict__ dbeta, int R,
+                                                     int C, int accum) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= R) return;
+  const int nchunk = C / 8;
+  const float mean = stats[2 * (long long)row], rstd = stats[2 * (long long)row + 1];
+  bf16x8 xv[LN_MAXCH], dv[LN_MAXCH];
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int i = 0; i < LN_MAXCH; ++i) {
+    const int ck = lane + 64 * i;
+    if (ck < nchunk) {
+      xv[i] = *(const bf16x8*)(x + (long long)row * C + ck * 8);
+      dv[i] = *(const bf16x8*)(dy + (long long)row * C + ck * 8);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float xh = ((float)xv[i][j] - mean) * rstd;
+        const float d = (float)dv[i][j] * gamma[ck * 8 + j];
+        s1 += d;
+        s2 += d * xh;
+      }
+    }
+  }
+  s1 = wave_sum(s1) / (float)C;
+  s2 = wave_sum(s2) / (float)C;
+#pragma unroll
+  for (int i = 0; i < LN_MAXCH; ++i) {
+    const int ck = lane + 64 * i;
+    if (ck < nchunk) {
+      bf16x8 o;
+      if (accum) o = *(const bf16x8*)(dx + (long long)row * C + ck * 8);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float xh = ((float)xv[i][j] - mean) * rstd;
+        const float dyv = (float)dv[i][j];
+        float r = rstd * (dyv * gamma[ck * 8 + j] - s1 - xh * s2);
+        if (accum) r += (float)o[j];
+        o[j] = (bf16)r;
+        if (dgamma) {
+          atomicAdd(&dgamma[ck * 8 + j], dyv * xh);
+          atomicAdd(&dbeta[ck * 8 + j], dyv);
+        }
+      }
+      *(bf16x8*)(dx + (long long)row * C + ck * 8) = o;
+    }
+  }
+}
+
+int launch_layernorm_fwd(const bf16* x, const float* gamma, const float* beta, bf16* y, float* stats, int R, int C,
+                         float eps, hipStream_t s) {
+  SHAPECHK(C % 8 == 0 && C <= 64 * 8 * LN_MAXCH, "layernorm: C=%d unsupported", C);
+  hipLaunchKernelGGL(ln_fwd_kernel, dim3(cdiv(R, 4)), dim3(256), 0, s, x, gamma, beta, y, stats, R, C, eps);
+  HIPCHK(hipGetLastError());
+  return PEA_OK;
+}
+
+int launch_layernorm_bwd(const bf16* x, const bf16* dy, const float* gamma, const float* stats, bf16* dx,
+                         float* dgamma, float* dbeta, int R, int C, int accum, hipStream_t s) {
+  SHAPECHK(C % 8 == 0 && C <= 64 * 8 * LN_MAXCH, "layernorm: C=%d unsupported", C);
+  hipLaunchKernelGGL(ln_bwd_kernel, dim3(cdiv(R, 4)), dim3(256), 0, s, x, dy, gamma, stats, dx, dgamma, dbeta, R, C,
+                     accum);
+  HIPCHK(hipGetLastError());
+  return PEA_OK;
+}

@@ -1,0 +1,71 @@
+// Shared device/host helpers for the gfx950 (MI355X, CDNA4) kernels.  wave = 64 lanes.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+typedef __bf16 bf16;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+#define PEA_LDS(p) ((__attribute__((address_space(3))) void*)(p))
+#define PEA_GLB(p) ((const __attribute__((address_space(1))) void*)(p))
+
+#define PEA_OK 0
+#define PEA_E_INVALID (-1)
+#define PEA_E_HIP (-2)
+#define PEA_E_SHAPE (-3)
+#define PEA_E_STATE (-4)
+#define PEA_E_NOTFOUND (-5)
+
+// thread-local last error text (C-ABI: pea_last_error)
+void pea_set_error(const char* fmt, ...);
+
+#define HIPCHK(x)                                                                              \
+  do {                                                                                         \
+    hipError_t e__ = (x);                                                                      \
+    if (e__ != hipSuccess) {                                                                   \
+      pea_set_error("%s:%d hip error %d (%s) in %s", __FILE__, __LINE__, (int)e__,            \
+                    hipGetErrorString(e__), #x);                                              \
+      return PEA_E_HIP;                                                                        \
+    }                                                                                          \
+  } while (0)
+
+#define SHAPECHK(cond, ...)                                                                    \
+  do {                                                                                         \
+    if (!(cond)) {                                                                             \
+      pea_set_error(__VA_ARGS__);                                                              \
+      return PEA_E_SHAPE;                                                                      \
+    }                                                                                          \
+  } while (0)
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_erf_grad(float x) {
+  // d/dx [x * Phi(x)] = Phi(x) + x * phi(x)
+  const float phi = 0.39894228040143268f * __expf(-0.5f * x * x);
+  return 0.5f * (1.0f + erff(x * 0.70710678118654752f)) + x * phi;
+}
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float siluf_(float x) { return x * sigmoidf_(x); }
+__device__ __forceinline__ float silu_grad(float x) {
+  const float s = sigmoidf_(x);
+  return s * (1.0f + x * (1.0f - s));
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+static inline long long cdivl(long long a, long long b) { return (a + b - 1) / b; }

@@ -1,0 +1,142 @@
+// Host-side launch interface of every HIP kernel family (one translation unit each).
+// All launchers enqueue on `stream`, never synchronise, and return PEA_OK / PEA_E_*.
+#pragma once
+#include "pea_common.h"
+
+// ---------------------------------------------------------------- gemm.hip
+// C[M][N] = epi( alpha * A[M][K] . W[N][K]^T ),  bf16 operands, fp32 accumulate (MFMA 32x32x16).
+// mode 0: A is a plain row-major matrix (lda).  mode 1: A is the im2col view of an NHWC
+// tensor for a 3x3 convolution (implicit GEMM), K = 9*Cin ordered (ky,kx,ci).
+struct GemmP {
+  int mode;
+  const bf16* A; int lda;
+  const bf16* W; int ldw;          // W[N][ldw]
+  void* C; int ldc; int out_f32;   // bf16 (default) or fp32 output; accum_f32: C(fp32) += result
+  int accum_f32;
+  int M, N, K;
+  float alpha;
+  const float* bias;               // [N] fp32 or null
+  const bf16* rowvec; int ldrv; int rows_per_batch;   // + rowvec[m / rows_per_batch][n]
+  int act;                         // 0 none, 1 GELU(erf), 2 SiLU   (applied after bias/rowvec)
+  bf16* preact; int ldpre;         // optional: store the pre-activation value (bf16)
+  const bf16* res; int ldres;      // + res[m][n] after activation (may alias C: accumulate)
+  // conv (mode 1): source NHWC [B][Hs][Ws][Cin]; output pixels [B][Ho][Wo]; M = B*Ho*Wo
+  int Hs, Ws, Cin, Ho, Wo;
+  int stride;                      // output -> virtual-input coordinate multiplier (1 or 2)
+  int shift;                       // virtual input = source upsampled by 2^shift (nearest) / zero-stuffed
+  int parity;                      // 1: only even virtual coordinates are real (transposed stride-2 conv)
+  const bf16* zeros;               // >= 16 bytes of zeros (out-of-bounds taps)
+};
+int launch_gemm(const GemmP& p, hipStream_t stream);
+
+// direct (non-MFMA) 3x3 convs for the 4-channel ends of the UNet
+// conv_in:  x NCHW fp32 [B][Cin][H][W] -> y NHWC bf16 [B][H][W][Cout];  w [Cout][Cin][3][3] fp32
+int launch_conv_in(const float* x, const float* w, const float* bias, bf16* y, int B, int Cin, int H, int W,
+                   int Cout, hipStream_t s);
+// conv_out: x NHWC bf16 [B][H][W][Cin] -> y NCHW fp32 [B][Cout][H][W];  w [Cout][3][3][Cin] fp32
+int launch_conv_out(const bf16* x, const float* w, const float* bias, float* y, int B, int Cin, int H, int W,
+                    int Cout, hipStream_t s);
+// dgrad of conv_out: dy NCHW fp32 [B][Cout][H][W] -> dx NHWC bf16 [B][H][W][Cin]
+int launch_conv_out_dgrad(const float* dy, const float* w, bf16* dx, int B, int Cin, int H, int W, int Cout,
+                          hipStream_t s);
+
+// ---------------------------------------------------------------- norm.hip
+// GroupNorm over NHWC bf16 [B][HW][C], `groups` groups; stats fp32 [B][groups][2] = (mean, rstd)
+int launch_groupnorm_fwd(const bf16* x, const float* gamma, const float* beta, bf16* y, float* stats,
+                         double* scratch, int B, int HW, int C, int groups, float eps, int silu, hipStream_t s);
+// dx (+= if accum) for y = [silu](GN(x)); gamma/beta frozen
+int launch_groupnorm_bwd(const bf16* x, const bf16* dy, const float* gamma, const float* beta, const float* stats,
+                         bf16* dx, double* scratch, int B, int HW, int C, int groups, int silu, int accum,
+                         hipStream_t s);
+// LayerNorm over rows [R][C] (C % 8 == 0, C <= 4096); stats fp32 [R][2] = (mean, rstd)
+int launch_layernorm_fwd(const bf16* x, const float* gamma, const float* beta, bf16* y, float* stats, int R, int C,
+                         float eps, hipStream_t s);
+int launch_layernorm_bwd(const bf16* x, const bf16* dy, const float* gamma, const float* stats, bf16* dx,
+                         float* dgamma, float* dbeta, int R, int C, int accum, hipStream_t s);
+
+// ---------------------------------------------------------------- attention.hip
+// O[b][q][h*64+d] = softmax(scale * Q K^T) V per (b, head); head_dim = 64.
+// Q rows stride ldq elements, batch stride = Sq*ldq (same for K,V with Skv, ldk/ldv).
+struct AttnP {
+  const bf16 *Q, *K, *V; int ldq, ldk, ldv;
+  bf16* O; int ldo;
+  float* lse;                      // [B][H][Sq]  (natural-log-sum-exp of scaled scores), may be null
+  int B, H, Sq, Skv;
+  float scale;
+  // backward
+  const bf16* dO; int lddo;
+  bf16 *dQ, *dK, *dV; int lddq, lddk, lddv;
+  float* delta;                    // [B][H][Sq] scratch: rowsum(dO * O)
+  int accum_dq, accum_dkv;         // += into existing gradients
+};
+int launch_attention_fwd(const AttnP& p, hipStream_t s);
+int launch_attention_bwd(const AttnP& p, hipStream_t s);
+
+// ---------------------------------------------------------------- elementwise.hip
+int launch_geglu_fwd(const bf16* hg, bf16* y, long long rows, int inner, hipStream_t s);   // hg [rows][2*inner]
+int launch_geglu_bwd(const bf16* hg, const bf16* dy, bf16* dhg, long long rows, int inner, hipStream_t s);
+int launch_add(const bf16* a, const bf16* b, bf16* y, long long n, hipStream_t s);          // y = a + b
+int launch_silu_fwd(const bf16* x, bf16* y, long long n, hipStream_t s);
+int launch_silu_bwd(const bf16* x, const bf16* dy, bf16* dx, long long n, int accum, hipStream_t s);
+int launch_gelu_fwd(const bf16* x, bf16* y, long long n, hipStream_t s);
+int launch_gelu_bwd(const bf16* x, const bf16* dy, bf16* dx, long long n, int accum, hipStream_t s);
+// concat along channels: y[r][0:C1] = a[r], y[r][C1:C1+C2] = b[r]
+int launch_concat2(const bf16* a, int C1, const bf16* b, int C2, bf16* y, long long rows, hipStream_t s);
+// split-add (backward of concat): da[r] (+)= dy[r][0:C1]; db[r] (+)= dy[r][C1:]
+int launch_split2(const bf16* dy, int C1, int C2, bf16* da, int accum_a, bf16* db, int accum_b, long long rows,
+                  hipStream_t s);
+// 2x2 sum pooling NHWC (backward of nearest 2x upsample): x [B][2H][2W][C] -> y [B][H][W][C]
+int launch_sumpool2(const bf16* x, bf16* y, int B, int H, int W, int C, int accum, hipStream_t s);
+int launch_cast_f32_bf16(const float* x, bf16* y, long long n, hipStream_t s);
+int launch_cast_bf16_f32(const bf16* x, float* y, long long n, hipStream_t s);
+int launch_transpose_bf16(const bf16* x, bf16* y, int R, int C, int ldy, hipStream_t s);   // y[c][r] = x[r][c]
+int launch_transpose_f32_bf16(const float* x, bf16* y, int R, int C, int ldy, hipStream_t s);
+int launch_nhwc_to_nchw_f32(const bf16* x, float* y, int B, int HW, int C, hipStream_t s);
+// conv weight repacks (fp32 torch layout [Co][Ci][3][3]) -> bf16
+int launch_pack_conv_fwd(const float* w, bf16* y, int Co, int Ci, hipStream_t s);          // y[co][(ky,kx,ci)]
+int launch_pack_conv_dgrad(const float* w, bf16* y, int Co, int Ci, hipStream_t s);        // y[ci][(2-ky,2-kx,co)]
+int launch_pack_conv_out(const float* w, float* y, int Co, int Ci, hipStream_t s);         // y[co][ky][kx][ci] fp32
+// sinusoidal timestep embedding (cos|sin), out bf16 [n][dim]; t given as fp32 values
+int launch_timestep_embed(const float* t, bf16* y, int n, int dim, hipStream_t s);
+// x_t = sqrt(ac[t]) x0 + sqrt(1-ac[t]) eps   (fp32 NCHW), ac table fp32[1000]
+int launch_add_noise(const float* x0, const float* eps, const long long* t, const float* ac, float* xt, int B,
+                     long long per, hipStream_t s);
+// y[b] = mask[b] ? u[b] : c[b]  rows of `per` bf16
+int launch_select_rows(const bf16* c, const bf16* u, const unsigned char* mask, bf16* y, int B, long long per,
+                       hipStream_t s);
+// backward of select: dc[b] = mask? 0 : dy[b]; du[b] = mask ? dy[b] : 0
+int launch_select_rows_bwd(const bf16* dy, const unsigned char* mask, bf16* dc, bf16* du, int B, long long per,
+                           hipStream_t s);
+// mean over tokens: y[b][c] = mean_l x[b][l][c];  bwd: dx[b][l][c] (+)= dy[b][c]/L
+int launch_mean_tokens(const bf16* x, bf16* y, int B, int L, int C, hipStream_t s);
+int launch_mean_tokens_bwd(const bf16* dy, bf16* dx, int B, int L, int C, int accum, hipStream_t s);
+// column sums of a bf16 matrix into fp32 (bias gradient): db[c] (+)= sum_r x[r][c]
+int launch_colsum(const bf16* x, float* db, int R, int C, int accum, hipStream_t s);
+int launch_fill_random_bf16(bf16* p, long long n, unsigned long long seed, float scale, hipStream_t s);
+int launch_fill_random_f32(float* p, long long n, unsigned long long seed, float scale, float offset, hipStream_t s);
+// fused AdamW over a flat fp32 buffer
+int launch_adamw(float* w, const float* g, float* m, float* v, long long n, float lr, float b1, float b2, float eps,
+                 float wd, int step, float gscale, hipStream_t s);
+
+// ---------------------------------------------------------------- kdloss.hip
+// Fused KD loss (train_sdxl_zh.py:399-441): all feature taps + the two noise terms in ONE launch.
+#define PEA_MAX_TAPS 12
+struct KdLossP {
+  int ntaps;
+  const bf16* fs[PEA_MAX_TAPS];    // student taps (any layout, elementwise-paired with ft)
+  const bf16* ft[PEA_MAX_TAPS];
+  bf16* dfs[PEA_MAX_TAPS];         // gradient seeds dL/dF_S (overwritten), may be null
+  long long per[PEA_MAX_TAPS];     // elements per sample
+  const float *eps_s, *eps, *eps_t;  // fp32 [B][per_eps]
+  float* deps_s;                   // dL/d eps_s fp32, may be null
+  long long per_eps;
+  const long long* zh;             // [B] int64 (1 = native caption)
+  int B;
+  float feat_weight;               // 0.1
+  float* partial;                  // [3 + ntaps] fp32 sums (zeroed by the launcher)
+  float* losses;                   // [4]: total, noise, logits, features (written by a finishing kernel)
+  const int* tap_finite_flags;     // unused (SD1.5 NaN guard handled through `nan_guard`)
+  int nan_guard;
+  float grad_scale;                // multiplies every seed (1/world for DP averaging, usually 1)
+};
+int launch_kd_loss(const KdLossP& p, hipStream_t s);

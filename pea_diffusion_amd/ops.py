@@ -1,0 +1,204 @@
+"""Operator-level Python bindings over the C ABI (include/pea_hip.h, `pea_op_*`).
+
+Thin: torch tensors provide device memory and the current stream, nothing else.  Every function
+takes/returns CUDA(HIP) tensors; bf16 activations are token-major ("NHWC").
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import List, Optional, Sequence
+
+import torch
+
+from ._lib import check, lib, ptr, stream_ptr
+
+BF = torch.bfloat16
+
+
+def _dev(t):
+    return t.device
+
+
+def gemm(a, w, bias=None, rowvec=None, rows_per_batch=1, act=0, res=None, want_preact=False, out_f32=False,
+         alpha=1.0, out=None, accum_f32=False):
+    """act(alpha * a @ w.T + bias + rowvec[m // rows_per_batch]) + res ; a [M,K] bf16, w [N,K] bf16."""
+    M, K = a.shape
+    N = w.shape[0]
+    if out is None:
+        out = torch.empty(M, N, device=a.device, dtype=torch.float32 if out_f32 else BF)
+    pre = torch.empty(M, N, device=a.device, dtype=BF) if want_preact else None
+    check(lib().pea_op_gemm(ptr(a), a.stride(0), ptr(w), w.stride(0), ptr(out), out.stride(0), M, N, K, alpha,
+                            ptr(bias), ptr(rowvec), rowvec.stride(0) if rowvec is not None else 0, rows_per_batch,
+                            act, ptr(pre), N, ptr(res), res.stride(0) if res is not None else 0,
+                            int(out.dtype == torch.float32), int(accum_f32), stream_ptr()))
+    return (out, pre) if want_preact else out
+
+
+def pack_conv(w_fp32, dgrad=False):
+    Co, Ci = w_fp32.shape[:2]
+    out = torch.empty((Ci, 9 * Co) if dgrad else (Co, 9 * Ci), device=w_fp32.device, dtype=BF)
+    check(lib().pea_op_pack_conv(ptr(w_fp32.contiguous()), ptr(out), Co, Ci, int(dgrad), stream_ptr()))
+    return out
+
+
+def conv3x3(x, w_packed, bias=None, stride=1, upsample2x=False, transposed2=False, rowvec=None, res=None):
+    """x [B,H,W,Cin] bf16 NHWC; w_packed [Cout, 9*Cin] -> [B,Ho,Wo,Cout]."""
+    B, H, W, Cin = x.shape
+    Cout = w_packed.shape[0]
+    sh = 1 if (upsample2x or transposed2) else 0
+    Hv, Wv = H << sh, W << sh
+    Ho, Wo = ((Hv + 1) // 2, (Wv + 1) // 2) if stride == 2 else (Hv, Wv)
+    y = torch.empty(B, Ho, Wo, Cout, device=x.device, dtype=BF)
+    check(lib().pea_op_conv3x3(ptr(x), ptr(w_packed), ptr(y), B, H, W, Cin, Cout, stride, int(upsample2x),
+                               int(transposed2), ptr(bias), ptr(rowvec),
+                               rowvec.stride(0) if rowvec is not None else 0, ptr(res), stream_ptr()))
+    return y
+
+
+def conv_in(x_nchw, w, bias):
+    B, Cin, H, W = x_nchw.shape
+    Cout = w.shape[0]
+    y = torch.empty(B, H, W, Cout, device=x_nchw.device, dtype=BF)
+    check(lib().pea_op_conv_in(ptr(x_nchw), ptr(w.contiguous()), ptr(bias), ptr(y), B, Cin, H, W, Cout, stream_ptr()))
+    return y
+
+
+def pack_conv_out(w):
+    Co, Ci = w.shape[:2]
+    out = torch.empty(Co, 3, 3, Ci, device=w.device, dtype=torch.float32)
+    check(lib().pea_op_pack_conv_out(ptr(w.contiguous()), ptr(out), Co, Ci, stream_ptr()))
+    return out
+
+
+def conv_out(x_nhwc, w_packed, bias):
+    B, H, W, Cin = x_nhwc.shape
+    Cout = w_packed.shape[0]
+    y = torch.empty(B, Cout, H, W, device=x_nhwc.device, dtype=torch.float32)
+    check(lib().pea_op_conv_out(ptr(x_nhwc), ptr(w_packed), ptr(bias), ptr(y), B, Cin, H, W, Cout, stream_ptr()))
+    return y
+
+
+def conv_out_dgrad(dy_nchw, w_packed, Cin):
+    B, Cout, H, W = dy_nchw.shape
+    dx = torch.empty(B, H, W, Cin, device=dy_nchw.device, dtype=BF)
+    check(lib().pea_op_conv_out_dgrad(ptr(dy_nchw), ptr(w_packed), ptr(dx), B, Cin, H, W, Cout, stream_ptr()))
+    return dx
+
+
+def groupnorm_fwd(x, gamma, beta, groups=32, eps=1e-5, silu=False):
+    B, HW, C = x.shape
+    y = torch.empty_like(x)
+    stats = torch.empty(B, groups, 2, device=x.device, dtype=torch.float32)
+    scratch = torch.empty(B * groups * 2, device=x.device, dtype=torch.float64)
+    check(lib().pea_op_groupnorm_fwd(ptr(x), ptr(gamma), ptr(beta), ptr(y), ptr(stats), ptr(scratch), B, HW, C, groups,
+                                     eps, int(silu), stream_ptr()))
+    return y, stats
+
+
+def groupnorm_bwd(x, dy, gamma, beta, stats, groups=32, silu=False, accum_into=None):
+    B, HW, C = x.shape
+    dx = accum_into if accum_into is not None else torch.empty_like(x)
+    scratch = torch.empty(B * groups * 2, device=x.device, dtype=torch.float64)
+    check(lib().pea_op_groupnorm_bwd(ptr(x), ptr(dy), ptr(gamma), ptr(beta), ptr(stats), ptr(dx), ptr(scratch), B, HW,
+                                     C, groups, int(silu), int(accum_into is not None), stream_ptr()))
+    return dx
+
+
+def layernorm_fwd(x, gamma, beta, eps=1e-5):
+    R, C = x.shape
+    y = torch.empty_like(x)
+    stats = torch.empty(R, 2, device=x.device, dtype=torch.float32)
+    check(lib().pea_op_layernorm_fwd(ptr(x), ptr(gamma), ptr(beta), ptr(y), ptr(stats), R, C, eps, stream_ptr()))
+    return y, stats
+
+
+def layernorm_bwd(x, dy, gamma, stats, want_param_grads=False, accum_into=None):
+    R, C = x.shape
+    dx = accum_into if accum_into is not None else torch.empty_like(x)
+    dg = torch.zeros(C, device=x.device, dtype=torch.float32) if want_param_grads else None
+    db = torch.zeros(C, device=x.device, dtype=torch.float32) if want_param_grads else None
+    check(lib().pea_op_layernorm_bwd(ptr(x), ptr(dy), ptr(gamma), ptr(stats), ptr(dx), ptr(dg), ptr(db), R, C,
+                                     int(accum_into is not None), stream_ptr()))
+    return (dx, dg, db) if want_param_grads else dx
+
+
+def attention_fwd(q, k, v, heads, scale=None):
+    """q [B,Sq,H*64], k/v [B,Skv,H*64] bf16 -> (o [B,Sq,H*64], lse [B,H,Sq])."""
+    B, Sq, C = q.shape
+    Skv = k.shape[1]
+    scale = scale if scale is not None else 64 ** -0.5
+    o = torch.empty(B, Sq, C, device=q.device, dtype=BF)
+    lse = torch.empty(B, heads, Sq, device=q.device, dtype=torch.float32)
+    check(lib().pea_op_attention_fwd(ptr(q), q.stride(1), ptr(k), k.stride(1), ptr(v), v.stride(1), ptr(o), C, ptr(lse),
+                                     B, heads, Sq, Skv, scale, stream_ptr()))
+    return o, lse
+
+
+def attention_bwd(q, k, v, o, do, lse, heads, scale=None):
+    B, Sq, C = q.shape
+    Skv = k.shape[1]
+    scale = scale if scale is not None else 64 ** -0.5
+    dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+    delta = torch.empty(B, heads, Sq, device=q.device, dtype=torch.float32)
+    check(lib().pea_op_attention_bwd(ptr(q), q.stride(1), ptr(k), k.stride(1), ptr(v), v.stride(1), ptr(o), C, ptr(do),
+                                     C, ptr(lse), ptr(delta), ptr(dq), C, ptr(dk), C, ptr(dv), C, B, heads, Sq, Skv,
+                                     scale, 0, 0, stream_ptr()))
+    return dq, dk, dv
+
+
+def geglu_fwd(hg):
+    rows, two = hg.shape
+    y = torch.empty(rows, two // 2, device=hg.device, dtype=BF)
+    check(lib().pea_op_geglu_fwd(ptr(hg), ptr(y), rows, two // 2, stream_ptr()))
+    return y
+
+
+def geglu_bwd(hg, dy):
+    d = torch.empty_like(hg)
+    check(lib().pea_op_geglu_bwd(ptr(hg), ptr(dy), ptr(d), hg.shape[0], hg.shape[1] // 2, stream_ptr()))
+    return d
+
+
+def sumpool2(x):
+    B, H2, W2, C = x.shape
+    y = torch.empty(B, H2 // 2, W2 // 2, C, device=x.device, dtype=BF)
+    check(lib().pea_op_sumpool2(ptr(x), ptr(y), B, H2 // 2, W2 // 2, C, 0, stream_ptr()))
+    return y
+
+
+def timestep_embed(t_f32, dim):
+    y = torch.empty(t_f32.numel(), dim, device=t_f32.device, dtype=BF)
+    check(lib().pea_op_timestep_embed(ptr(t_f32), ptr(y), t_f32.numel(), dim, stream_ptr()))
+    return y
+
+
+def add_noise(x0, eps, t, ac):
+    xt = torch.empty_like(x0)
+    check(lib().pea_op_add_noise(ptr(x0), ptr(eps), ptr(t), ptr(ac), ptr(xt), x0.shape[0], x0[0].numel(), stream_ptr()))
+    return xt
+
+
+def kd_loss(taps_s: Sequence[torch.Tensor], taps_t: Sequence[torch.Tensor], eps_s, eps, eps_t, zh,
+            feat_weight=0.1, nan_guard=False, grad_scale=1.0, want_grads=True):
+    """-> (losses fp32[4] device, [dL/dtap_s], dL/d eps_s).  taps: bf16 [B, ...] paired layouts."""
+    n = len(taps_s)
+    B = eps_s.shape[0]
+    dev = eps_s.device
+    dt = [torch.empty_like(t) for t in taps_s] if want_grads else []
+    de = torch.empty_like(eps_s) if want_grads else None
+    arr = ctypes.c_void_p * max(n, 1)
+    a_s = arr(*[t.data_ptr() for t in taps_s])
+    a_t = arr(*[t.data_ptr() for t in taps_t])
+    a_d = arr(*[t.data_ptr() for t in dt]) if want_grads else None
+    per = (ctypes.c_longlong * max(n, 1))(*[t[0].numel() for t in taps_s])
+    losses = torch.empty(4, device=dev, dtype=torch.float32)
+    ws = torch.empty(64, device=dev, dtype=torch.float64)
+    check(lib().pea_op_kd_loss(n, a_s, a_t, a_d, per, ptr(eps_s), ptr(eps), ptr(eps_t), ptr(de), eps_s[0].numel(),
+                               ptr(zh), B, feat_weight, int(nan_guard), grad_scale, ptr(losses), ptr(ws),
+                               stream_ptr()))
+    return losses, dt, de
+
+
+def adamw_(w, g, m, v, lr, step, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0, grad_scale=1.0):
+    check(lib().pea_op_adamw(ptr(w), ptr(g), ptr(m), ptr(v), w.numel(), lr, beta1, beta2, eps, weight_decay, step,
+                             grad_scale, stream_ptr()))

@@ -1,0 +1,294 @@
+"""Kernel-level parity (-m gpu): every HIP kernel family, called through the C ABI, against a
+plain torch fp32 CPU reference of the same op on the same bf16-rounded inputs.
+
+Tolerances (written here, used everywhere below):
+  * fp32-stored outputs (losses, fp32 GEMM output, conv_out, add_noise):   rtol 1e-3, atol 1e-4
+  * bf16-stored outputs: the reference is compared after the same final rounding; allowed
+    deviation is 1 bf16 ulp (rtol 2^-7) plus atol scaled to the tensor (2^-7 * rms), because a
+    differently-ordered fp32 accumulation can flip the final rounding of an element.
+"""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+BF = torch.bfloat16
+
+
+@pytest.fixture(scope="module")
+def ops():
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a MI355X (torch.cuda.is_available() is False)")
+    from pea_diffusion_amd import ops as o
+    return o
+
+
+def bfr(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(BF)
+
+
+def close_bf16(name, got, ref, ulps=1.0):
+    got = got.detach().float().cpu()
+    ref = ref.detach().float()
+    rms = ref.pow(2).mean().sqrt().item() + 1e-30
+    err = (got - ref).abs()
+    tol = ulps * (2.0 ** -7) * (ref.abs() + rms)
+    bad = (err > tol).float().mean().item()
+    rel_l2 = ((got - ref).pow(2).sum().sqrt() / (ref.pow(2).sum().sqrt() + 1e-30)).item()
+    print(f"[{name}] max_abs={err.max().item():.3e} rel_l2={rel_l2:.3e} rms={rms:.3e} frac_bad={bad:.2e}")
+    assert torch.isfinite(got).all(), name
+    assert bad == 0.0 and rel_l2 < 6e-3, f"{name}: frac_bad={bad} rel_l2={rel_l2}"
+
+
+def close_f32(name, got, ref, rtol=1e-3, atol=1e-4):
+    got = got.detach().float().cpu()
+    ref = ref.detach().float()
+    err = (got - ref).abs()
+    print(f"[{name}] max_abs={err.max().item():.3e} ref_max={ref.abs().max().item():.3e}")
+    torch.testing.assert_close(got, ref, rtol=rtol, atol=atol)
+
+
+# ------------------------------------------------------------------------------------ GEMM
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 384, 512), (308, 640, 2048), (4, 1280, 320),
+                                   (1000, 100, 192), (2048, 5120, 640)])
+def test_gemm_plain(ops, M, N, K):
+    a, w = bfr(M, K, seed=1), bfr(N, K, seed=2, scale=K ** -0.5)
+    out = ops.gemm(a.cuda(), w.cuda())
+    close_bf16(f"gemm {M}x{N}x{K}", out, a.float() @ w.float().T)
+
+
+def test_gemm_epilogues(ops):
+    M, N, K, rpb = 192, 256, 128, 48
+    a, w = bfr(M, K, seed=1), bfr(N, K, seed=2, scale=K ** -0.5)
+    bias = torch.randn(N, generator=torch.Generator().manual_seed(3))
+    rv, res = bfr(M // rpb, N, seed=4), bfr(M, N, seed=5)
+    base = a.float() @ w.float().T * 0.5 + bias + rv.float().repeat_interleave(rpb, 0)
+    for act, fn in [(0, lambda t: t), (1, F.gelu), (2, F.silu)]:
+        out, pre = ops.gemm(a.cuda(), w.cuda(), bias=bias.cuda(), rowvec=rv.cuda(), rows_per_batch=rpb, act=act,
+                            res=res.cuda(), want_preact=True, alpha=0.5)
+        close_bf16(f"gemm epi act={act}", out, fn(base) + res.float())
+        close_bf16(f"gemm preact act={act}", pre, base)
+    o32 = ops.gemm(a.cuda(), w.cuda(), out_f32=True)
+    close_f32("gemm fp32 out", o32, a.float() @ w.float().T, rtol=1e-3, atol=1e-4)
+    acc = torch.ones(M, N, device="cuda")
+    ops.gemm(a.cuda(), w.cuda(), out=acc, accum_f32=True)
+    close_f32("gemm fp32 accum", acc, a.float() @ w.float().T + 1.0)
+    # accumulate into a bf16 gradient buffer: res aliases the output
+    gbuf = res.clone().cuda()
+    ops.gemm(a.cuda(), w.cuda(), res=gbuf, out=gbuf)
+    close_bf16("gemm bf16 accumulate", gbuf, a.float() @ w.float().T + res.float())
+
+
+# ------------------------------------------------------------------------------------ conv
+def _nhwc(x_nchw):
+    return x_nchw.permute(0, 2, 3, 1).contiguous()
+
+
+@pytest.mark.parametrize("B,H,Cin,Cout,stride,ups", [(2, 16, 64, 128, 1, False), (1, 32, 320, 320, 1, False),
+                                                     (2, 16, 128, 128, 2, False), (2, 8, 64, 64, 1, True),
+                                                     (1, 12, 192, 64, 1, False)])
+def test_conv3x3_fwd(ops, B, H, Cin, Cout, stride, ups):
+    x = bfr(B, Cin, H, H, seed=1)
+    w = torch.randn(Cout, Cin, 3, 3, generator=torch.Generator().manual_seed(2)) * (9 * Cin) ** -0.5
+    bias = torch.randn(Cout, generator=torch.Generator().manual_seed(3))
+    wq = w.to(BF).float()
+    xin = F.interpolate(x.float(), scale_factor=2.0, mode="nearest") if ups else x.float()
+    ref = F.conv2d(xin, wq, bias, stride=stride, padding=1)
+    wp = ops.pack_conv(wq.cuda())
+    y = ops.conv3x3(_nhwc(x).cuda(), wp, bias=bias.cuda(), stride=stride, upsample2x=ups)
+    close_bf16(f"conv3x3 B{B} H{H} {Cin}->{Cout} s{stride} ups{ups}", y, _nhwc(ref))
+
+
+def test_conv3x3_epilogue_rowvec_res(ops):
+    B, H, Cin, Cout = 2, 8, 64, 128
+    x = bfr(B, Cin, H, H, seed=1)
+    wq = (torch.randn(Cout, Cin, 3, 3, generator=torch.Generator().manual_seed(2)) * (9 * Cin) ** -0.5).to(BF).float()
+    bias = torch.randn(Cout, generator=torch.Generator().manual_seed(3))
+    temb, res = bfr(B, Cout, seed=4), bfr(B, H, H, Cout, seed=5)
+    ref = F.conv2d(x.float(), wq, bias, padding=1) + temb.float()[:, :, None, None] + res.float().permute(0, 3, 1, 2)
+    y = ops.conv3x3(_nhwc(x).cuda(), ops.pack_conv(wq.cuda()), bias=bias.cuda(), rowvec=temb.cuda(), res=res.cuda())
+    close_bf16("conv3x3 + temb + res", y, _nhwc(ref))
+
+
+@pytest.mark.parametrize("stride,ups", [(1, False), (2, False), (1, True)])
+def test_conv3x3_dgrad(ops, stride, ups):
+    B, H, Cin, Cout = 2, 8, 64, 128
+    x = bfr(B, Cin, H, H, seed=1).float().requires_grad_(True)
+    wq = (torch.randn(Cout, Cin, 3, 3, generator=torch.Generator().manual_seed(2)) * (9 * Cin) ** -0.5).to(BF).float()
+    xin = F.interpolate(x, scale_factor=2.0, mode="nearest") if ups else x
+    y = F.conv2d(xin, wq, None, stride=stride, padding=1)
+    dy = bfr(*y.shape, seed=7)
+    y.backward(dy.float())
+    wd = ops.pack_conv(wq.cuda(), dgrad=True)            # [Cin, 9*Cout]
+    dyn = _nhwc(dy).cuda()
+    if stride == 2:
+        dx = ops.conv3x3(dyn, wd, transposed2=True)      # zero-stuffed transposed conv at the input resolution
+    elif ups:
+        dx = ops.sumpool2(ops.conv3x3(dyn, wd))          # dgrad at the upsampled resolution, then 2x2 sum
+    else:
+        dx = ops.conv3x3(dyn, wd)
+    close_bf16(f"conv3x3 dgrad s{stride} ups{ups}", dx, _nhwc(x.grad), ulps=2.0)
+
+
+def test_conv_in_out(ops):
+    B, H, C = 2, 16, 64
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(B, 4, H, H, generator=g)
+    w_in, b_in = torch.randn(C, 4, 3, 3, generator=g) * 0.2, torch.randn(C, generator=g)
+    y = ops.conv_in(x.cuda(), w_in.cuda(), b_in.cuda())
+    close_bf16("conv_in", y, _nhwc(F.conv2d(x, w_in, b_in, padding=1)))
+    h = bfr(B, C, H, H, seed=3)
+    w_out, b_out = torch.randn(4, C, 3, 3, generator=g) * 0.05, torch.randn(4, generator=g)
+    wp = ops.pack_conv_out(w_out.cuda())
+    close_f32("conv_out", ops.conv_out(_nhwc(h).cuda(), wp, b_out.cuda()), F.conv2d(h.float(), w_out, b_out, padding=1))
+    hh = h.float().requires_grad_(True)
+    dy = torch.randn(B, 4, H, H, generator=g)
+    F.conv2d(hh, w_out, b_out, padding=1).backward(dy)
+    close_bf16("conv_out dgrad", ops.conv_out_dgrad(dy.cuda(), wp, C), _nhwc(hh.grad))
+
+
+# ------------------------------------------------------------------------------------ norms
+@pytest.mark.parametrize("B,HW,C,silu", [(2, 256, 320, True), (2, 64, 64, False), (1, 1024, 960, True),
+                                         (3, 16, 2560, True), (2, 4096, 640, False)])
+def test_groupnorm(ops, B, HW, C, silu):
+    x = (bfr(B, HW, C, seed=1).float() * 1.5 + 0.7).to(BF)
+    g = torch.Generator().manual_seed(2)
+    gamma, beta = 1 + 0.3 * torch.randn(C, generator=g), 0.2 * torch.randn(C, generator=g)
+    xr = x.float().requires_grad_(True)
+    z = F.group_norm(xr.permute(0, 2, 1), 32, gamma, beta, 1e-5).permute(0, 2, 1)
+    yr = F.silu(z) if silu else z
+    y, stats = ops.groupnorm_fwd(x.cuda(), gamma.cuda(), beta.cuda(), 32, 1e-5, silu)
+    close_bf16(f"groupnorm fwd C{C} silu{silu}", y, yr)
+    dy = bfr(B, HW, C, seed=3)
+    yr.backward(dy.float())
+    dx = ops.groupnorm_bwd(x.cuda(), dy.cuda(), gamma.cuda(), beta.cuda(), stats, 32, silu)
+    close_bf16(f"groupnorm bwd C{C} silu{silu}", dx, xr.grad, ulps=2.0)
+
+
+@pytest.mark.parametrize("R,C", [(64, 640), (308, 1024), (100, 1280), (16, 128), (7, 2048)])
+def test_layernorm(ops, R, C):
+    x = (bfr(R, C, seed=1).float() * 2 - 0.5).to(BF)
+    g = torch.Generator().manual_seed(2)
+    gamma, beta = (1 + 0.3 * torch.randn(C, generator=g)).requires_grad_(True), (0.2 * torch.randn(C, generator=g)).requires_grad_(True)
+    xr = x.float().requires_grad_(True)
+    yr = F.layer_norm(xr, (C,), gamma, beta, 1e-5)
+    y, stats = ops.layernorm_fwd(x.cuda(), gamma.detach().cuda(), beta.detach().cuda())
+    close_bf16(f"layernorm fwd {R}x{C}", y, yr)
+    dy = bfr(R, C, seed=3)
+    yr.backward(dy.float())
+    dx, dg, db = ops.layernorm_bwd(x.cuda(), dy.cuda(), gamma.detach().cuda(), stats, want_param_grads=True)
+    close_bf16(f"layernorm bwd {R}x{C}", dx, xr.grad, ulps=2.0)
+    close_f32("layernorm dgamma", dg, gamma.grad, rtol=2e-3, atol=2e-3)
+    close_f32("layernorm dbeta", db, beta.grad, rtol=2e-3, atol=2e-3)
+
+
+# ------------------------------------------------------------------------------------ attention
+def _attn_ref(q, k, v, H):
+    B, Sq, C = q.shape
+    qh = q.view(B, Sq, H, 64).transpose(1, 2)
+    kh = k.view(B, -1, H, 64).transpose(1, 2)
+    vh = v.view(B, -1, H, 64).transpose(1, 2)
+    s = qh @ kh.transpose(-1, -2) * 0.125
+    o = (torch.softmax(s, -1) @ vh).transpose(1, 2).reshape(B, Sq, C)
+    return o, torch.logsumexp(s, -1)
+
+
+@pytest.mark.parametrize("use_tr", [1, 0])
+@pytest.mark.parametrize("B,H,Sq,Skv", [(2, 2, 256, 256), (1, 3, 128, 77), (2, 2, 16, 16), (1, 2, 1024, 200),
+                                        (1, 1, 64, 7)])
+def test_attention_fwd_bwd(ops, use_tr, B, H, Sq, Skv):
+    from pea_diffusion_amd._lib import lib
+    lib().pea_debug_set_attn_tr(use_tr)
+    try:
+        q, k, v = bfr(B, Sq, H * 64, seed=1), bfr(B, Skv, H * 64, seed=2), bfr(B, Skv, H * 64, seed=3)
+        qr, kr, vr = [t.float().requires_grad_(True) for t in (q, k, v)]
+        oref, lref = _attn_ref(qr, kr, vr, H)
+        o, lse = ops.attention_fwd(q.cuda(), k.cuda(), v.cuda(), H)
+        tag = f"attn tr{use_tr} B{B} H{H} Sq{Sq} Skv{Skv}"
+        close_bf16(tag + " O", o, oref, ulps=2.0)
+        close_f32(tag + " lse", lse, lref, rtol=1e-3, atol=2e-3)
+        do = bfr(B, Sq, H * 64, seed=4)
+        oref.backward(do.float())
+        dq, dk, dv = ops.attention_bwd(q.cuda(), k.cuda(), v.cuda(), o, do.cuda(), lse, H)
+        close_bf16(tag + " dQ", dq, qr.grad, ulps=4.0)
+        close_bf16(tag + " dK", dk, kr.grad, ulps=4.0)
+        close_bf16(tag + " dV", dv, vr.grad, ulps=4.0)
+    finally:
+        lib().pea_debug_set_attn_tr(1)
+
+
+def test_attention_softmax_spike(ops):
+    """forces a late running-max jump (online-softmax rescale path)"""
+    B, H, Sq, Skv = 1, 1, 64, 256
+    q, k, v = bfr(B, Sq, 64, seed=1), bfr(B, Skv, 64, seed=2), bfr(B, Skv, 64, seed=3)
+    k[0, 200] = (q[0, 5].float() * 4).to(BF)
+    oref, lref = _attn_ref(q.float(), k.float(), v.float(), H)
+    o, lse = ops.attention_fwd(q.cuda(), k.cuda(), v.cuda(), H)
+    close_bf16("attn spike O", o, oref, ulps=2.0)
+    close_f32("attn spike lse", lse, lref, rtol=1e-3, atol=2e-3)
+
+
+# ------------------------------------------------------------------------------------ glue
+def test_geglu(ops):
+    hg = bfr(96, 2 * 320, seed=1)
+    hr = hg.float().requires_grad_(True)
+    h, gate = hr.chunk(2, -1)
+    yr = h * F.gelu(gate)
+    close_bf16("geglu fwd", ops.geglu_fwd(hg.cuda()), yr)
+    dy = bfr(96, 320, seed=2)
+    yr.backward(dy.float())
+    close_bf16("geglu bwd", ops.geglu_bwd(hg.cuda(), dy.cuda()), hr.grad, ulps=2.0)
+
+
+def test_timestep_embed_and_add_noise(ops):
+    from oracle.step_ref import add_noise, ddpm_alphas_cumprod
+    from oracle.unet_ref import timestep_embedding
+    t = torch.tensor([0., 10., 250., 999., 1024.])
+    close_bf16("timestep_embed 320", ops.timestep_embed(t.cuda(), 320), timestep_embedding(t, 320), ulps=2.0)
+    close_bf16("timestep_embed 256", ops.timestep_embed(t.cuda(), 256), timestep_embedding(t, 256), ulps=2.0)
+    g = torch.Generator().manual_seed(0)
+    x0, eps = torch.randn(4, 4, 16, 16, generator=g), torch.randn(4, 4, 16, 16, generator=g)
+    ts = torch.tensor([10, 250, 500, 999])
+    xt = ops.add_noise(x0.cuda(), eps.cuda(), ts.cuda(), ddpm_alphas_cumprod().cuda())
+    close_f32("add_noise", xt, add_noise(x0, eps, ts), rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("zh", [[1, 0, 0, 1], [0, 0, 0, 0], [1, 1, 1, 1]])
+def test_kd_loss(ops, zh):
+    from oracle.step_ref import kd_losses
+    B = 4
+    shapes = [(B, 64, 8, 8), (B, 128, 4, 4), (B, 128, 4, 4), (B, 128, 8, 8), (B, 128, 16, 16), (B, 64, 16, 16),
+              (B, 320, 24, 24)]
+    fs = [bfr(*s, seed=10 + i) for i, s in enumerate(shapes)]
+    ft = [bfr(*s, seed=30 + i) for i, s in enumerate(shapes)]
+    g = torch.Generator().manual_seed(5)
+    es, e, et = [torch.randn(B, 4, 16, 16, generator=g) for _ in range(3)]
+    z = torch.tensor(zh)
+    fsr = [t.float().requires_grad_(True) for t in fs]
+    esr = es.clone().requires_grad_(True)
+    tot, l0, l1, l2 = kd_losses(esr, e, et, fsr, [t.float() for t in ft], z)
+    tot.backward()
+    losses, dt, de = ops.kd_loss([t.cuda() for t in fs], [t.cuda() for t in ft], es.cuda(), e.cuda(), et.cuda(), z.cuda())
+    close_f32("kd losses", losses, torch.stack([tot, l0, l1, l2]).detach(), rtol=1e-3, atol=1e-5)
+    close_f32("kd deps", de, esr.grad, rtol=1e-3, atol=1e-9)
+    for i, (d, r) in enumerate(zip(dt, fsr)):
+        ref = r.grad if r.grad is not None else torch.zeros_like(r)
+        close_bf16(f"kd dtap{i}", d, ref, ulps=2.0)
+
+
+def test_adamw(ops):
+    g = torch.Generator().manual_seed(0)
+    w = torch.randn(1000, generator=g)
+    p = w.clone().requires_grad_(True)
+    opt = torch.optim.AdamW([p], lr=1e-2, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01)
+    wd, m, v = w.cuda(), torch.zeros(1000, device="cuda"), torch.zeros(1000, device="cuda")
+    for step in range(1, 4):
+        gr = torch.randn(1000, generator=g)
+        p.grad = gr.clone()
+        opt.step()
+        ops.adamw_(wd, gr.cuda(), m, v, 1e-2, step, weight_decay=0.01)
+    close_f32("adamw", wd, p.detach(), rtol=1e-4, atol=1e-6)
