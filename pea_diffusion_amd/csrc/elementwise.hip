@@ -430,3 +430,75 @@ int launch_adamw(float* w, const float* g, float* m, float* v, long long n, floa
   HIPCHK(hipGetLastError());
   return PEA_OK;
 }
+
+// ---- per-batch column sums with fp32 atomics: out[b][c] += sum_p x[b][p][c]
+// (gradient of the per-sample time-embedding row vector added in the ResBlock conv1 epilogue)
+__global__ void colsum_batched_kernel(const bf16* __restrict__ x, float* __restrict__ out, int HW, int C, int ldo,
+                                      int pix_per_block) {
+  const int nchunk = C / 8;
+  const int ppb = blockDim.x / nchunk;
+  const int ck = threadIdx.x % nchunk, pl = threadIdx.x / nchunk;
+  if (pl >= ppb) return;
+  const int b = blockIdx.y;
+  const int p0 = blockIdx.x * pix_per_block, p1 = min(p0 + pix_per_block, HW);
+  float s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (int p = p0 + pl; p < p1; p += ppb) {
+    const bf16x8 v = *(const bf16x8*)(x + ((long long)b * HW + p) * C + ck * 8);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s[j] += (float)v[j];
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) atomicAdd(&out[(long long)b * ldo + ck * 8 + j], s[j]);
+}
+int launch_colsum_batched(const bf16* x, float* out, int B, int HW, int C, int ldo, hipStream_t s) {
+  SHAPECHK(C % 8 == 0 && C / 8 <= 1024, "colsum_batched: C=%d", C);
+  const int nchunk = C / 8;
+  int ppb = 256 / nchunk;
+  if (ppb < 1) ppb = 1;
+  int per = ppb * 64;
+  if (per > HW) per = HW;
+  hipLaunchKernelGGL(colsum_batched_kernel, dim3(cdiv(HW, per), B), dim3(nchunk * ppb), 0, s, x, out, HW, C, ldo, per);
+  HIPCHK(hipGetLastError());
+  return PEA_OK;
+}
+
+// y (+)= x   (bf16), and bf16 <- fp32 with optional accumulate
+__global__ void accum_kernel(const bf16* __restrict__ x, bf16* __restrict__ y, long long n8, int accum) {
+  EW_LOOP(i, n8) {
+    bf16x8 v = *(const bf16x8*)(x + i * 8);
+    if (accum) {
+      const bf16x8 o = *(const bf16x8*)(y + i * 8);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = (bf16)((float)v[j] + (float)o[j]);
+    }
+    *(bf16x8*)(y + i * 8) = v;
+  }
+}
+int launch_accum(const bf16* x, bf16* y, long long n, int accum, hipStream_t s) {
+  SHAPECHK(n % 8 == 0, "accum: n %% 8");
+  hipLaunchKernelGGL(accum_kernel, dim3(EW_GRID(n / 8)), dim3(256), 0, s, x, y, n / 8, accum);
+  HIPCHK(hipGetLastError());
+  return PEA_OK;
+}
+// strided 2-D copy/accumulate of bf16 (column slices of fused buffers): y[r][0:C] (+)= x[r][0:C]
+__global__ void copy2d_kernel(const bf16* __restrict__ x, int ldx, bf16* __restrict__ y, int ldy, long long rows,
+                              int C, int accum) {
+  const int ck = C / 8;
+  EW_LOOP(i, rows * ck) {
+    const long long r = i / ck;
+    const int c = (int)(i - r * ck) * 8;
+    bf16x8 v = *(const bf16x8*)(x + r * ldx + c);
+    if (accum) {
+      const bf16x8 o = *(const bf16x8*)(y + r * ldy + c);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = (bf16)((float)v[j] + (float)o[j]);
+    }
+    *(bf16x8*)(y + r * ldy + c) = v;
+  }
+}
+int launch_copy2d(const bf16* x, int ldx, bf16* y, int ldy, long long rows, int C, int accum, hipStream_t s) {
+  SHAPECHK(C % 8 == 0 && ldx % 8 == 0 && ldy % 8 == 0, "copy2d: alignment");
+  hipLaunchKernelGGL(copy2d_kernel, dim3(EW_GRID(rows * (C / 8))), dim3(256), 0, s, x, ldx, y, ldy, rows, C, accum);
+  HIPCHK(hipGetLastError());
+  return PEA_OK;
+}

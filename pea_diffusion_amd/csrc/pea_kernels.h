@@ -140,3 +140,8 @@ struct KdLossP {
   float grad_scale;                // multiplies every seed (1/world for DP averaging, usually 1)
 };
 int launch_kd_loss(const KdLossP& p, hipStream_t s);
+
+// late additions (elementwise.hip)
+int launch_colsum_batched(const bf16* x, float* out, int B, int HW, int C, int ldo, hipStream_t s);
+int launch_accum(const bf16* x, bf16* y, long long n, int accum, hipStream_t s);
+int launch_copy2d(const bf16* x, int ldx, bf16* y, int ldy, long long rows, int C, int accum, hipStream_t s);
