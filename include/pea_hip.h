@@ -113,6 +113,96 @@ int pea_op_kd_loss(int ntaps, const void* const* taps_s, const void* const* taps
 int pea_op_adamw(float* w, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2,
                  float eps, float weight_decay, int step, float grad_scale, void* stream);
 
+
+/* ========================================================================== model level ====
+ * The three plug-in surfaces of the reference, as opaque handles.                               */
+
+/* UNet2DConditionModel config (diffusers 0.23 names; `heads` is what diffusers calls
+ * `attention_head_dim` for SDXL).  Arrays are in DOWN-block order, n_levels entries used.        */
+typedef struct pea_unet_config {
+  int in_channels, out_channels;
+  int n_levels;
+  int block_out[4];
+  int down_cross[4];          /* 1 = CrossAttnDownBlock2D, 0 = DownBlock2D */
+  int up_cross[4];            /* 1 = CrossAttnUpBlock2D,   0 = UpBlock2D  (UP order) */
+  int layers_per_block;
+  int depth[4];               /* transformer_layers_per_block */
+  int heads[4];               /* attention heads; channels / heads must be 64 */
+  int cross_dim;
+  int linear_proj;            /* use_linear_projection */
+  int groups;
+  float eps;
+  int text_time;              /* addition_embed_type == "text_time" */
+  int add_time_dim;
+  int proj_in_dim;
+} pea_unet_config;
+
+/* Builds the static op tape for a fixed (batch B, latent H x W, context length L) and allocates
+ * its activations (all kept resident: 288 GB HBM) -- replaces `UNet2DConditionModel.from_pretrained`
+ * (train_sdxl_zh.py:138,151).  needs_grad=1 adds the reverse data-gradient tape (student);
+ * own_weights=0 creates a context that must borrow weights via pea_unet_share_weights (the
+ * reference loads teacher and student from the same checkpoint, train_sdxl_zh.py:138 vs :151).    */
+int pea_unet_create(const pea_unet_config* cfg, int B, int H, int W, int L, int needs_grad, int own_weights,
+                    void** out);
+int pea_unet_destroy(void* unet);
+int pea_unet_num_weights(void* unet);
+/* diffusers state-dict key + torch shape (d0,d1; conv adds [3][3]) of weight i; kind: 0 vector,
+ * 1 linear [d0][d1] (1x1 convs included), 2 conv3x3 [d0][d1][3][3], 3 conv_in, 4 conv_out         */
+int pea_unet_weight_info(void* unet, int i, char* name, int name_len, long long* numel, int* kind, int* d0, int* d1);
+/* src: DEVICE fp32, torch layout, `numel` elements; converted to the internal bf16 layouts      */
+int pea_unet_load_weight(void* unet, const char* name, const float* src, long long numel, void* stream);
+/* random weights of this architecture (no checkpoints exist in the image)                        */
+int pea_unet_init_random(void* unet, unsigned long long seed, void* stream);
+int pea_unet_share_weights(void* dst, void* src);
+/* unet(sample, t, encoder_hidden_states, added_cond_kwargs={text_embeds,time_ids})[0]
+ * (train_sdxl_zh.py:397,415; tests/test_sdxl_zh.py:384-391).  x, eps_out: fp32 NCHW [B][4][H][W];
+ * t: fp32 [B]; ehs: [B][L][cross_dim], text: [B][pooled], dtype 0 = fp32, 1 = bf16; time_ids fp32 [B][6]. */
+int pea_unet_forward(void* unet, const float* x, const float* t, const void* ehs, int ehs_dtype, const void* text,
+                     int text_dtype, const float* time_ids, float* eps_out, void* stream);
+/* feature taps in the order of the reference's cast_hook (train_sdxl_zh.py:79-84): d0.., m, u0..  */
+int pea_unet_num_taps(void* unet);
+int pea_unet_tap_info(void* unet, int k, void** data, void** grad, int* B, int* H, int* W, int* C);
+int pea_unet_tap_export_nchw(void* unet, int k, int grad, float* out, void* stream);
+/* reverse pass: d(loss)/d(eps) in `deps` (fp32 NCHW, may be NULL) plus tap gradient seeds already
+ * written into the tap grad buffers for every k with bit k set in tap_seed_mask.  Results:
+ * pea_unet_input_grads -> bf16 d(ehs) [B][L][cross], d(text_embeds) [B][pooled].                 */
+int pea_unet_backward(void* unet, const float* deps, unsigned tap_seed_mask, void* stream);
+int pea_unet_input_grads(void* unet, void** d_ehs, void** d_text);
+int pea_unet_memory(void* unet, long long* weight_bytes, long long* act_bytes, long long* grad_bytes, int* n_ops);
+
+/* The PEA adapter `MLP(in_dim, out_dim, hidden_dim, out_dim1, use_residual)` (train_sdxl_zh.py:43-67);
+ * out_dim1 = 0 selects the SD1.5 variant (train_sd_zh.py:41-56).  Parameters live in ONE flat fp32
+ * device buffer owned by the caller, in state_dict order (layernorm.weight, layernorm.bias,
+ * projector.0.weight, projector.2.weight, projector.4.weight, fc.weight, fc.bias).               */
+int pea_adapter_create(int in_dim, int out_dim, int hidden_dim, int out_dim1, int use_residual, void** out);
+int pea_adapter_destroy(void* ad);
+long long pea_adapter_num_params(void* ad);
+int pea_adapter_bind(void* ad, float* flat_params);
+int pea_adapter_prepare(void* ad, int batch, int L);     /* rows = batch * L */
+int pea_adapter_sync(void* ad, void* stream);            /* refresh bf16 working copies after an update */
+/* x1, x2 = proj(x): enc [batch][L][in] (dtype 0 fp32 / 1 bf16) -> pooled fp32 [batch][out] (may be NULL),
+ * tokens fp32 [batch][L][out1]                                                                   */
+int pea_adapter_forward(void* ad, const void* enc, int dtype, float* pooled, float* tokens, void* stream);
+/* grads (flat fp32, same layout as the parameters) (+)= backward of the last forward             */
+int pea_adapter_backward(void* ad, const float* d_pooled, const float* d_tokens, float* grads, int accumulate,
+                         void* stream);
+
+/* The fused KD training step (train_sdxl_zh.py:311-441 downstream of the frozen encoders).       */
+int pea_trainer_create(void* adapter, void* student, void* teacher, float feat_weight, int nan_guard,
+                       const float* alphas_cumprod, void** out);
+int pea_trainer_destroy(void* tr);
+/* latents/noise fp32 [B][4][H][W]; timesteps int64 [B]; enc/enc_uncond fp32 [B][L][in]; prompt_mask uint8 [B];
+ * zh_or_not int64 [B]; teacher_ehs/teacher_neg fp32 [B][Lt][cross]; teacher_pooled fp32 [B][pooled] or NULL;
+ * time_ids fp32 [B][6] or NULL.  grads: flat fp32 adapter gradients; losses fp32[4] device =
+ * (loss, train_loss, train_loss_logits, train_loss_features).                                    */
+int pea_train_step(void* tr, const float* latents, const float* noise, const long long* timesteps,
+                   const float* enc, const float* enc_uncond, const unsigned char* prompt_mask,
+                   const long long* zh_or_not, const float* teacher_ehs, const float* teacher_neg,
+                   const float* teacher_pooled, const float* time_ids, float grad_scale, float* grads,
+                   int accumulate, float* losses, void* stream);
+/* intermediate results of the last step (fp32 NCHW [B][4][H][W]): which 0 = x_t, 1 = eps_student, 2 = eps_teacher */
+int pea_trainer_export(void* tr, int which, float* out, void* stream);
+
 /* debugging aid for the parity tests: 1 = ds_read_b64_tr_b16 transpose reads (default), 0 = scalar gathers */
 void pea_debug_set_attn_tr(int v);
 

@@ -25,7 +25,7 @@ class PeaError(RuntimeError):
 
 _CT = {
     "int": ctypes.c_int, "float": ctypes.c_float, "long long": ctypes.c_longlong, "double": ctypes.c_double,
-    "uint64_t": ctypes.c_uint64, "unsigned long long": ctypes.c_ulonglong,
+    "uint64_t": ctypes.c_uint64, "unsigned long long": ctypes.c_ulonglong, "unsigned": ctypes.c_uint,
 }
 
 
@@ -44,6 +44,7 @@ def parse_header(path: str = HEADER) -> Dict[str, Tuple[object, List[object]]]:
     src = open(path).read()
     src = re.sub(r"/\*.*?\*/", " ", src, flags=re.S)
     src = re.sub(r"//[^\n]*", " ", src)
+    src = re.sub(r"typedef\s+struct[^{]*\{.*?\}\s*\w+\s*;", " ", src, flags=re.S)
     protos = {}
     for m in re.finditer(r"([A-Za-z_][\w\s\*]*?)\b(pea_\w+)\s*\(([^;{]*?)\)\s*;", src):
         ret, name, args = m.group(1).strip(), m.group(2), m.group(3).strip()

@@ -1,0 +1,88 @@
+"""UNet2DConditionModel configurations (diffusers 0.23 field names) and the ctypes mirror of
+`pea_unet_config` (include/pea_hip.h).  The reference never states these numbers itself: it loads
+them with `UNet2DConditionModel.from_pretrained(args.model_path, subfolder="unet")`
+(train_sdxl_zh.py:138,151); the values below are the published SDXL-base / SD1.5 / SSD-1B configs."""
+from __future__ import annotations
+
+import ctypes
+from dataclasses import dataclass
+from typing import Optional, Tuple
+
+
+@dataclass
+class UNetConfig:
+    in_channels: int = 4
+    out_channels: int = 4
+    sample_size: int = 128
+    block_out_channels: Tuple[int, ...] = (320, 640, 1280)
+    down_block_types: Tuple[str, ...] = ("DownBlock2D", "CrossAttnDownBlock2D", "CrossAttnDownBlock2D")
+    up_block_types: Tuple[str, ...] = ("CrossAttnUpBlock2D", "CrossAttnUpBlock2D", "UpBlock2D")
+    layers_per_block: int = 2
+    transformer_layers_per_block: Tuple[int, ...] = (1, 2, 10)
+    num_attention_heads: Tuple[int, ...] = (5, 10, 20)   # diffusers: `attention_head_dim`
+    cross_attention_dim: int = 2048
+    use_linear_projection: bool = True
+    norm_num_groups: int = 32
+    norm_eps: float = 1e-5
+    addition_embed_type: Optional[str] = "text_time"
+    addition_time_embed_dim: int = 256
+    projection_class_embeddings_input_dim: int = 2816
+    name: str = "sdxl"
+
+    @property
+    def pooled_dim(self) -> int:
+        return self.projection_class_embeddings_input_dim - 6 * self.addition_time_embed_dim
+
+
+def sdxl_config() -> UNetConfig:
+    return UNetConfig()
+
+
+def ssd1b_config() -> UNetConfig:
+    return UNetConfig(transformer_layers_per_block=(1, 2, 4), name="ssd1b")
+
+
+def sd15_config() -> UNetConfig:
+    return UNetConfig(
+        sample_size=64, block_out_channels=(320, 640, 1280, 1280),
+        down_block_types=("CrossAttnDownBlock2D",) * 3 + ("DownBlock2D",),
+        up_block_types=("UpBlock2D",) + ("CrossAttnUpBlock2D",) * 3,
+        transformer_layers_per_block=(1, 1, 1, 1), num_attention_heads=(8, 8, 8, 8),
+        cross_attention_dim=768, use_linear_projection=False, addition_embed_type=None,
+        addition_time_embed_dim=0, projection_class_embeddings_input_dim=0, name="sd15")
+
+
+def tiny_config() -> UNetConfig:
+    return UNetConfig(sample_size=16, block_out_channels=(64, 128, 128), transformer_layers_per_block=(1, 1, 2),
+                      num_attention_heads=(1, 2, 2), cross_attention_dim=128, addition_time_embed_dim=32,
+                      projection_class_embeddings_input_dim=128 + 6 * 32, name="tiny")
+
+
+class CUNetConfig(ctypes.Structure):
+    _fields_ = [("in_channels", ctypes.c_int), ("out_channels", ctypes.c_int), ("n_levels", ctypes.c_int),
+                ("block_out", ctypes.c_int * 4), ("down_cross", ctypes.c_int * 4), ("up_cross", ctypes.c_int * 4),
+                ("layers_per_block", ctypes.c_int), ("depth", ctypes.c_int * 4), ("heads", ctypes.c_int * 4),
+                ("cross_dim", ctypes.c_int), ("linear_proj", ctypes.c_int), ("groups", ctypes.c_int),
+                ("eps", ctypes.c_float), ("text_time", ctypes.c_int), ("add_time_dim", ctypes.c_int),
+                ("proj_in_dim", ctypes.c_int)]
+
+
+def to_c(cfg) -> CUNetConfig:
+    """accepts this module's UNetConfig or any object with the same (diffusers) field names."""
+    n = len(cfg.block_out_channels)
+    c = CUNetConfig()
+    c.in_channels, c.out_channels, c.n_levels = cfg.in_channels, cfg.out_channels, n
+    for i in range(n):
+        c.block_out[i] = cfg.block_out_channels[i]
+        c.down_cross[i] = int(cfg.down_block_types[i].startswith("CrossAttn"))
+        c.up_cross[i] = int(cfg.up_block_types[i].startswith("CrossAttn"))
+        c.depth[i] = cfg.transformer_layers_per_block[i]
+        c.heads[i] = cfg.num_attention_heads[i]
+    c.layers_per_block = cfg.layers_per_block
+    c.cross_dim = cfg.cross_attention_dim
+    c.linear_proj = int(cfg.use_linear_projection)
+    c.groups, c.eps = cfg.norm_num_groups, cfg.norm_eps
+    c.text_time = int(cfg.addition_embed_type == "text_time")
+    c.add_time_dim = cfg.addition_time_embed_dim
+    c.proj_in_dim = cfg.projection_class_embeddings_input_dim
+    return c

@@ -1,0 +1,250 @@
+// C-ABI, model level (include/pea_hip.h): UNet contexts, the PEA adapter, the KD trainer.
+#include <string.h>
+
+#include "../../include/pea_hip.h"
+#include "model.h"
+
+#define RCX(x)                        \
+  do {                                \
+    int rc__ = (x);                   \
+    if (rc__ != PEA_OK) return rc__;  \
+  } while (0)
+#define NOTNULL(p, what)                         \
+  do {                                           \
+    if (!(p)) {                                  \
+      pea_set_error("%s: null handle", what);    \
+      return PEA_E_INVALID;                      \
+    }                                            \
+  } while (0)
+
+static_assert(sizeof(pea_unet_config) == sizeof(PeaUnetCfg), "config struct mismatch");
+
+extern "C" {
+
+int pea_unet_create(const pea_unet_config* cfg, int B, int H, int W, int L, int needs_grad, int own_weights,
+                    void** out) {
+  NOTNULL(cfg, "pea_unet_create");
+  NOTNULL(out, "pea_unet_create");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
+    pea_set_error("pea_unet_create: no HIP device (there is no CPU fallback)");
+    return PEA_E_HIP;
+  }
+  Unet* u = new Unet();
+  memcpy(&u->cfg, cfg, sizeof(PeaUnetCfg));
+  u->B = B; u->H = H; u->W = W; u->L = L; u->needs_grad = needs_grad != 0; u->owns_weights = own_weights != 0;
+  int rc = u->build();
+  if (rc == PEA_OK) rc = u->alloc();
+  if (rc != PEA_OK) {
+    delete u;
+    return rc;
+  }
+  *out = u;
+  return PEA_OK;
+}
+int pea_unet_destroy(void* h) {
+  delete (Unet*)h;
+  return PEA_OK;
+}
+int pea_unet_num_weights(void* h) { return h ? (int)((Unet*)h)->slots.size() : 0; }
+int pea_unet_weight_info(void* h, int i, char* name, int name_len, long long* numel, int* kind, int* d0, int* d1) {
+  NOTNULL(h, "pea_unet_weight_info");
+  Unet* u = (Unet*)h;
+  if (i < 0 || i >= (int)u->slots.size()) {
+    pea_set_error("pea_unet_weight_info: index %d out of range", i);
+    return PEA_E_INVALID;
+  }
+  const WSlot& s = u->slots[i];
+  if (name && name_len > 0) {
+    strncpy(name, s.name.c_str(), name_len - 1);
+    name[name_len - 1] = 0;
+  }
+  if (numel) *numel = s.numel;
+  if (kind) *kind = s.kind;
+  if (d0) *d0 = s.d0;
+  if (d1) *d1 = s.d1;
+  return PEA_OK;
+}
+int pea_unet_load_weight(void* h, const char* name, const float* src, long long numel, void* stream) {
+  NOTNULL(h, "pea_unet_load_weight");
+  Unet* u = (Unet*)h;
+  if (!u->owns_weights) {
+    pea_set_error("pea_unet_load_weight: context borrows its weights");
+    return PEA_E_STATE;
+  }
+  return u->load_weight(name, src, numel, (hipStream_t)stream);
+}
+int pea_unet_init_random(void* h, unsigned long long seed, void* stream) {
+  NOTNULL(h, "pea_unet_init_random");
+  return ((Unet*)h)->init_random(seed, (hipStream_t)stream);
+}
+int pea_unet_share_weights(void* dst, void* src) {
+  NOTNULL(dst, "pea_unet_share_weights");
+  NOTNULL(src, "pea_unet_share_weights");
+  return ((Unet*)dst)->share_weights_from(*(Unet*)src);
+}
+int pea_unet_forward(void* h, const float* x, const float* t, const void* ehs, int ehs_dtype, const void* text,
+                     int text_dtype, const float* time_ids, float* eps_out, void* stream) {
+  NOTNULL(h, "pea_unet_forward");
+  return ((Unet*)h)->forward(x, t, ehs, ehs_dtype, text, text_dtype, time_ids, eps_out, (hipStream_t)stream);
+}
+int pea_unet_num_taps(void* h) { return h ? (int)((Unet*)h)->taps.size() : 0; }
+int pea_unet_tap_info(void* h, int k, void** data, void** grad, int* B, int* H, int* W, int* C) {
+  NOTNULL(h, "pea_unet_tap_info");
+  Unet* u = (Unet*)h;
+  if (k < 0 || k >= (int)u->taps.size()) {
+    pea_set_error("pea_unet_tap_info: tap %d out of range", k);
+    return PEA_E_INVALID;
+  }
+  const Tn& t = u->tn[u->taps[k]];
+  if (data) *data = t.d;
+  if (grad) *grad = t.g;
+  if (B) *B = t.B;
+  if (H) *H = t.H;
+  if (W) *W = t.W;
+  if (C) *C = t.cols;
+  return PEA_OK;
+}
+int pea_unet_tap_export_nchw(void* h, int k, int grad, float* out, void* stream) {
+  NOTNULL(h, "pea_unet_tap_export_nchw");
+  Unet* u = (Unet*)h;
+  if (k < 0 || k >= (int)u->taps.size()) {
+    pea_set_error("pea_unet_tap_export_nchw: tap %d out of range", k);
+    return PEA_E_INVALID;
+  }
+  const Tn& t = u->tn[u->taps[k]];
+  const bf16* src = grad ? t.g : t.d;
+  NOTNULL(src, "pea_unet_tap_export_nchw(grad)");
+  return launch_nhwc_to_nchw_f32(src, out, t.B, t.H * t.W, t.cols, (hipStream_t)stream);
+}
+int pea_unet_backward(void* h, const float* deps, unsigned tap_seed_mask, void* stream) {
+  NOTNULL(h, "pea_unet_backward");
+  Unet* u = (Unet*)h;
+  u->begin_backward();
+  for (size_t k = 0; k < u->taps.size(); ++k)
+    if (tap_seed_mask & (1u << k)) u->tn[u->taps[k]].gw = true;
+  return u->backward(deps, (hipStream_t)stream);
+}
+int pea_unet_input_grads(void* h, void** d_ehs, void** d_text) {
+  NOTNULL(h, "pea_unet_input_grads");
+  Unet* u = (Unet*)h;
+  if (d_ehs) *d_ehs = u->tn[u->t_ehs].gw ? u->tn[u->t_ehs].g : nullptr;
+  if (d_text) *d_text = (u->t_text >= 0 && u->tn[u->t_text].gw) ? u->tn[u->t_text].g : nullptr;
+  return PEA_OK;
+}
+int pea_unet_memory(void* h, long long* weight_bytes, long long* act_bytes, long long* grad_bytes, int* n_ops) {
+  NOTNULL(h, "pea_unet_memory");
+  Unet* u = (Unet*)h;
+  if (weight_bytes) *weight_bytes = (long long)u->wbytes;
+  if (act_bytes) *act_bytes = (long long)u->abytes;
+  if (grad_bytes) *grad_bytes = (long long)u->gbytes;
+  if (n_ops) *n_ops = (int)u->ops.size();
+  return PEA_OK;
+}
+
+// ------------------------------------------------------------------------------ adapter
+int pea_adapter_create(int in_dim, int out_dim, int hidden_dim, int out_dim1, int use_residual, void** out) {
+  NOTNULL(out, "pea_adapter_create");
+  Adapter* a = new Adapter();
+  a->in_dim = in_dim; a->out_dim = out_dim; a->hidden = hidden_dim; a->out1 = out_dim1; a->use_residual = use_residual;
+  a->nparam = 2LL * in_dim + (long long)hidden_dim * in_dim + (long long)hidden_dim * hidden_dim +
+              (long long)out_dim * hidden_dim + (long long)out_dim1 * out_dim + out_dim1;
+  *out = a;
+  return PEA_OK;
+}
+int pea_adapter_destroy(void* h) {
+  delete (Adapter*)h;
+  return PEA_OK;
+}
+long long pea_adapter_num_params(void* h) { return h ? ((Adapter*)h)->nparam : 0; }
+int pea_adapter_bind(void* h, float* flat_params) {
+  NOTNULL(h, "pea_adapter_bind");
+  ((Adapter*)h)->params = flat_params;
+  return PEA_OK;
+}
+int pea_adapter_prepare(void* h, int batch, int L) {
+  NOTNULL(h, "pea_adapter_prepare");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
+    pea_set_error("pea_adapter_prepare: no HIP device (there is no CPU fallback)");
+    return PEA_E_HIP;
+  }
+  return ((Adapter*)h)->prepare(batch, L);
+}
+int pea_adapter_sync(void* h, void* stream) {
+  NOTNULL(h, "pea_adapter_sync");
+  return ((Adapter*)h)->sync_weights((hipStream_t)stream);
+}
+int pea_adapter_forward(void* h, const void* enc, int dtype, float* pooled, float* tokens, void* stream) {
+  NOTNULL(h, "pea_adapter_forward");
+  Adapter* a = (Adapter*)h;
+  hipStream_t s = (hipStream_t)stream;
+  RCX(a->forward(enc, nullptr, dtype, s));
+  if (a->out1) {
+    if (pooled) RCX(launch_cast_bf16_f32(a->pooled, pooled, (long long)a->B2 * a->out_dim, s));
+    if (tokens) RCX(launch_cast_bf16_f32(a->tok, tokens, (long long)a->R * a->out1, s));
+  } else if (tokens) {
+    RCX(launch_cast_bf16_f32(a->z2, tokens, (long long)a->R * a->out_dim, s));
+  }
+  return PEA_OK;
+}
+int pea_adapter_backward(void* h, const float* d_pooled, const float* d_tokens, float* grads, int accumulate,
+                         void* stream) {
+  NOTNULL(h, "pea_adapter_backward");
+  Adapter* a = (Adapter*)h;
+  hipStream_t s = (hipStream_t)stream;
+  if (a->out1) {
+    if (d_tokens) RCX(launch_cast_f32_bf16(d_tokens, a->dtok, (long long)a->R * a->out1, s));
+    else HIPCHK(hipMemsetAsync(a->dtok, 0, (size_t)a->R * a->out1 * 2, s));
+    if (d_pooled) RCX(launch_cast_f32_bf16(d_pooled, a->dpool, (long long)a->B2 * a->out_dim, s));
+    else HIPCHK(hipMemsetAsync(a->dpool, 0, (size_t)a->B2 * a->out_dim * 2, s));
+  } else {
+    NOTNULL(d_tokens, "pea_adapter_backward(d_tokens)");
+    RCX(launch_cast_f32_bf16(d_tokens, a->dz2, (long long)a->R * a->out_dim, s));
+  }
+  return a->backward(grads, accumulate, s);
+}
+
+// ------------------------------------------------------------------------------ trainer
+int pea_trainer_create(void* adapter, void* student, void* teacher, float feat_weight, int nan_guard,
+                       const float* alphas_cumprod, void** out) {
+  NOTNULL(adapter, "pea_trainer_create");
+  NOTNULL(student, "pea_trainer_create");
+  NOTNULL(teacher, "pea_trainer_create");
+  Trainer* t = new Trainer();
+  t->ad = (Adapter*)adapter; t->student = (Unet*)student; t->teacher = (Unet*)teacher;
+  t->feat_weight = feat_weight; t->nan_guard = nan_guard;
+  int rc = t->prepare();
+  if (rc == PEA_OK && alphas_cumprod)
+    if (hipMemcpy(t->ac, alphas_cumprod, 4000, hipMemcpyDeviceToDevice) != hipSuccess) rc = PEA_E_HIP;
+  if (rc != PEA_OK) {
+    delete t;
+    return rc;
+  }
+  *out = t;
+  return PEA_OK;
+}
+int pea_trainer_destroy(void* h) {
+  delete (Trainer*)h;
+  return PEA_OK;
+}
+int pea_train_step(void* h, const float* latents, const float* noise, const long long* timesteps, const float* enc,
+                   const float* enc_uncond, const unsigned char* prompt_mask, const long long* zh_or_not,
+                   const float* teacher_ehs, const float* teacher_neg, const float* teacher_pooled,
+                   const float* time_ids, float grad_scale, float* grads, int accumulate, float* losses,
+                   void* stream) {
+  NOTNULL(h, "pea_train_step");
+  return ((Trainer*)h)->step(latents, noise, timesteps, enc, enc_uncond, prompt_mask, zh_or_not, teacher_ehs,
+                             teacher_neg, teacher_pooled, time_ids, grad_scale, grads, accumulate, losses,
+                             (hipStream_t)stream);
+}
+int pea_trainer_export(void* h, int which, float* out, void* stream) {
+  NOTNULL(h, "pea_trainer_export");
+  Trainer* t = (Trainer*)h;
+  const float* src = which == 0 ? t->xt : which == 1 ? t->eps_s : t->eps_t;
+  const size_t n = (size_t)t->student->B * t->student->cfg.in_channels * t->student->H * t->student->W;
+  HIPCHK(hipMemcpyAsync(out, src, n * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  return PEA_OK;
+}
+
+}  // extern "C"

@@ -502,3 +502,12 @@ int launch_copy2d(const bf16* x, int ldx, bf16* y, int ldy, long long rows, int 
   HIPCHK(hipGetLastError());
   return PEA_OK;
 }
+
+__global__ void cast_i64_f32_kernel(const long long* __restrict__ x, float* __restrict__ y, long long n) {
+  EW_LOOP(i, n) y[i] = (float)x[i];
+}
+int launch_cast_i64_f32(const long long* x, float* y, long long n, hipStream_t s) {
+  hipLaunchKernelGGL(cast_i64_f32_kernel, dim3(EW_GRID(n)), dim3(256), 0, s, x, y, n);
+  HIPCHK(hipGetLastError());
+  return PEA_OK;
+}

@@ -1,0 +1,157 @@
+// Host runtime: the UNet as a static op tape (forward schedule + reverse data-gradient
+// schedule), the PEA adapter, and the fused KD training step.  No autograd, no tracing compiler:
+// the tape is built once per (config, batch, resolution, context length) and every launch is an
+// explicit kernel from pea_kernels.h.
+#pragma once
+#include <deque>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "pea_kernels.h"
+
+struct PeaUnetCfg {          // mirrors `pea_unet_config` of include/pea_hip.h
+  int in_channels, out_channels;
+  int n_levels;
+  int block_out[4];
+  int down_cross[4];         // CrossAttnDownBlock2D ?
+  int up_cross[4];           // CrossAttnUpBlock2D ?
+  int layers_per_block;
+  int depth[4];              // transformer_layers_per_block (down order)
+  int heads[4];              // attention heads per level (down order); head_dim must be 64
+  int cross_dim;
+  int linear_proj;           // use_linear_projection (SDXL 1, SD1.5 0 -> 1x1 conv weights [C][C][1][1])
+  int groups;
+  float eps;
+  int text_time;             // addition_embed_type == "text_time"
+  int add_time_dim;          // addition_time_embed_dim
+  int proj_in_dim;           // projection_class_embeddings_input_dim
+};
+
+enum WKind { W_VEC, W_LINEAR, W_CONV3, W_CONV_IN, W_CONV_OUT };
+
+struct WSlot {
+  std::string name;
+  int kind;
+  int d0 = 0, d1 = 0;        // LINEAR: [N=d0][K=d1]; CONV3: [Co=d0][Ci=d1][3][3]; VEC: [d0]
+  long long numel = 0;
+  // device copies (pointers into the weight arena; fused matrices share a base with offsets)
+  float* f32 = nullptr;      // VEC / CONV_IN raw / CONV_OUT packed
+  bf16* w = nullptr; int ldw = 0;        // forward layout  [N][K] (conv: K = 9*Ci, (ky,kx,ci))
+  bf16* wt = nullptr; int ldwt = 0;      // dgrad layout    [K][N] (conv: [Ci][9*Co] flipped)
+  bool need_wt = false;
+  bool loaded = false;
+  // arena bookkeeping
+  size_t off_f32 = (size_t)-1, off_w = (size_t)-1, off_wt = (size_t)-1;
+  int fused_parent = -1;     // index of the fused matrix this slot is a row block of
+  int row_off = 0;
+};
+
+struct FusedMat {            // several Linear weights stacked along N sharing one input
+  int N = 0, K = 0;
+  bf16* w = nullptr; bf16* wt = nullptr; float* bias = nullptr;
+  size_t off_w = (size_t)-1, off_wt = (size_t)-1, off_bias = (size_t)-1;
+  bool need_wt = false, has_bias = false;
+};
+
+struct Tn {
+  long long rows = 0; int cols = 0;
+  int B = 0, H = 0, W = 0;
+  bf16* d = nullptr; bf16* g = nullptr;
+  bool rg = false;           // requires grad
+  bool gw = false;           // gradient already written in the current backward pass
+  size_t off_d = 0, off_g = 0;
+  bool external = false;     // no buffer of its own
+};
+
+enum OpKind { OP_CONV_IN, OP_CONV3, OP_LINEAR, OP_GN, OP_LN, OP_ATTN, OP_GEGLU, OP_CONCAT, OP_SILU, OP_TEMB,
+              OP_CONV_OUT };
+
+struct Op {
+  int kind;
+  int a = -1, b = -1, c = -1;     // input tensors
+  int acol = 0, bcol = 0, ccol = 0;
+  int out = -1;
+  int res = -1;                   // residual tensor (epilogue add)
+  int rv = -1, rv_off = 0;        // per-sample row vector tensor + column offset (conv1 + temb)
+  int w = -1, bias = -1;          // weight slots (GN/LN: gamma, beta); fused: index into fused list (w = -2 - idx)
+  int fused = -1;
+  int p0 = 0, p1 = 0, p2 = 0, p3 = 0;
+  float f0 = 0.f;
+  float* aux = nullptr; size_t aux_off = 0, aux_bytes = 0;   // GN/LN stats, attention lse
+  int src = 0;                    // OP_TEMB: 0 = timesteps, 1 = time_ids
+};
+
+struct Unet {
+  PeaUnetCfg cfg;
+  int B, H, W, L;                 // batch, latent H/W, context length
+  bool needs_grad;
+  std::deque<WSlot> slots;
+  std::map<std::string, int> slot_by_name;
+  std::deque<FusedMat> fused;
+  std::vector<Tn> tn;
+  std::vector<Op> ops;
+  std::vector<int> taps;          // tensor ids: d0.., m, u0..
+  int t_ehs = -1, t_text = -1, t_tproj = -1, t_out_in = -1;
+  int tproj_total = 0;
+  // arenas
+  char* warena = nullptr; size_t wbytes = 0; bool owns_weights = true;
+  char* aarena = nullptr; size_t abytes = 0;
+  char* garena = nullptr; size_t gbytes = 0;
+  // scratch
+  double* gn_scratch = nullptr; float* delta = nullptr; bf16* ups_tmp = nullptr; float* tproj_grad = nullptr;
+  float* tmp_f32 = nullptr; size_t tmp_f32_elems = 0;   // load-time staging
+  const bf16* zeros = nullptr;
+  // per-call externals
+  const float* x_in = nullptr; const float* t_in = nullptr; const float* tid_in = nullptr;
+  float* eps_out = nullptr; const float* deps_in = nullptr;
+
+  int build();
+  int alloc();
+  int load_weight(const char* name, const float* dev_ptr, long long numel, hipStream_t s);
+  int init_random(unsigned long long seed, hipStream_t s);
+  int share_weights_from(const Unet& src);
+  int forward(const float* x, const float* t, const void* ehs, int ehs_dtype, const void* text, int text_dtype,
+              const float* time_ids, float* eps, hipStream_t s);
+  int backward(const float* deps, hipStream_t s);   // tap grads must have been seeded (or zero-flagged) first
+  void begin_backward();
+  int all_loaded(std::string* missing) const;
+  ~Unet();
+};
+
+struct Adapter {
+  int in_dim, out_dim, hidden, out1, use_residual;   // out1 == 0: SD1.5 variant (tokens only)
+  int R = 0, Rpad = 0, B2 = 0, L = 0;                // rows = B2 * L
+  long long nparam = 0;
+  // flat fp32 parameter order == state_dict order: layernorm.weight, layernorm.bias,
+  // projector.0.weight, projector.2.weight, projector.4.weight, fc.weight, fc.bias
+  long long off_lnw, off_lnb, off_w0, off_w1, off_w2, off_fcw, off_fcb;
+  float* params = nullptr;        // caller-owned flat fp32 (device)
+  char* arena = nullptr;
+  bf16 *w0, *w1, *w2, *wfc, *w0t, *w1t, *w2t, *wfct;            // bf16 working copies
+  bf16 *x, *xn, *z0, *a0, *z1, *a1, *z2, *a2, *tok, *pooled;     // activations
+  bf16 *dtok, *da2, *dz2, *da1, *dz1, *da0, *dz0, *dxn, *dpool;  // gradients
+  bf16 *tA, *tB;                                                 // transposed operands for wgrad
+  float* ln_stats;
+  int prepare(int B2, int L);
+  int sync_weights(hipStream_t s);                               // refresh bf16 copies after an optimizer step
+  int forward(const void* enc, const void* enc2, int dtype, hipStream_t s);   // enc [B2*L][in] or two halves
+  int backward(float* grads, int accumulate, hipStream_t s);     // consumes dtok / dpool
+  ~Adapter();
+};
+
+struct Trainer {
+  Adapter* ad; Unet* student; Unet* teacher;
+  float feat_weight = 0.1f; int nan_guard = 0;
+  float* xt = nullptr; float* eps_s = nullptr; float* eps_t = nullptr; float* deps = nullptr; float* ac = nullptr;
+  bf16* t_ehs_sel = nullptr; bf16* dehs_full = nullptr;
+  float* losses = nullptr; double* kd_ws = nullptr;
+  bf16 *tehs_c = nullptr, *tehs_n = nullptr;
+  int prepare();
+  int step(const float* latents, const float* noise, const long long* timesteps, const float* enc,
+           const float* enc_uncond, const unsigned char* prompt_mask, const long long* zh, const float* teacher_ehs,
+           const float* teacher_neg, const float* teacher_pooled, const float* time_ids, float grad_scale,
+           float* grads, int accumulate, float* losses_out, hipStream_t s);
+  float* t_f32 = nullptr;
+  ~Trainer();
+};

@@ -1,0 +1,935 @@
+// UNet op tape (build / forward / reverse data-gradient pass), weight store, PEA adapter and
+// the fused KD training step.  Mirrors, op for op, the diffusers-0.23 UNet2DConditionModel
+// graph that train_sdxl_zh.py:397,415 executes (restated on CPU in oracle/unet_ref.py), with
+// diffusers state-dict key names for every weight.
+#include "model.h"
+
+#include <string.h>
+
+#include <algorithm>
+
+static inline size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
+int pea_zero_page(const bf16** out);
+
+#define RC(x)                \
+  do {                       \
+    int rc__ = (x);          \
+    if (rc__ != PEA_OK) return rc__; \
+  } while (0)
+
+// ============================================================================ graph construction
+namespace {
+struct Builder {
+  Unet& u;
+  explicit Builder(Unet& un) : u(un) {}
+  int T(long long rows, int cols, int B = 0, int H = 0, int W = 0) {
+    Tn t;
+    t.rows = rows; t.cols = cols; t.B = B; t.H = H; t.W = W;
+    u.tn.push_back(t);
+    return (int)u.tn.size() - 1;
+  }
+  int slot(const std::string& name, int kind, int d0, int d1, long long numel) {
+    auto it = u.slot_by_name.find(name);
+    if (it != u.slot_by_name.end()) return it->second;
+    WSlot s;
+    s.name = name; s.kind = kind; s.d0 = d0; s.d1 = d1; s.numel = numel;
+    u.slots.push_back(s);
+    const int id = (int)u.slots.size() - 1;
+    u.slot_by_name[name] = id;
+    return id;
+  }
+  int vec(const std::string& n, int d) { return slot(n, W_VEC, d, 0, d); }
+  int lin(const std::string& n, int N, int K) { return slot(n, W_LINEAR, N, K, (long long)N * K); }
+  int conv3(const std::string& n, int Co, int Ci) { return slot(n, W_CONV3, Co, Ci, 9LL * Co * Ci); }
+
+  Op& push(int kind) {
+    Op o;
+    o.kind = kind;
+    u.ops.push_back(o);
+    return u.ops.back();
+  }
+  int linear(int x, const std::string& pfx, int N, bool bias, int res = -1) {
+    const int K = u.tn[x].cols;
+    const int w = lin(pfx + ".weight", N, K);
+    const int b = bias ? vec(pfx + ".bias", N) : -1;
+    const int out = T(u.tn[x].rows, N, u.tn[x].B, u.tn[x].H, u.tn[x].W);
+    Op& o = push(OP_LINEAR);
+    o.a = x; o.w = w; o.bias = b; o.out = out; o.res = res;
+    return out;
+  }
+  // several Linear layers over the same input, stacked along N (one GEMM)
+  int fused_linear(int x, const std::vector<std::string>& pfx, const std::vector<int>& Ns, bool bias) {
+    const int K = u.tn[x].cols;
+    FusedMat f;
+    f.K = K; f.has_bias = bias;
+    u.fused.push_back(f);
+    const int fi = (int)u.fused.size() - 1;
+    int off = 0;
+    for (size_t i = 0; i < pfx.size(); ++i) {
+      const int w = lin(pfx[i] + ".weight", Ns[i], K);
+      u.slots[w].fused_parent = fi; u.slots[w].row_off = off;
+      if (bias) {
+        const int b = vec(pfx[i] + ".bias", Ns[i]);
+        u.slots[b].fused_parent = fi; u.slots[b].row_off = off;
+      }
+      off += Ns[i];
+    }
+    u.fused[fi].N = off;
+    const int out = T(u.tn[x].rows, off, u.tn[x].B, u.tn[x].H, u.tn[x].W);
+    Op& o = push(OP_LINEAR);
+    o.a = x; o.fused = fi; o.out = out;
+    return out;
+  }
+  int gn(int x, const std::string& pfx, bool silu, float eps) {
+    const int C = u.tn[x].cols;
+    const int out = T(u.tn[x].rows, C, u.tn[x].B, u.tn[x].H, u.tn[x].W);
+    Op& o = push(OP_GN);
+    o.a = x; o.out = out; o.w = vec(pfx + ".weight", C); o.bias = vec(pfx + ".bias", C);
+    o.p0 = silu; o.f0 = eps; o.aux_bytes = sizeof(float) * 2 * u.B * u.cfg.groups;
+    return out;
+  }
+  int ln(int x, const std::string& pfx) {
+    const int C = u.tn[x].cols;
+    const int out = T(u.tn[x].rows, C, u.tn[x].B, u.tn[x].H, u.tn[x].W);
+    Op& o = push(OP_LN);
+    o.a = x; o.out = out; o.w = vec(pfx + ".weight", C); o.bias = vec(pfx + ".bias", C);
+    o.f0 = 1e-5f; o.aux_bytes = sizeof(float) * 2 * u.tn[x].rows;
+    return out;
+  }
+  int silu(int x) {
+    const int out = T(u.tn[x].rows, u.tn[x].cols, u.tn[x].B, u.tn[x].H, u.tn[x].W);
+    Op& o = push(OP_SILU);
+    o.a = x; o.out = out;
+    return out;
+  }
+  int conv(int x, const std::string& pfx, int Cout, int stride, int ups, int rv = -1, int rv_off = 0, int res = -1) {
+    const Tn& t = u.tn[x];
+    const int Hv = ups ? t.H * 2 : t.H, Wv = ups ? t.W * 2 : t.W;
+    const int Ho = stride == 2 ? (Hv + 1) / 2 : Hv, Wo = stride == 2 ? (Wv + 1) / 2 : Wv;
+    const int w = conv3(pfx + ".weight", Cout, t.cols);
+    const int b = vec(pfx + ".bias", Cout);
+    const int out = T((long long)t.B * Ho * Wo, Cout, t.B, Ho, Wo);
+    Op& o = push(OP_CONV3);
+    o.a = x; o.w = w; o.bias = b; o.out = out; o.p0 = stride; o.p1 = ups; o.rv = rv; o.rv_off = rv_off; o.res = res;
+    return out;
+  }
+  int concat(int a, int b) {
+    const int out = T(u.tn[a].rows, u.tn[a].cols + u.tn[b].cols, u.tn[a].B, u.tn[a].H, u.tn[a].W);
+    Op& o = push(OP_CONCAT);
+    o.a = a; o.b = b; o.out = out;
+    return out;
+  }
+
+  int tproj_off = 0;
+  int resnet(int x, const std::string& pfx, int cout) {
+    const int cin = u.tn[x].cols;
+    const float eps = u.cfg.eps;
+    int h = gn(x, pfx + ".norm1", true, eps);
+    h = conv(h, pfx + ".conv1", cout, 1, 0, u.t_tproj, tproj_off);
+    tproj_off += cout;
+    h = gn(h, pfx + ".norm2", true, eps);
+    int sc = x;
+    if (cin != cout) sc = linear(x, pfx + ".conv_shortcut", cout, true);
+    return conv(h, pfx + ".conv2", cout, 1, 0, -1, 0, sc);
+  }
+  int transformer(int x, const std::string& pfx, int heads, int depth) {
+    const int C = u.tn[x].cols;
+    const Tn t0 = u.tn[x];
+    const int S = t0.H * t0.W;
+    int h = gn(x, pfx + ".norm", false, 1e-6f);
+    h = linear(h, pfx + ".proj_in", C, true);
+    for (int i = 0; i < depth; ++i) {
+      const std::string bp = pfx + ".transformer_blocks." + std::to_string(i);
+      int n1 = ln(h, bp + ".norm1");
+      int qkv = fused_linear(n1, {bp + ".attn1.to_q", bp + ".attn1.to_k", bp + ".attn1.to_v"}, {C, C, C}, false);
+      int a1 = T(t0.rows, C, t0.B, t0.H, t0.W);
+      {
+        Op& o = push(OP_ATTN);
+        o.a = qkv; o.acol = 0; o.b = qkv; o.bcol = C; o.c = qkv; o.ccol = 2 * C; o.out = a1;
+        o.p0 = heads; o.p1 = S; o.p2 = S; o.aux_bytes = sizeof(float) * t0.B * heads * S;
+      }
+      h = linear(a1, bp + ".attn1.to_out.0", C, true, h);
+      int n2 = ln(h, bp + ".norm2");
+      int q2 = linear(n2, bp + ".attn2.to_q", C, false);
+      int kv = fused_linear(u.t_ehs, {bp + ".attn2.to_k", bp + ".attn2.to_v"}, {C, C}, false);
+      int a2 = T(t0.rows, C, t0.B, t0.H, t0.W);
+      {
+        Op& o = push(OP_ATTN);
+        o.a = q2; o.acol = 0; o.b = kv; o.bcol = 0; o.c = kv; o.ccol = C; o.out = a2;
+        o.p0 = heads; o.p1 = S; o.p2 = u.L; o.aux_bytes = sizeof(float) * t0.B * heads * S;
+      }
+      h = linear(a2, bp + ".attn2.to_out.0", C, true, h);
+      int n3 = ln(h, bp + ".norm3");
+      int hg = linear(n3, bp + ".ff.net.0.proj", 8 * C, true);
+      int g = T(t0.rows, 4 * C, t0.B, t0.H, t0.W);
+      {
+        Op& o = push(OP_GEGLU);
+        o.a = hg; o.out = g;
+      }
+      h = linear(g, bp + ".ff.net.2", C, true, h);
+    }
+    return linear(h, pfx + ".proj_out", C, true, x);
+  }
+};
+
+// cout of every ResnetBlock2D in creation order (to size the fused time_emb_proj matrix)
+std::vector<std::pair<std::string, int>> enumerate_resnets(const PeaUnetCfg& c) {
+  std::vector<std::pair<std::string, int>> r;
+  const int n = c.n_levels;
+  for (int i = 0; i < n; ++i)
+    for (int j = 0; j < c.layers_per_block; ++j)
+      r.push_back({"down_blocks." + std::to_string(i) + ".resnets." + std::to_string(j), c.block_out[i]});
+  r.push_back({"mid_block.resnets.0", c.block_out[n - 1]});
+  r.push_back({"mid_block.resnets.1", c.block_out[n - 1]});
+  for (int i = 0; i < n; ++i)
+    for (int j = 0; j < c.layers_per_block + 1; ++j)
+      r.push_back({"up_blocks." + std::to_string(i) + ".resnets." + std::to_string(j), c.block_out[n - 1 - i]});
+  return r;
+}
+}  // namespace
+
+int Unet::build() {
+  const PeaUnetCfg& c = cfg;
+  SHAPECHK(c.n_levels >= 2 && c.n_levels <= 4, "unet: n_levels=%d", c.n_levels);
+  for (int i = 0; i < c.n_levels; ++i) {
+    SHAPECHK(c.block_out[i] % 64 == 0, "unet: block_out_channels[%d]=%d must be a multiple of 64", i, c.block_out[i]);
+    if (c.down_cross[i] || c.up_cross[c.n_levels - 1 - i] || i == c.n_levels - 1)
+      SHAPECHK(c.heads[i] * 64 == c.block_out[i],
+               "unet: level %d has %d heads over %d channels; only head_dim 64 is implemented in HIP", i, c.heads[i],
+               c.block_out[i]);
+  }
+  SHAPECHK(c.cross_dim % 64 == 0, "unet: cross_attention_dim %% 64");
+  SHAPECHK((H % (1 << (c.n_levels - 1))) == 0 && (W % (1 << (c.n_levels - 1))) == 0, "unet: latent %dx%d", H, W);
+  Builder bd(*this);
+  const int temb_dim = c.block_out[0] * 4;
+  // conditioning inputs
+  t_ehs = bd.T((long long)B * L, c.cross_dim, B, 1, L);
+  tn[t_ehs].rg = needs_grad;
+  if (c.text_time) {
+    const int pooled = c.proj_in_dim - 6 * c.add_time_dim;
+    SHAPECHK(pooled > 0 && pooled % 8 == 0 && c.proj_in_dim % 64 == 0, "unet: projection dims");
+    t_text = bd.T(B, pooled, B);
+    tn[t_text].rg = needs_grad;
+  }
+  // time embedding
+  int te = bd.T(B, c.block_out[0], B);
+  { Op& o = bd.push(OP_TEMB); o.out = te; o.src = 0; o.p0 = c.block_out[0]; }
+  int emb = bd.linear(te, "time_embedding.linear_1", temb_dim, true);
+  emb = bd.silu(emb);
+  emb = bd.linear(emb, "time_embedding.linear_2", temb_dim, true);
+  if (c.text_time) {
+    int tid = bd.T(B, 6 * c.add_time_dim, B);
+    { Op& o = bd.push(OP_TEMB); o.out = tid; o.src = 1; o.p0 = c.add_time_dim; }
+    int add = bd.concat(t_text, tid);
+    int a = bd.linear(add, "add_embedding.linear_1", temb_dim, true);
+    a = bd.silu(a);
+    emb = bd.linear(a, "add_embedding.linear_2", temb_dim, true, emb);
+  }
+  int semb = bd.silu(emb);
+  {   // all ResnetBlock2D.time_emb_proj stacked into one GEMM over silu(emb)
+    auto rs = enumerate_resnets(c);
+    std::vector<std::string> names;
+    std::vector<int> ns;
+    for (auto& r : rs) { names.push_back(r.first + ".time_emb_proj"); ns.push_back(r.second); }
+    t_tproj = bd.fused_linear(semb, names, ns, true);
+    tproj_total = tn[t_tproj].cols;
+    ops.back().p3 = 1;   // its gradient arrives through the fp32 column-sum scratch
+  }
+  // conv_in
+  int x = bd.T((long long)B * H * W, c.block_out[0], B, H, W);
+  {
+    Op& o = bd.push(OP_CONV_IN);
+    o.out = x;
+    o.w = bd.slot("conv_in.weight", W_CONV_IN, c.block_out[0], c.in_channels, 9LL * c.block_out[0] * c.in_channels);
+    o.bias = bd.vec("conv_in.bias", c.block_out[0]);
+  }
+  std::vector<int> skips{x};
+  const int n = c.n_levels;
+  for (int i = 0; i < n; ++i) {
+    const std::string p = "down_blocks." + std::to_string(i);
+    for (int j = 0; j < c.layers_per_block; ++j) {
+      x = bd.resnet(x, p + ".resnets." + std::to_string(j), c.block_out[i]);
+      if (c.down_cross[i]) x = bd.transformer(x, p + ".attentions." + std::to_string(j), c.heads[i], c.depth[i]);
+      skips.push_back(x);
+    }
+    if (i != n - 1) {
+      x = bd.conv(x, p + ".downsamplers.0.conv", c.block_out[i], 2, 0);
+      skips.push_back(x);
+    }
+    taps.push_back(x);
+  }
+  x = bd.resnet(x, "mid_block.resnets.0", c.block_out[n - 1]);
+  x = bd.transformer(x, "mid_block.attentions.0", c.heads[n - 1], c.depth[n - 1]);
+  x = bd.resnet(x, "mid_block.resnets.1", c.block_out[n - 1]);
+  taps.push_back(x);
+  for (int i = 0; i < n; ++i) {
+    const std::string p = "up_blocks." + std::to_string(i);
+    const int lvl = n - 1 - i;
+    for (int j = 0; j < c.layers_per_block + 1; ++j) {
+      const int sk = skips.back();
+      skips.pop_back();
+      x = bd.concat(x, sk);
+      x = bd.resnet(x, p + ".resnets." + std::to_string(j), c.block_out[lvl]);
+      if (c.up_cross[i]) x = bd.transformer(x, p + ".attentions." + std::to_string(j), c.heads[lvl], c.depth[lvl]);
+    }
+    if (i != n - 1) x = bd.conv(x, p + ".upsamplers.0.conv", c.block_out[lvl], 1, 1);
+    taps.push_back(x);
+  }
+  SHAPECHK(skips.empty(), "unet: skip stack not consumed (%d left)", (int)skips.size());
+  x = bd.gn(x, "conv_norm_out", true, c.eps);
+  t_out_in = x;
+  {
+    Op& o = bd.push(OP_CONV_OUT);
+    o.a = x;
+    o.w = bd.slot("conv_out.weight", W_CONV_OUT, c.out_channels, c.block_out[0], 9LL * c.out_channels * c.block_out[0]);
+    o.bias = bd.vec("conv_out.bias", c.out_channels);
+  }
+  // requires-grad propagation + which weights need a dgrad layout
+  for (Op& o : ops) {
+    bool rg = false;
+    for (int t : {o.a, o.b, o.c, o.res, o.rv})
+      if (t >= 0 && tn[t].rg) rg = true;
+    if (o.out >= 0) tn[o.out].rg = tn[o.out].rg || rg;
+    if ((o.kind == OP_LINEAR || o.kind == OP_CONV3) && o.a >= 0 && tn[o.a].rg) {
+      if (o.fused >= 0) fused[o.fused].need_wt = true;
+      else slots[o.w].need_wt = true;
+    }
+  }
+  return PEA_OK;
+}
+
+int Unet::alloc() {
+  // ---- weights
+  size_t off = 0;
+  size_t max_numel = 0;
+  if (owns_weights) {
+    for (FusedMat& f : fused) {
+      f.off_w = off; off += al256((size_t)f.N * f.K * 2);
+      if (f.need_wt) { f.off_wt = off; off += al256((size_t)f.N * f.K * 2); }
+      if (f.has_bias) { f.off_bias = off; off += al256((size_t)f.N * 4); }
+    }
+    for (WSlot& s : slots) {
+      max_numel = std::max(max_numel, (size_t)s.numel);
+      if (s.fused_parent >= 0) continue;
+      if (s.kind == W_VEC || s.kind == W_CONV_IN || s.kind == W_CONV_OUT) { s.off_f32 = off; off += al256(s.numel * 4); }
+      else {
+        s.off_w = off; off += al256(s.numel * 2);
+        if (s.need_wt) { s.off_wt = off; off += al256(s.numel * 2); }
+      }
+    }
+    wbytes = off;
+    HIPCHK(hipMalloc((void**)&warena, wbytes));
+    for (FusedMat& f : fused) {
+      f.w = (bf16*)(warena + f.off_w);
+      if (f.need_wt) f.wt = (bf16*)(warena + f.off_wt);
+      if (f.has_bias) f.bias = (float*)(warena + f.off_bias);
+    }
+    for (WSlot& s : slots) {
+      if (s.fused_parent >= 0) {
+        FusedMat& f = fused[s.fused_parent];
+        if (s.kind == W_VEC) s.f32 = f.bias + s.row_off;
+        else {
+          s.w = f.w + (size_t)s.row_off * f.K; s.ldw = f.K;
+          if (f.need_wt) { s.wt = f.wt + s.row_off; s.ldwt = f.N; s.need_wt = true; }
+        }
+        continue;
+      }
+      if (s.off_f32 != (size_t)-1) s.f32 = (float*)(warena + s.off_f32);
+      if (s.off_w != (size_t)-1) {
+        s.w = (bf16*)(warena + s.off_w);
+        s.ldw = s.kind == W_CONV3 ? 9 * s.d1 : s.d1;
+      }
+      if (s.off_wt != (size_t)-1) {
+        s.wt = (bf16*)(warena + s.off_wt);
+        s.ldwt = s.kind == W_CONV3 ? 9 * s.d0 : s.d0;
+      }
+    }
+    tmp_f32_elems = max_numel;
+    HIPCHK(hipMalloc((void**)&tmp_f32, tmp_f32_elems * 4));
+  }
+  // ---- activations (+ per-op aux), gradients
+  size_t ao = 0, go = 0;
+  for (Tn& t : tn) {
+    t.off_d = ao; ao += al256((size_t)t.rows * t.cols * 2);
+    if (needs_grad && t.rg) { t.off_g = go; go += al256((size_t)t.rows * t.cols * 2); }
+  }
+  for (Op& o : ops)
+    if (o.aux_bytes) { o.aux_off = ao; ao += al256(o.aux_bytes); }
+  abytes = ao; gbytes = go;
+  HIPCHK(hipMalloc((void**)&aarena, abytes));
+  if (gbytes) HIPCHK(hipMalloc((void**)&garena, gbytes));
+  for (Tn& t : tn) {
+    t.d = (bf16*)(aarena + t.off_d);
+    if (needs_grad && t.rg) t.g = (bf16*)(garena + t.off_g);
+  }
+  for (Op& o : ops)
+    if (o.aux_bytes) o.aux = (float*)(aarena + o.aux_off);
+  // ---- scratch
+  size_t delta_elems = 0, ups_elems = 0;
+  for (Op& o : ops) {
+    if (o.kind == OP_ATTN) delta_elems = std::max(delta_elems, (size_t)B * o.p0 * o.p1);
+    if (o.kind == OP_CONV3 && o.p1 && tn[o.a].rg)
+      ups_elems = std::max(ups_elems, (size_t)tn[o.out].rows * tn[o.a].cols);
+  }
+  HIPCHK(hipMalloc((void**)&gn_scratch, sizeof(double) * 2 * B * cfg.groups));
+  if (needs_grad) {
+    if (delta_elems) HIPCHK(hipMalloc((void**)&delta, delta_elems * 4));
+    if (ups_elems) HIPCHK(hipMalloc((void**)&ups_tmp, ups_elems * 2));
+    HIPCHK(hipMalloc((void**)&tproj_grad, sizeof(float) * B * tproj_total));
+  }
+  RC(pea_zero_page(&zeros));
+  return PEA_OK;
+}
+
+Unet::~Unet() {
+  if (owns_weights && warena) hipFree(warena);
+  if (tmp_f32) hipFree(tmp_f32);
+  if (aarena) hipFree(aarena);
+  if (garena) hipFree(garena);
+  if (gn_scratch) hipFree(gn_scratch);
+  if (delta) hipFree(delta);
+  if (ups_tmp) hipFree(ups_tmp);
+  if (tproj_grad) hipFree(tproj_grad);
+}
+
+int Unet::load_weight(const char* name, const float* src, long long numel, hipStream_t s) {
+  auto it = slot_by_name.find(name);
+  if (it == slot_by_name.end()) {
+    pea_set_error("unet: unknown weight '%s'", name);
+    return PEA_E_NOTFOUND;
+  }
+  WSlot& w = slots[it->second];
+  SHAPECHK(numel == w.numel, "unet: weight '%s' has %lld elements, expected %lld", name, numel, w.numel);
+  switch (w.kind) {
+    case W_VEC:
+    case W_CONV_IN:
+      HIPCHK(hipMemcpyAsync(w.f32, src, numel * 4, hipMemcpyDeviceToDevice, s));
+      break;
+    case W_CONV_OUT:
+      RC(launch_pack_conv_out(src, w.f32, w.d0, w.d1, s));
+      break;
+    case W_LINEAR:
+      RC(launch_cast_f32_bf16(src, w.w, numel, s));
+      if (w.wt) RC(launch_transpose_f32_bf16(src, w.wt, w.d0, w.d1, w.ldwt, s));
+      break;
+    case W_CONV3:
+      RC(launch_pack_conv_fwd(src, w.w, w.d0, w.d1, s));
+      if (w.wt) RC(launch_pack_conv_dgrad(src, w.wt, w.d0, w.d1, s));
+      break;
+  }
+  w.loaded = true;
+  return PEA_OK;
+}
+
+static bool ends_with(const std::string& s, const char* suf) {
+  const size_t n = strlen(suf);
+  return s.size() >= n && s.compare(s.size() - n, n, suf) == 0;
+}
+
+int Unet::init_random(unsigned long long seed, hipStream_t s) {
+  SHAPECHK(owns_weights, "unet: init_random on a context that shares weights");
+  unsigned long long i = 0;
+  for (WSlot& w : slots) {
+    ++i;
+    float scale = 0.02f, offset = 0.f;
+    if (w.kind == W_LINEAR) scale = 1.0f / sqrtf((float)w.d1);
+    else if (w.kind == W_CONV3 || w.kind == W_CONV_IN || w.kind == W_CONV_OUT) scale = 1.0f / sqrtf(9.0f * w.d1);
+    else if (ends_with(w.name, ".weight")) { scale = 0.f; offset = 1.f; }    // norm gammas
+    RC(launch_fill_random_f32(tmp_f32, w.numel, seed * 1000003ull + i, scale, offset, s));
+    RC(load_weight(w.name.c_str(), tmp_f32, w.numel, s));
+  }
+  return PEA_OK;
+}
+
+int Unet::share_weights_from(const Unet& src) {
+  SHAPECHK(!owns_weights, "unet: share_weights_from needs a context created without its own weights");
+  SHAPECHK(src.slots.size() == slots.size() && src.fused.size() == fused.size(), "unet: configs differ");
+  for (size_t i = 0; i < slots.size(); ++i) {
+    const WSlot& a = src.slots[i];
+    WSlot& b = slots[i];
+    SHAPECHK(a.name == b.name && a.numel == b.numel, "unet: weight tables differ at %s", a.name.c_str());
+    SHAPECHK(!b.need_wt || a.wt, "unet: source lacks the dgrad layout of %s", a.name.c_str());
+    b.f32 = a.f32; b.w = a.w; b.ldw = a.ldw; b.wt = a.wt; b.ldwt = a.ldwt; b.loaded = a.loaded;
+  }
+  for (size_t i = 0; i < fused.size(); ++i) {
+    fused[i].w = src.fused[i].w; fused[i].wt = src.fused[i].wt; fused[i].bias = src.fused[i].bias;
+  }
+  return PEA_OK;
+}
+
+int Unet::all_loaded(std::string* missing) const {
+  for (const WSlot& w : slots)
+    if (!w.loaded) {
+      if (missing) *missing = w.name;
+      return 0;
+    }
+  return 1;
+}
+
+// ============================================================================ forward
+static void fill_gemm(GemmP& p) { memset(&p, 0, sizeof(p)); p.alpha = 1.f; p.rows_per_batch = 1; }
+
+int Unet::forward(const float* x, const float* t, const void* ehs, int ehs_dtype, const void* text, int text_dtype,
+                  const float* time_ids, float* eps, hipStream_t s) {
+  std::string miss;
+  if (!all_loaded(&miss)) {
+    pea_set_error("unet: weight '%s' was never loaded", miss.c_str());
+    return PEA_E_STATE;
+  }
+  x_in = x; t_in = t; tid_in = time_ids; eps_out = eps;
+  {
+    Tn& e = tn[t_ehs];
+    const long long n = e.rows * e.cols;
+    if ((const void*)e.d != ehs) {
+      if (ehs_dtype == 0) RC(launch_cast_f32_bf16((const float*)ehs, e.d, n, s));
+      else HIPCHK(hipMemcpyAsync(e.d, ehs, n * 2, hipMemcpyDeviceToDevice, s));
+    }
+    if (t_text >= 0) {
+      Tn& q = tn[t_text];
+      SHAPECHK(text != nullptr && time_ids != nullptr, "unet: text_embeds/time_ids required (text_time)");
+      const long long m = q.rows * q.cols;
+      if ((const void*)q.d != text) {
+        if (text_dtype == 0) RC(launch_cast_f32_bf16((const float*)text, q.d, m, s));
+        else HIPCHK(hipMemcpyAsync(q.d, text, m * 2, hipMemcpyDeviceToDevice, s));
+      }
+    }
+  }
+  for (Op& o : ops) {
+    switch (o.kind) {
+      case OP_TEMB: {
+        Tn& out = tn[o.out];
+        if (o.src == 0) RC(launch_timestep_embed(t_in, out.d, B, o.p0, s));
+        else RC(launch_timestep_embed(tid_in, out.d, B * 6, o.p0, s));
+        break;
+      }
+      case OP_LINEAR: {
+        Tn &a = tn[o.a], &out = tn[o.out];
+        GemmP p; fill_gemm(p);
+        p.A = a.d; p.lda = a.cols; p.M = (int)a.rows; p.K = a.cols; p.N = out.cols;
+        if (o.fused >= 0) { FusedMat& f = fused[o.fused]; p.W = f.w; p.ldw = f.K; p.bias = f.bias; }
+        else { WSlot& w = slots[o.w]; p.W = w.w; p.ldw = w.ldw; p.bias = o.bias >= 0 ? slots[o.bias].f32 : nullptr; }
+        p.C = out.d; p.ldc = out.cols;
+        if (o.res >= 0) { p.res = tn[o.res].d; p.ldres = tn[o.res].cols; }
+        RC(launch_gemm(p, s));
+        break;
+      }
+      case OP_SILU:
+        RC(launch_silu_fwd(tn[o.a].d, tn[o.out].d, tn[o.a].rows * tn[o.a].cols, s));
+        break;
+      case OP_CONCAT:
+        RC(launch_concat2(tn[o.a].d, tn[o.a].cols, tn[o.b].d, tn[o.b].cols, tn[o.out].d, tn[o.a].rows, s));
+        break;
+      case OP_CONV_IN:
+        RC(launch_conv_in(x_in, slots[o.w].f32, slots[o.bias].f32, tn[o.out].d, B, cfg.in_channels, H, W,
+                          tn[o.out].cols, s));
+        break;
+      case OP_CONV3: {
+        Tn &a = tn[o.a], &out = tn[o.out];
+        GemmP p; fill_gemm(p);
+        p.mode = 1; p.A = a.d; p.W = slots[o.w].w; p.ldw = slots[o.w].ldw; p.C = out.d; p.ldc = out.cols;
+        p.Hs = a.H; p.Ws = a.W; p.Cin = a.cols; p.Ho = out.H; p.Wo = out.W; p.stride = o.p0; p.shift = o.p1 ? 1 : 0;
+        p.M = (int)out.rows; p.N = out.cols; p.K = 9 * a.cols; p.bias = slots[o.bias].f32; p.zeros = zeros;
+        p.rows_per_batch = out.H * out.W;
+        if (o.rv >= 0) { p.rowvec = tn[o.rv].d + o.rv_off; p.ldrv = tn[o.rv].cols; }
+        if (o.res >= 0) { p.res = tn[o.res].d; p.ldres = tn[o.res].cols; }
+        RC(launch_gemm(p, s));
+        break;
+      }
+      case OP_GN: {
+        Tn& a = tn[o.a];
+        RC(launch_groupnorm_fwd(a.d, slots[o.w].f32, slots[o.bias].f32, tn[o.out].d, o.aux, gn_scratch, a.B,
+                                a.H * a.W, a.cols, cfg.groups, o.f0, o.p0, s));
+        break;
+      }
+      case OP_LN: {
+        Tn& a = tn[o.a];
+        RC(launch_layernorm_fwd(a.d, slots[o.w].f32, slots[o.bias].f32, tn[o.out].d, o.aux, (int)a.rows, a.cols, o.f0,
+                                s));
+        break;
+      }
+      case OP_ATTN: {
+        AttnP p; memset(&p, 0, sizeof(p));
+        p.Q = tn[o.a].d + o.acol; p.ldq = tn[o.a].cols; p.K = tn[o.b].d + o.bcol; p.ldk = tn[o.b].cols;
+        p.V = tn[o.c].d + o.ccol; p.ldv = tn[o.c].cols; p.O = tn[o.out].d; p.ldo = tn[o.out].cols; p.lse = o.aux;
+        p.B = B; p.H = o.p0; p.Sq = o.p1; p.Skv = o.p2; p.scale = 0.125f;
+        RC(launch_attention_fwd(p, s));
+        break;
+      }
+      case OP_GEGLU:
+        RC(launch_geglu_fwd(tn[o.a].d, tn[o.out].d, tn[o.a].rows, tn[o.out].cols, s));
+        break;
+      case OP_CONV_OUT:
+        RC(launch_conv_out(tn[o.a].d, slots[o.w].f32, slots[o.bias].f32, eps_out, B, tn[o.a].cols, H, W,
+                           cfg.out_channels, s));
+        break;
+    }
+  }
+  return PEA_OK;
+}
+
+// ============================================================================ backward
+void Unet::begin_backward() {
+  for (Tn& t : tn) t.gw = false;
+}
+
+int Unet::backward(const float* deps, hipStream_t s) {
+  SHAPECHK(needs_grad, "unet: created without gradient support");
+  HIPCHK(hipMemsetAsync(tproj_grad, 0, sizeof(float) * B * tproj_total, s));
+  for (int oi = (int)ops.size() - 1; oi >= 0; --oi) {
+    Op& o = ops[oi];
+    if (o.kind == OP_CONV_OUT) {
+      if (!deps) continue;
+      Tn& a = tn[o.a];
+      SHAPECHK(!a.gw, "unet: conv_out input gradient already written");
+      RC(launch_conv_out_dgrad(deps, slots[o.w].f32, a.g, B, a.cols, H, W, cfg.out_channels, s));
+      a.gw = true;
+      continue;
+    }
+    if (o.out < 0) continue;
+    Tn& out = tn[o.out];
+    if (!out.rg) continue;
+    if (o.kind == OP_LINEAR && o.p3 == 1) {   // fused time_emb_proj: gradient collected in fp32
+      RC(launch_cast_f32_bf16(tproj_grad, out.g, (long long)B * tproj_total, s));
+      out.gw = true;
+    }
+    if (!out.gw) continue;                     // no consumer produced a gradient for this tensor
+    switch (o.kind) {
+      case OP_LINEAR: {
+        Tn& a = tn[o.a];
+        if (a.rg) {
+          GemmP p; fill_gemm(p);
+          p.A = out.g; p.lda = out.cols; p.M = (int)out.rows; p.K = out.cols; p.N = a.cols;
+          if (o.fused >= 0) { FusedMat& f = fused[o.fused]; p.W = f.wt; p.ldw = f.N; }
+          else { WSlot& w = slots[o.w]; p.W = w.wt; p.ldw = w.ldwt; }
+          SHAPECHK(p.W != nullptr, "unet: dgrad weights missing for op %d", oi);
+          p.C = a.g; p.ldc = a.cols;
+          if (a.gw) { p.res = a.g; p.ldres = a.cols; }
+          RC(launch_gemm(p, s));
+          a.gw = true;
+        }
+        if (o.res >= 0 && tn[o.res].rg) {
+          Tn& r = tn[o.res];
+          RC(launch_accum(out.g, r.g, r.rows * r.cols, r.gw, s));
+          r.gw = true;
+        }
+        break;
+      }
+      case OP_SILU: {
+        Tn& a = tn[o.a];
+        if (a.rg) { RC(launch_silu_bwd(a.d, out.g, a.g, a.rows * a.cols, a.gw, s)); a.gw = true; }
+        break;
+      }
+      case OP_CONCAT: {
+        Tn &a = tn[o.a], &b = tn[o.b];
+        RC(launch_split2(out.g, a.cols, b.cols, a.rg ? a.g : nullptr, a.gw, b.rg ? b.g : nullptr, b.gw, a.rows, s));
+        if (a.rg) a.gw = true;
+        if (b.rg) b.gw = true;
+        break;
+      }
+      case OP_CONV3: {
+        Tn& a = tn[o.a];
+        if (a.rg) {
+          WSlot& w = slots[o.w];
+          SHAPECHK(w.wt != nullptr, "unet: conv dgrad weights missing for %s", w.name.c_str());
+          GemmP p; fill_gemm(p);
+          p.mode = 1; p.A = out.g; p.W = w.wt; p.ldw = w.ldwt; p.Hs = out.H; p.Ws = out.W; p.Cin = out.cols;
+          p.N = a.cols; p.K = 9 * out.cols; p.zeros = zeros; p.stride = 1;
+          if (o.p1) {            // upsample-folded conv: gradient at the upsampled resolution, then 2x2 sum
+            p.Ho = out.H; p.Wo = out.W; p.M = (int)out.rows; p.C = ups_tmp; p.ldc = a.cols;
+            RC(launch_gemm(p, s));
+            RC(launch_sumpool2(ups_tmp, a.g, a.B, a.H, a.W, a.cols, a.gw, s));
+          } else {
+            if (o.p0 == 2) { p.shift = 1; p.parity = 1; }
+            p.Ho = a.H; p.Wo = a.W; p.M = (int)a.rows; p.C = a.g; p.ldc = a.cols;
+            if (a.gw) { p.res = a.g; p.ldres = a.cols; }
+            RC(launch_gemm(p, s));
+          }
+          a.gw = true;
+        }
+        if (o.rv >= 0 && tn[o.rv].rg)
+          RC(launch_colsum_batched(out.g, tproj_grad + o.rv_off, out.B, out.H * out.W, out.cols, tproj_total, s));
+        if (o.res >= 0 && tn[o.res].rg) {
+          Tn& r = tn[o.res];
+          RC(launch_accum(out.g, r.g, r.rows * r.cols, r.gw, s));
+          r.gw = true;
+        }
+        break;
+      }
+      case OP_GN: {
+        Tn& a = tn[o.a];
+        if (a.rg) {
+          RC(launch_groupnorm_bwd(a.d, out.g, slots[o.w].f32, slots[o.bias].f32, o.aux, a.g, gn_scratch, a.B,
+                                  a.H * a.W, a.cols, cfg.groups, o.p0, a.gw, s));
+          a.gw = true;
+        }
+        break;
+      }
+      case OP_LN: {
+        Tn& a = tn[o.a];
+        if (a.rg) {
+          RC(launch_layernorm_bwd(a.d, out.g, slots[o.w].f32, o.aux, a.g, nullptr, nullptr, (int)a.rows, a.cols, a.gw,
+                                  s));
+          a.gw = true;
+        }
+        break;
+      }
+      case OP_ATTN: {
+        Tn &q = tn[o.a], &k = tn[o.b], &v = tn[o.c];
+        AttnP p; memset(&p, 0, sizeof(p));
+        p.Q = q.d + o.acol; p.ldq = q.cols; p.K = k.d + o.bcol; p.ldk = k.cols; p.V = v.d + o.ccol; p.ldv = v.cols;
+        p.O = out.d; p.ldo = out.cols; p.lse = o.aux; p.B = B; p.H = o.p0; p.Sq = o.p1; p.Skv = o.p2; p.scale = 0.125f;
+        p.dO = out.g; p.lddo = out.cols; p.delta = delta;
+        SHAPECHK(!q.gw && !k.gw, "unet: attention operand gradient written twice");
+        if (q.rg) { p.dQ = q.g + o.acol; p.lddq = q.cols; }
+        if (k.rg) { p.dK = k.g + o.bcol; p.lddk = k.cols; p.dV = v.g + o.ccol; p.lddv = v.cols; }
+        RC(launch_attention_bwd(p, s));
+        if (q.rg) q.gw = true;
+        if (k.rg) { k.gw = true; v.gw = true; }
+        break;
+      }
+      case OP_GEGLU: {
+        Tn& a = tn[o.a];
+        if (a.rg) {
+          SHAPECHK(!a.gw, "unet: geglu input gradient written twice");
+          RC(launch_geglu_bwd(a.d, out.g, a.g, a.rows, out.cols, s));
+          a.gw = true;
+        }
+        break;
+      }
+      default:
+        break;
+    }
+  }
+  return PEA_OK;
+}
+
+// ============================================================================ adapter
+// MLP of train_sdxl_zh.py:43-67 (SD1.5: train_sd_zh.py:41-56): LayerNorm -> 3 x (Linear, no bias)
+// with GELU(erf) between -> { GELU -> Linear+bias = tokens ; mean over tokens = pooled }.
+// Forward GEMMs use the fused GELU epilogue (pre-activation stashed for the backward);
+// backward = dgrad (transposed bf16 copies) + wgrad (fp32 accumulation into the flat grad buffer).
+Adapter::~Adapter() {
+  if (arena) hipFree(arena);
+}
+
+int Adapter::prepare(int B2_, int L_) {
+  SHAPECHK(in_dim % 64 == 0 && hidden % 64 == 0 && out_dim % 64 == 0 && (out1 == 0 || out1 % 64 == 0),
+           "adapter: dims must be multiples of 64 (in=%d hidden=%d out=%d out1=%d)", in_dim, hidden, out_dim, out1);
+  SHAPECHK(!use_residual || in_dim == out_dim, "adapter: use_residual needs in_dim == out_dim");
+  B2 = B2_; L = L_; R = B2 * L; Rpad = (R + 63) / 64 * 64;
+  off_lnw = 0; off_lnb = in_dim; off_w0 = off_lnb + in_dim; off_w1 = off_w0 + (long long)hidden * in_dim;
+  off_w2 = off_w1 + (long long)hidden * hidden; off_fcw = off_w2 + (long long)out_dim * hidden;
+  off_fcb = off_fcw + (long long)out1 * out_dim; nparam = off_fcb + out1;
+  if (arena) { hipFree(arena); arena = nullptr; }
+  size_t off = 0;
+  std::vector<std::pair<bf16**, size_t>> req;
+  auto want = [&](bf16** p, size_t elems) { req.push_back({p, off}); off += al256(elems * 2); };
+  const size_t mx = (size_t)std::max(std::max(in_dim, hidden), std::max(out_dim, std::max(out1, 64)));
+  want(&w0, (size_t)hidden * in_dim); want(&w1, (size_t)hidden * hidden); want(&w2, (size_t)out_dim * hidden);
+  want(&wfc, (size_t)out1 * out_dim + 64);
+  want(&w0t, (size_t)hidden * in_dim); want(&w1t, (size_t)hidden * hidden); want(&w2t, (size_t)out_dim * hidden);
+  want(&wfct, (size_t)out1 * out_dim + 64);
+  want(&x, (size_t)R * in_dim); want(&xn, (size_t)R * in_dim);
+  want(&z0, (size_t)R * hidden); want(&a0, (size_t)R * hidden); want(&z1, (size_t)R * hidden); want(&a1, (size_t)R * hidden);
+  want(&z2, (size_t)R * out_dim); want(&a2, (size_t)R * out_dim); want(&tok, (size_t)R * (out1 ? out1 : 64));
+  want(&pooled, (size_t)B2 * out_dim);
+  want(&dtok, (size_t)R * (out1 ? out1 : 64)); want(&da2, (size_t)R * out_dim); want(&dz2, (size_t)R * out_dim);
+  want(&da1, (size_t)R * hidden); want(&dz1, (size_t)R * hidden); want(&da0, (size_t)R * hidden);
+  want(&dz0, (size_t)R * hidden); want(&dxn, (size_t)R * in_dim); want(&dpool, (size_t)B2 * out_dim);
+  want(&tA, mx * Rpad); want(&tB, mx * Rpad);
+  const size_t stats_off = off;
+  off += al256((size_t)R * 2 * 4);
+  HIPCHK(hipMalloc((void**)&arena, off));
+  HIPCHK(hipMemset(arena, 0, off));
+  for (auto& r : req) *r.first = (bf16*)(arena + r.second);
+  ln_stats = (float*)(arena + stats_off);
+  return PEA_OK;
+}
+
+int Adapter::sync_weights(hipStream_t s) {
+  SHAPECHK(params != nullptr, "adapter: parameter buffer not set");
+  RC(launch_cast_f32_bf16(params + off_w0, w0, (long long)hidden * in_dim, s));
+  RC(launch_cast_f32_bf16(params + off_w1, w1, (long long)hidden * hidden, s));
+  RC(launch_cast_f32_bf16(params + off_w2, w2, (long long)out_dim * hidden, s));
+  RC(launch_transpose_f32_bf16(params + off_w0, w0t, hidden, in_dim, hidden, s));
+  RC(launch_transpose_f32_bf16(params + off_w1, w1t, hidden, hidden, hidden, s));
+  RC(launch_transpose_f32_bf16(params + off_w2, w2t, out_dim, hidden, out_dim, s));
+  if (out1) {
+    RC(launch_cast_f32_bf16(params + off_fcw, wfc, (long long)out1 * out_dim, s));
+    RC(launch_transpose_f32_bf16(params + off_fcw, wfct, out1, out_dim, out1, s));
+  }
+  return PEA_OK;
+}
+
+static int agemm(const bf16* A, int lda, const bf16* W, int ldw, void* C, int ldc, int M, int N, int K, int act,
+                 bf16* pre, const float* bias, int out_f32, int accum, hipStream_t s) {
+  GemmP p; fill_gemm(p);
+  p.A = A; p.lda = lda; p.W = W; p.ldw = ldw; p.C = C; p.ldc = ldc; p.M = M; p.N = N; p.K = K; p.act = act;
+  p.preact = pre; p.ldpre = N; p.bias = bias; p.out_f32 = out_f32; p.accum_f32 = accum;
+  return launch_gemm(p, s);
+}
+
+int Adapter::forward(const void* enc, const void* enc2, int dtype, hipStream_t s) {
+  SHAPECHK(arena && params, "adapter: prepare()/bind() first");
+  // enc2 == nullptr: enc holds all R rows; otherwise enc / enc2 hold R/2 rows each (cond | uncond)
+  const long long n1 = (enc2 ? (long long)(R / 2) : (long long)R) * in_dim;
+  if (dtype == 0) RC(launch_cast_f32_bf16((const float*)enc, x, n1, s));
+  else HIPCHK(hipMemcpyAsync(x, enc, (size_t)n1 * 2, hipMemcpyDeviceToDevice, s));
+  if (enc2) {
+    if (dtype == 0) RC(launch_cast_f32_bf16((const float*)enc2, x + n1, n1, s));
+    else HIPCHK(hipMemcpyAsync(x + n1, enc2, (size_t)n1 * 2, hipMemcpyDeviceToDevice, s));
+  }
+  RC(launch_layernorm_fwd(x, params + off_lnw, params + off_lnb, xn, ln_stats, R, in_dim, 1e-5f, s));
+  RC(agemm(xn, in_dim, w0, in_dim, a0, hidden, R, hidden, in_dim, 1, z0, nullptr, 0, 0, s));
+  RC(agemm(a0, hidden, w1, hidden, a1, hidden, R, hidden, hidden, 1, z1, nullptr, 0, 0, s));
+  if (out1) {
+    RC(agemm(a1, hidden, w2, hidden, a2, out_dim, R, out_dim, hidden, 1, z2, nullptr, 0, 0, s));
+    RC(agemm(a2, out_dim, wfc, out_dim, tok, out1, R, out1, out_dim, 0, nullptr, params + off_fcb, 0, 0, s));
+    if (use_residual) {
+      RC(launch_add(z2, x, dz2, (long long)R * out_dim, s));   // dz2 is free during the forward pass
+      RC(launch_mean_tokens(dz2, pooled, B2, L, out_dim, s));
+    } else {
+      RC(launch_mean_tokens(z2, pooled, B2, L, out_dim, s));
+    }
+  } else {
+    RC(agemm(a1, hidden, w2, hidden, z2, out_dim, R, out_dim, hidden, 0, nullptr, nullptr, 0, 0, s));
+  }
+  return PEA_OK;
+}
+
+// dW[N][K] (+)= dZ[R][N]^T . X[R][K]  via transposed operands (contraction padded to Rpad with zeros)
+static int wgrad(Adapter& a, const bf16* dZ, int N, const bf16* X, int K, float* dW, int accum, hipStream_t s) {
+  RC(launch_transpose_bf16(dZ, a.tA, a.R, N, a.Rpad, s));
+  RC(launch_transpose_bf16(X, a.tB, a.R, K, a.Rpad, s));
+  return agemm(a.tA, a.Rpad, a.tB, a.Rpad, dW, K, N, K, a.Rpad, 0, nullptr, nullptr, 1, accum, s);
+}
+
+int Adapter::backward(float* g, int accumulate, hipStream_t s) {
+  // inputs: dtok [R][out1] (SD1.5: dz2 [R][out]) and dpool [B2][out] already filled by the caller
+  if (!accumulate) HIPCHK(hipMemsetAsync(g, 0, nparam * 4, s));
+  if (out1) {
+    RC(agemm(dtok, out1, wfct, out1, da2, out_dim, R, out_dim, out1, 0, nullptr, nullptr, 0, 0, s));
+    RC(wgrad(*this, dtok, out1, a2, out_dim, g + off_fcw, 1, s));
+    RC(launch_colsum(dtok, g + off_fcb, R, out1, 1, s));
+    RC(launch_gelu_bwd(z2, da2, dz2, (long long)R * out_dim, 0, s));
+    RC(launch_mean_tokens_bwd(dpool, dz2, B2, L, out_dim, 1, s));
+  }
+  RC(agemm(dz2, out_dim, w2t, out_dim, da1, hidden, R, hidden, out_dim, 0, nullptr, nullptr, 0, 0, s));
+  RC(wgrad(*this, dz2, out_dim, a1, hidden, g + off_w2, 1, s));
+  RC(launch_gelu_bwd(z1, da1, dz1, (long long)R * hidden, 0, s));
+  RC(agemm(dz1, hidden, w1t, hidden, da0, hidden, R, hidden, hidden, 0, nullptr, nullptr, 0, 0, s));
+  RC(wgrad(*this, dz1, hidden, a0, hidden, g + off_w1, 1, s));
+  RC(launch_gelu_bwd(z0, da0, dz0, (long long)R * hidden, 0, s));
+  RC(agemm(dz0, hidden, w0t, hidden, dxn, in_dim, R, in_dim, hidden, 0, nullptr, nullptr, 0, 0, s));
+  RC(wgrad(*this, dz0, hidden, xn, in_dim, g + off_w0, 1, s));
+  RC(launch_layernorm_bwd(x, dxn, params + off_lnw, ln_stats, da0 /*unused dx sink*/, g + off_lnw, g + off_lnb, R,
+                          in_dim, 0, s));
+  return PEA_OK;
+}
+
+// ============================================================================ trainer
+Trainer::~Trainer() {
+  for (void* p : {(void*)xt, (void*)eps_s, (void*)eps_t, (void*)deps, (void*)ac, (void*)t_ehs_sel, (void*)dehs_full, (void*)t_f32,
+                  (void*)losses, (void*)kd_ws, (void*)tehs_c, (void*)tehs_n})
+    if (p) hipFree(p);
+}
+
+int Trainer::prepare() {
+  Unet& S = *student;
+  Unet& Tt = *teacher;
+  SHAPECHK(S.needs_grad, "trainer: student context needs gradient support");
+  SHAPECHK(S.B == Tt.B && S.H == Tt.H && S.W == Tt.W, "trainer: student/teacher shapes differ");
+  SHAPECHK(S.taps.size() == Tt.taps.size(), "trainer: tap counts differ");
+  for (size_t k = 0; k < S.taps.size(); ++k)
+    SHAPECHK(S.tn[S.taps[k]].rows == Tt.tn[Tt.taps[k]].rows && S.tn[S.taps[k]].cols == Tt.tn[Tt.taps[k]].cols,
+             "trainer: tap %d shapes differ", (int)k);
+  SHAPECHK(ad->B2 == 2 * S.B && ad->L == S.L, "trainer: adapter prepared for %d x %d, need %d x %d", ad->B2, ad->L,
+           2 * S.B, S.L);
+  const int tok_dim = ad->out1 ? ad->out1 : ad->out_dim;
+  SHAPECHK(tok_dim == S.cfg.cross_dim, "trainer: adapter token dim %d != student cross_attention_dim %d", tok_dim,
+           S.cfg.cross_dim);
+  const size_t n = (size_t)S.B * S.cfg.in_channels * S.H * S.W;
+  HIPCHK(hipMalloc((void**)&xt, n * 4));
+  HIPCHK(hipMalloc((void**)&eps_s, n * 4));
+  HIPCHK(hipMalloc((void**)&eps_t, n * 4));
+  HIPCHK(hipMalloc((void**)&deps, n * 4));
+  HIPCHK(hipMalloc((void**)&losses, 16));
+  HIPCHK(hipMalloc((void**)&kd_ws, 512));
+  HIPCHK(hipMalloc((void**)&tehs_c, (size_t)Tt.B * Tt.L * Tt.cfg.cross_dim * 2));
+  HIPCHK(hipMalloc((void**)&tehs_n, (size_t)Tt.B * Tt.L * Tt.cfg.cross_dim * 2));
+  // DDPM alphas_cumprod, scaled_linear betas (train_sdxl_zh.py:140)
+  std::vector<float> acv(1000);
+  {
+    const float b0 = sqrtf(0.00085f), b1 = sqrtf(0.012f);
+    float prod = 1.f;
+    for (int i = 0; i < 1000; ++i) {
+      const float sb = b0 + (b1 - b0) * (float)i / 999.0f;
+      prod *= 1.0f - sb * sb;
+      acv[i] = prod;
+    }
+  }
+  HIPCHK(hipMalloc((void**)&ac, 4000));
+  HIPCHK(hipMemcpy(ac, acv.data(), 4000, hipMemcpyHostToDevice));
+  return PEA_OK;
+}
+
+// One KD training step on one batch (train_sdxl_zh.py:311-441 after the frozen encoders):
+// add_noise -> adapter (cond | uncond) -> CFG-dropout select -> student UNet (taps) -> teacher UNet
+// -> fused KD loss + gradient seeds -> student data-gradient pass -> adapter dgrad + wgrad.
+int Trainer::step(const float* latents, const float* noise, const long long* timesteps, const float* enc,
+                  const float* enc_uncond, const unsigned char* prompt_mask, const long long* zh,
+                  const float* teacher_ehs, const float* teacher_neg, const float* teacher_pooled,
+                  const float* time_ids, float grad_scale, float* grads, int accumulate, float* losses_out,
+                  hipStream_t s) {
+  Unet& S = *student;
+  Unet& Tt = *teacher;
+  Adapter& A = *ad;
+  const int B = S.B;
+  const long long per_img = (long long)S.cfg.in_channels * S.H * S.W;
+  if (!t_f32) HIPCHK(hipMalloc((void**)&t_f32, sizeof(float) * B));
+  RC(launch_add_noise(latents, noise, timesteps, ac, xt, B, per_img, s));
+  RC(launch_cast_i64_f32(timesteps, t_f32, B, s));
+  // adapter on (cond | uncond) rows; train_sdxl_zh.py:383-384
+  RC(A.forward(enc, enc_uncond, 0, s));
+  const long long per_tok = (long long)S.L * S.cfg.cross_dim;
+  const bf16* tokens = A.out1 ? A.tok : A.z2;
+  Tn& ehs = S.tn[S.t_ehs];
+  RC(launch_select_rows(tokens, tokens + B * per_tok, prompt_mask, ehs.d, B, per_tok, s));      // :395
+  RC(S.forward(xt, t_f32, ehs.d, 1, S.t_text >= 0 ? (const void*)A.pooled : nullptr, 1, time_ids, eps_s, s));
+  // teacher (no grad); :410-415
+  const long long per_tt = (long long)Tt.L * Tt.cfg.cross_dim;
+  RC(launch_cast_f32_bf16(teacher_ehs, tehs_c, B * per_tt, s));
+  RC(launch_cast_f32_bf16(teacher_neg, tehs_n, B * per_tt, s));
+  Tn& tehs = Tt.tn[Tt.t_ehs];
+  RC(launch_select_rows(tehs_c, tehs_n, prompt_mask, tehs.d, B, per_tt, s));                     // :413
+  RC(Tt.forward(xt, t_f32, tehs.d, 1, teacher_pooled, 0, time_ids, eps_t, s));
+  // fused KD loss + seeds; :399-441
+  KdLossP kp;
+  memset(&kp, 0, sizeof(kp));
+  kp.ntaps = (int)S.taps.size();
+  S.begin_backward();
+  for (int k = 0; k < kp.ntaps; ++k) {
+    Tn& ts = S.tn[S.taps[k]];
+    kp.fs[k] = ts.d; kp.ft[k] = Tt.tn[Tt.taps[k]].d; kp.dfs[k] = ts.g;
+    kp.per[k] = ts.rows / B * ts.cols;
+    ts.gw = true;
+  }
+  kp.eps_s = eps_s; kp.eps = noise; kp.eps_t = eps_t; kp.deps_s = deps; kp.per_eps = per_img; kp.zh = zh; kp.B = B;
+  kp.feat_weight = feat_weight; kp.nan_guard = nan_guard; kp.grad_scale = grad_scale; kp.losses = losses;
+  kp.partial = (float*)kd_ws;
+  RC(launch_kd_loss(kp, s));
+  if (losses_out) HIPCHK(hipMemcpyAsync(losses_out, losses, 16, hipMemcpyDeviceToDevice, s));
+  // student data-gradient pass
+  RC(S.backward(deps, s));
+  SHAPECHK(ehs.gw, "trainer: no gradient reached encoder_hidden_states");
+  // route d(ehs) to the cond / uncond adapter rows; pooled gradient only to the cond half (:384,390)
+  bf16* dtokens = A.out1 ? A.dtok : A.dz2;
+  RC(launch_select_rows_bwd(ehs.g, prompt_mask, dtokens, dtokens + B * per_tok, B, per_tok, s));
+  if (A.out1) {
+    HIPCHK(hipMemsetAsync(A.dpool, 0, (size_t)A.B2 * A.out_dim * 2, s));
+    if (S.t_text >= 0 && S.tn[S.t_text].gw)
+      HIPCHK(hipMemcpyAsync(A.dpool, S.tn[S.t_text].g, (size_t)B * A.out_dim * 2, hipMemcpyDeviceToDevice, s));
+  }
+  RC(A.backward(grads, accumulate, s));
+  return PEA_OK;
+}

@@ -145,3 +145,4 @@ int launch_kd_loss(const KdLossP& p, hipStream_t s);
 int launch_colsum_batched(const bf16* x, float* out, int B, int HW, int C, int ldo, hipStream_t s);
 int launch_accum(const bf16* x, bf16* y, long long n, int accum, hipStream_t s);
 int launch_copy2d(const bf16* x, int ldx, bf16* y, int ldy, long long rows, int C, int accum, hipStream_t s);
+int launch_cast_i64_f32(const long long* x, float* y, long long n, hipStream_t s);

@@ -1,0 +1,137 @@
+"""`PEATrainer`: the reference's KD `training_step` (train_sdxl_zh.py:305-449) downstream of the frozen
+VAE / text encoders, as ONE call into libpea_hip.so, plus the optimizer + LR schedule of
+utils/model_utils.py:45-81 (FusedAdam(adam_w_mode=True), polynomial decay with warmup) and the
+data-parallel gradient all-reduce (one RCCL all-reduce on the flat adapter-grad buffer; replaces
+DeepSpeed ZeRO-1, train_sdxl_zh.sh:22,87)."""
+from __future__ import annotations
+
+import ctypes
+import os
+from typing import Dict, Optional
+
+import torch
+
+from . import ops
+from ._lib import PeaError, check, lib, ptr, stream_ptr
+from .adapter import PEAAdapter
+from .unet import HipUNet
+
+
+def ddpm_alphas_cumprod(n=1000, beta_start=0.00085, beta_end=0.012):
+    """DDPMScheduler(beta_schedule="scaled_linear") of train_sdxl_zh.py:140"""
+    betas = torch.linspace(beta_start ** 0.5, beta_end ** 0.5, n, dtype=torch.float32) ** 2
+    return torch.cumprod(1.0 - betas, dim=0)
+
+
+def polynomial_lr(step: int, base_lr: float, warmup: int, total: int, lr_end: float, power: float = 1.0) -> float:
+    """transformers' polynomial-decay-with-warmup (selected by utils/model_utils.py:136-138)"""
+    if step < warmup:
+        return base_lr * step / max(1, warmup)
+    if step > total:
+        return lr_end
+    rem = 1 - (step - warmup) / max(1, total - warmup)
+    return (base_lr - lr_end) * rem ** power + lr_end
+
+
+class PEATrainer:
+    LOG_KEYS = ("loss", "train_loss", "train_loss_logits", "train_loss_features")
+
+    def __init__(self, adapter: PEAAdapter, student: HipUNet, teacher: HipUNet, feat_weight: float = 0.1,
+                 nan_guard: bool = False, lr: float = 1e-5, betas=(0.9, 0.999), eps: float = 1e-8,
+                 weight_decay: float = 0.0, warmup_steps: int = 100, total_steps: int = 2232142, lr_end: float = 5e-8):
+        self.adapter, self.student, self.teacher = adapter, student, teacher
+        adapter.prepare(2 * student.B, student.L)
+        adapter._sync()
+        self._h = ctypes.c_void_p()
+        self._ac = ddpm_alphas_cumprod().to(student.device)
+        check(lib().pea_trainer_create(adapter._h, student._h, teacher._h, feat_weight, int(nan_guard), ptr(self._ac),
+                                       ctypes.byref(self._h)))
+        self.losses = torch.zeros(4, device=student.device)
+        self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
+        self.warmup_steps, self.total_steps, self.lr_end = warmup_steps, total_steps, lr_end
+        self.global_step = 0
+        self._m = torch.zeros_like(adapter.flat_param)
+        self._v = torch.zeros_like(adapter.flat_param)
+        self._comm_stream = None
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None) and self._h.value:
+                lib().pea_trainer_destroy(self._h)
+                self._h = ctypes.c_void_p()
+        except Exception:
+            pass
+
+    def _dev(self, t, dtype):
+        return t.detach().to(self.student.device, dtype).contiguous()
+
+    def training_step(self, batch: Dict[str, torch.Tensor], batch_idx: int = 0, sync: bool = False):
+        """batch: the post-encoder form of the reference batch: latents, noise, timesteps, enc,
+        enc_uncond, prompt_mask, zh_or_not, teacher_ehs, teacher_neg [, teacher_pooled, time_ids].
+        Leaves the adapter gradients in `adapter.flat_grad`; returns {"loss": device scalar, ...}."""
+        f32, dev = torch.float32, self._dev
+        self.adapter._sync()
+        b = {k: dev(batch[k], f32) for k in ("latents", "noise", "enc", "enc_uncond", "teacher_ehs", "teacher_neg")}
+        ts = dev(batch["timesteps"], torch.int64)
+        pm = dev(batch["prompt_mask"], torch.uint8)
+        zh = dev(batch["zh_or_not"], torch.int64)
+        tp = dev(batch["teacher_pooled"], f32) if "teacher_pooled" in batch else None
+        tid = dev(batch["time_ids"], f32) if "time_ids" in batch else None
+        world = self.world_size
+        check(lib().pea_train_step(self._h, ptr(b["latents"]), ptr(b["noise"]), ptr(ts), ptr(b["enc"]),
+                                   ptr(b["enc_uncond"]), ptr(pm), ptr(zh), ptr(b["teacher_ehs"]), ptr(b["teacher_neg"]),
+                                   ptr(tp), ptr(tid), 1.0, ptr(self.adapter.flat_grad), 0, ptr(self.losses),
+                                   stream_ptr()))
+        self._keep = (b, ts, pm, zh, tp, tid)
+        if world > 1:
+            self.all_reduce_grads()
+        for p, o in zip(self.adapter._plist(), self.adapter._offsets):
+            p.grad = self.adapter.flat_grad[o:o + p.numel()].view_as(p)
+        out = {k: self.losses[i] for i, k in enumerate(self.LOG_KEYS)}
+        if sync:
+            torch.cuda.synchronize()
+        return out
+
+    # ---- data parallel: ONE all-reduce over the flat adapter-grad buffer (24-46 MB), averaged
+    @property
+    def world_size(self) -> int:
+        import torch.distributed as dist
+        return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+    def all_reduce_grads(self, async_op: bool = False):
+        import torch.distributed as dist
+        g = self.adapter.flat_grad
+        work = dist.all_reduce(g, op=dist.ReduceOp.SUM, async_op=async_op)
+        if async_op:
+            return work
+        g.div_(self.world_size)
+        return None
+
+    def export(self, which: str) -> torch.Tensor:
+        idx = {"x_t": 0, "eps_student": 1, "eps_teacher": 2}[which]
+        out = torch.empty(self.student.B, self.student.cfg.in_channels, self.student.H, self.student.W,
+                          device=self.student.device)
+        check(lib().pea_trainer_export(self._h, idx, ptr(out), stream_ptr()))
+        return out
+
+    # ---- optimizer (FusedAdam adam_w_mode + polynomial schedule; weight_decay never reaches the
+    # reference's optimizer, utils/model_utils.py:64-67 + train_sdxl_zh.py:167, so the default is 0)
+    def current_lr(self) -> float:
+        return polynomial_lr(self.global_step, self.lr, self.warmup_steps, self.total_steps, self.lr_end)
+
+    def optimizer_step(self):
+        self.global_step += 1
+        lr = polynomial_lr(self.global_step, self.lr, self.warmup_steps, self.total_steps, self.lr_end)
+        ops.adamw_(self.adapter.flat_param, self.adapter.flat_grad, self._m, self._v, lr, self.global_step,
+                   self.betas[0], self.betas[1], self.eps, self.weight_decay)
+        self.adapter.flat_param._version  # noqa: B018  (in-place op below bumps the version counter)
+        self.adapter.mark_updated()
+
+    def save_adapter(self, root: str):
+        """`torch.save(self.proj.state_dict(), f"{root}/proj_{global_step}/pytorch_model.bin")`
+        (train_sdxl_zh.py:443-448)"""
+        d = os.path.join(root, f"proj_{self.global_step}")
+        os.makedirs(d, exist_ok=True)
+        torch.save({k: v.detach().cpu().clone() for k, v in self.adapter.state_dict().items()},
+                   os.path.join(d, "pytorch_model.bin"))
+        return d

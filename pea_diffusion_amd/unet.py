@@ -1,0 +1,190 @@
+"""`HipUNet`: the UNet plug-in surface of the reference --
+`unet(sample, t, encoder_hidden_states, added_cond_kwargs=..., return_dict=False)[0]`
+(train_sdxl_zh.py:397,415; tests/test_sdxl_zh.py:384-391) -- backed by the HIP op tape in
+libpea_hip.so.  `down_blocks[i]`, `mid_block`, `up_blocks[i]` accept `register_forward_hook`
+so the reference's `cast_hook` (train_sdxl_zh.py:79-84) works unchanged."""
+from __future__ import annotations
+
+import ctypes
+from typing import Dict, List, Optional
+
+import torch
+
+from . import config as _cfg
+from ._lib import PeaError, check, lib, ptr, stream_ptr
+
+
+class _HookHandle:
+    def __init__(self, lst, fn):
+        self.lst, self.fn = lst, fn
+
+    def remove(self):
+        if self.fn in self.lst:
+            self.lst.remove(self.fn)
+
+
+class _BlockShim:
+    """Hook-able stand-in for a diffusers block; `residuals_present` mirrors the `(hidden, res_samples)`
+    tuple that down blocks return (reference getActivation, train_sdxl_zh.py:69-77)."""
+
+    def __init__(self, name: str, tap_index: int, residuals_present: bool):
+        self.name, self.tap_index, self.residuals_present = name, tap_index, residuals_present
+        self._hooks: List = []
+
+    def register_forward_hook(self, fn):
+        self._hooks.append(fn)
+        return _HookHandle(self._hooks, fn)
+
+
+class _Config:
+    def __init__(self, cfg):
+        self.__dict__.update(cfg.__dict__)
+
+
+class HipUNet:
+    def __init__(self, cfg, batch: int, height: Optional[int] = None, width: Optional[int] = None, ctx_len: int = 77,
+                 needs_grad: bool = False, share_weights_from: Optional["HipUNet"] = None):
+        if not torch.cuda.is_available():
+            raise PeaError("HipUNet needs a MI355X (no CPU fallback)")
+        self.cfg = cfg
+        self.config = _Config(cfg)
+        self.in_channels = cfg.in_channels
+        self.B, self.H, self.W, self.L = batch, height or cfg.sample_size, width or cfg.sample_size, ctx_len
+        self.needs_grad = needs_grad
+        self.dtype = torch.bfloat16
+        self.device = torch.device("cuda", torch.cuda.current_device())
+        self._h = ctypes.c_void_p()
+        c = _cfg.to_c(cfg)
+        check(lib().pea_unet_create(ctypes.byref(c), self.B, self.H, self.W, self.L, int(needs_grad),
+                                    int(share_weights_from is None), ctypes.byref(self._h)))
+        if share_weights_from is not None:
+            check(lib().pea_unet_share_weights(self._h, share_weights_from._h))
+            self._weights_owner = share_weights_from      # keep alive
+        n = len(cfg.block_out_channels)
+        self.down_blocks = [_BlockShim(f"d{i}", i, True) for i in range(n)]
+        self.mid_block = _BlockShim("m", n, False)
+        self.up_blocks = [_BlockShim(f"u{i}", n + 1 + i, False) for i in range(n)]
+        self.num_taps = lib().pea_unet_num_taps(self._h)
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None) and self._h.value:
+                lib().pea_unet_destroy(self._h)
+                self._h = ctypes.c_void_p()
+        except Exception:
+            pass
+
+    # ---------------------------------------------------------------- weights
+    def weight_table(self) -> Dict[str, tuple]:
+        """{diffusers key: torch shape}"""
+        out = {}
+        name = ctypes.create_string_buffer(256)
+        numel, kind, d0, d1 = ctypes.c_longlong(), ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+        for i in range(lib().pea_unet_num_weights(self._h)):
+            check(lib().pea_unet_weight_info(self._h, i, name, 256, ctypes.byref(numel), ctypes.byref(kind),
+                                             ctypes.byref(d0), ctypes.byref(d1)))
+            k = kind.value
+            if k == 0:
+                shape = (d0.value,)
+            elif k == 1:
+                shape = (d0.value, d1.value)
+            else:
+                shape = (d0.value, d1.value, 3, 3)
+            out[name.value.decode()] = shape
+        return out
+
+    def load_state_dict(self, sd: Dict[str, torch.Tensor], strict: bool = True):
+        table = self.weight_table()
+        missing = [k for k in table if k not in sd]
+        unexpected = [k for k in sd if k not in table]
+        if strict and (missing or unexpected):
+            raise PeaError(f"load_state_dict: missing={missing[:5]} unexpected={unexpected[:5]}")
+        for k, shape in table.items():
+            if k not in sd:
+                continue
+            t = sd[k]
+            n = 1
+            for s in shape:
+                n *= s
+            if t.numel() != n:
+                raise PeaError(f"load_state_dict: {k} has shape {tuple(t.shape)}, expected {shape} (or 1x1 conv)")
+            t = t.detach().to(device=self.device, dtype=torch.float32).contiguous()
+            check(lib().pea_unet_load_weight(self._h, k.encode(), ptr(t), t.numel(), stream_ptr()))
+        torch.cuda.current_stream().synchronize()      # staging tensors above are freed after this call
+        return missing, unexpected
+
+    def init_random(self, seed: int = 0):
+        check(lib().pea_unet_init_random(self._h, seed, stream_ptr()))
+
+    def memory(self):
+        w, a, g, n = ctypes.c_longlong(), ctypes.c_longlong(), ctypes.c_longlong(), ctypes.c_int()
+        check(lib().pea_unet_memory(self._h, ctypes.byref(w), ctypes.byref(a), ctypes.byref(g), ctypes.byref(n)))
+        return {"weight_bytes": w.value, "activation_bytes": a.value, "grad_bytes": g.value, "n_ops": n.value}
+
+    # ---------------------------------------------------------------- forward
+    def __call__(self, sample, timestep, encoder_hidden_states, added_cond_kwargs=None, cross_attention_kwargs=None,
+                 return_dict=False, down_block_additional_residuals=None, mid_block_additional_residual=None):
+        if down_block_additional_residuals is not None or mid_block_additional_residual is not None:
+            raise NotImplementedError("ControlNet residual injection is not implemented in the HIP path yet")
+        B = sample.shape[0]
+        if tuple(sample.shape) != (self.B, self.in_channels, self.H, self.W):
+            raise PeaError(f"HipUNet built for {(self.B, self.in_channels, self.H, self.W)}, got {tuple(sample.shape)}")
+        x = sample.detach().to(self.device, torch.float32).contiguous()
+        t = timestep if torch.is_tensor(timestep) else torch.tensor([timestep])
+        t = t.to(self.device, torch.float32).reshape(-1).expand(B).contiguous()
+        ehs = encoder_hidden_states.detach().to(self.device)
+        if tuple(ehs.shape) != (self.B, self.L, self.cfg.cross_attention_dim):
+            raise PeaError(f"encoder_hidden_states {tuple(ehs.shape)} != {(self.B, self.L, self.cfg.cross_attention_dim)}")
+        e_dt = 1 if ehs.dtype == torch.bfloat16 else 0
+        ehs = ehs.contiguous() if e_dt else ehs.float().contiguous()
+        text = tid = None
+        t_dt = 0
+        if self.cfg.addition_embed_type == "text_time":
+            text = added_cond_kwargs["text_embeds"].detach().to(self.device)
+            t_dt = 1 if text.dtype == torch.bfloat16 else 0
+            text = text.contiguous() if t_dt else text.float().contiguous()
+            tid = added_cond_kwargs["time_ids"].detach().to(self.device, torch.float32).contiguous()
+        eps = torch.empty(self.B, self.cfg.out_channels, self.H, self.W, device=self.device, dtype=torch.float32)
+        check(lib().pea_unet_forward(self._h, ptr(x), ptr(t), ptr(ehs), e_dt, ptr(text), t_dt, ptr(tid), ptr(eps),
+                                     stream_ptr()))
+        self._keep = (x, t, ehs, text, tid)
+        for blk in list(self.down_blocks) + [self.mid_block] + list(self.up_blocks):
+            if blk._hooks:
+                tap = self.tap(blk.tap_index)
+                out = (tap, ()) if blk.residuals_present else tap
+                for fn in list(blk._hooks):
+                    fn(blk, (), out)
+        out = eps.to(sample.dtype) if sample.dtype in (torch.float16, torch.bfloat16) else eps
+        return (out,)
+
+    def tap(self, k: int, grad: bool = False) -> torch.Tensor:
+        """feature tap k (cast_hook order) as an NCHW fp32 tensor"""
+        B, H, W, C = ctypes.c_int(), ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+        check(lib().pea_unet_tap_info(self._h, k, None, None, ctypes.byref(B), ctypes.byref(H), ctypes.byref(W),
+                                      ctypes.byref(C)))
+        out = torch.empty(B.value, C.value, H.value, W.value, device=self.device, dtype=torch.float32)
+        check(lib().pea_unet_tap_export_nchw(self._h, k, int(grad), ptr(out), stream_ptr()))
+        return out
+
+    def tap_pointers(self, k: int):
+        d, g = ctypes.c_void_p(), ctypes.c_void_p()
+        B, H, W, C = ctypes.c_int(), ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+        check(lib().pea_unet_tap_info(self._h, k, ctypes.byref(d), ctypes.byref(g), ctypes.byref(B), ctypes.byref(H),
+                                      ctypes.byref(W), ctypes.byref(C)))
+        return d.value, g.value, (B.value, H.value, W.value, C.value)
+
+    # ---------------------------------------------------------------- backward (data gradients only)
+    def backward(self, d_eps: Optional[torch.Tensor], tap_seed_mask: int = 0):
+        """-> (d_encoder_hidden_states [B,L,cross] fp32, d_text_embeds [B,pooled] fp32 or None)"""
+        de = d_eps.detach().to(self.device, torch.float32).contiguous() if d_eps is not None else None
+        check(lib().pea_unet_backward(self._h, ptr(de), tap_seed_mask, stream_ptr()))
+        pe, pt = ctypes.c_void_p(), ctypes.c_void_p()
+        check(lib().pea_unet_input_grads(self._h, ctypes.byref(pe), ctypes.byref(pt)))
+        d_ehs = d_text = None
+        if pe.value:
+            d_ehs = torch.empty(self.B, self.L, self.cfg.cross_attention_dim, device=self.device)
+            check(lib().pea_op_cast_bf16_f32(pe, ptr(d_ehs), d_ehs.numel(), stream_ptr()))
+        if pt.value:
+            d_text = torch.empty(self.B, self.cfg.pooled_dim, device=self.device)
+            check(lib().pea_op_cast_bf16_f32(pt, ptr(d_text), d_text.numel(), stream_ptr()))
+        return d_ehs, d_text

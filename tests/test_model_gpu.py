@@ -1,0 +1,256 @@
+"""Model-level parity (-m gpu): the HIP UNet tape (forward + data-gradient backward), the adapter and
+the fused KD training step, called through the C ABI, against the CPU oracle (oracle/*.py) on the same
+seeded inputs and the same (bf16-rounded) weights.
+
+Tolerances: single kernels are held to 1 bf16 ulp in tests/test_ops_gpu.py.  Through a whole UNet
+(~10^2 chained bf16-stored ops) element-wise 1e-3 is not meaningful (SURVEY 7 "tolerance vs depth"), so
+end-to-end checks use relative L2 error: <= 2e-2 for forward tensors, <= 4e-2 for gradients that went
+through the full forward + backward, and rtol 1e-2 for the loss scalars (fp32 reductions of bf16 data).
+"""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a MI355X")
+    return torch.device("cuda")
+
+
+def rel_l2(a, b):
+    a, b = a.detach().float().cpu(), b.detach().float().cpu()
+    return ((a - b).pow(2).sum().sqrt() / (b.pow(2).sum().sqrt() + 1e-30)).item()
+
+
+def round_weights_bf16_(module):
+    with torch.no_grad():
+        for n, p in module.named_parameters():
+            if p.dim() >= 2:
+                p.copy_(p.to(torch.bfloat16).float())
+
+
+def make_pair(cfg_fn, B, L, needs_grad, seed=0, hw=None):
+    from oracle.unet_ref import UNet2DConditionRef
+    from pea_diffusion_amd import config as pc
+    from pea_diffusion_amd.unet import HipUNet
+    ocfg = cfg_fn()
+    torch.manual_seed(seed)
+    ref = UNet2DConditionRef(ocfg)
+    round_weights_bf16_(ref)
+    hw = hw or ocfg.sample_size
+    hip = HipUNet(getattr(pc, cfg_fn.__name__)(), B, hw, hw, L, needs_grad=needs_grad)
+    missing, unexpected = hip.load_state_dict(ref.state_dict())
+    assert not missing and not unexpected
+    return ocfg, ref, hip
+
+
+def cond_inputs(cfg, B, L, hw, seed=1):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(B, 4, hw, hw, generator=g)
+    t = torch.tensor([10, 250, 500, 999][:B])
+    ehs = torch.randn(B, L, cfg.cross_attention_dim, generator=g)
+    added = None
+    if cfg.addition_embed_type == "text_time":
+        added = {"text_embeds": torch.randn(B, cfg.pooled_dim, generator=g),
+                 "time_ids": torch.tensor([[hw * 8, hw * 8, 0, 0, hw * 8, hw * 8]] * B)}
+    return x, t, ehs, added
+
+
+def test_weight_table_matches_oracle_state_dict(gpu):
+    from oracle.unet_ref import UNet2DConditionRef, tiny_config
+    from pea_diffusion_amd import config as pc
+    from pea_diffusion_amd.unet import HipUNet
+    with torch.device("meta"):
+        ref = UNet2DConditionRef(tiny_config())
+    hip = HipUNet(pc.tiny_config(), 1, 16, 16, 7)
+    table = hip.weight_table()
+    sd = {k: tuple(v.shape) for k, v in ref.state_dict().items()}
+    assert set(table) == set(sd)
+    for k, shp in table.items():
+        assert int(np.prod(shp)) == int(np.prod(sd[k])), k
+
+
+@pytest.mark.parametrize("B,L", [(2, 7), (1, 77)])
+def test_unet_forward_tiny(gpu, B, L):
+    from oracle.unet_ref import cast_hook_ref, tap_names, tiny_config
+    cfg, ref, hip = make_pair(tiny_config, B, L, needs_grad=False)
+    x, t, ehs, added = cond_inputs(cfg, B, L, cfg.sample_size)
+    taps = {}
+    cast_hook_ref(ref, taps)
+    with torch.no_grad():
+        eref = ref(x, t, ehs.to(torch.bfloat16).float(), added_cond_kwargs=added)[0]
+    # reference-style hooks on the HIP UNet (train_sdxl_zh.py:69-84 semantics)
+    got = {}
+    n = len(cfg.block_out_channels)
+    for i in range(n):
+        hip.down_blocks[i].register_forward_hook(lambda m, inp, out, k=f"d{i}": got.__setitem__(k, out[0]))
+        hip.up_blocks[i].register_forward_hook(lambda m, inp, out, k=f"u{i}": got.__setitem__(k, out))
+    hip.mid_block.register_forward_hook(lambda m, inp, out: got.__setitem__("m", out))
+    eps = hip(x.cuda(), t.cuda(), ehs.cuda(), added_cond_kwargs={k: v.cuda() for k, v in added.items()})[0]
+    e = rel_l2(eps, eref)
+    print(f"[unet fwd tiny B{B} L{L}] eps rel_l2={e:.3e}")
+    assert set(got) == set(tap_names(cfg))
+    for k in tap_names(cfg):
+        ek = rel_l2(got[k], taps[k])
+        print(f"   tap {k}: shape {tuple(got[k].shape)} rel_l2={ek:.3e}")
+        assert got[k].shape == taps[k].shape and ek < 2e-2, k
+    assert e < 2e-2
+
+
+def test_unet_backward_tiny(gpu):
+    from oracle.unet_ref import cast_hook_ref, tap_names, tiny_config
+    from pea_diffusion_amd._lib import check, lib, ptr, stream_ptr
+    B, L = 2, 9
+    cfg, ref, hip = make_pair(tiny_config, B, L, needs_grad=True)
+    for p in ref.parameters():
+        p.requires_grad_(False)
+    x, t, ehs, added = cond_inputs(cfg, B, L, cfg.sample_size)
+    ehs_r = ehs.to(torch.bfloat16).float().requires_grad_(True)
+    te_r = added["text_embeds"].to(torch.bfloat16).float().requires_grad_(True)
+    taps = {}
+    cast_hook_ref(ref, taps)
+    eref = ref(x, t, ehs_r, added_cond_kwargs={"text_embeds": te_r, "time_ids": added["time_ids"]})[0]
+    g = torch.Generator().manual_seed(5)
+    names = tap_names(cfg)
+    seeds = {k: torch.randn(taps[k].shape, generator=g) * 0.1 for k in names}
+    d_eps = torch.randn(eref.shape, generator=g)
+    loss = (eref * d_eps).sum() + sum((taps[k] * seeds[k]).sum() for k in names)
+    loss.backward()
+    hip(x.cuda(), t.cuda(), ehs.cuda(), added_cond_kwargs={k: v.cuda() for k, v in added.items()})
+    mask = 0
+    for i, k in enumerate(names):
+        _, gptr, (b, h, w, c) = hip.tap_pointers(i)
+        s = seeds[k].permute(0, 2, 3, 1).contiguous().cuda()
+        check(lib().pea_op_cast_f32_bf16(ptr(s), ctypes.c_void_p(gptr), s.numel(), stream_ptr()))
+        mask |= 1 << i
+    d_ehs, d_text = hip.backward(d_eps.cuda(), mask)
+    e1, e2 = rel_l2(d_ehs, ehs_r.grad), rel_l2(d_text, te_r.grad)
+    print(f"[unet bwd tiny] d_ehs rel_l2={e1:.3e} |ref|={ehs_r.grad.norm():.3e}  d_text rel_l2={e2:.3e} "
+          f"|ref|={te_r.grad.norm():.3e}")
+    assert e1 < 4e-2 and e2 < 4e-2
+
+
+def test_adapter_module_matches_reference_golden(gpu, golden_dir):
+    """PEAAdapter vs golden vectors captured from the reference's own MLP (small dims are multiples of 64
+    only for `sd15_full`/`sdxl_6M`/...; the small goldens use dims the MFMA tiles do not accept, so the
+    full-size seeded goldens are used here)."""
+    import os
+    from pea_diffusion_amd.adapter import PEAAdapter
+    for tag in ["sdxl_6M", "sdxl_11M", "sd15_full"]:
+        g = np.load(os.path.join(golden_dir, f"mlp_{tag}.npz"))
+        args = [int(a) for a in g["args"]]
+        torch.manual_seed(int(g["seed"]))
+        m = PEAAdapter(*args[:3], None) if len(args) == 3 else PEAAdapter(args[0], args[1], args[2], args[3], bool(args[4]))
+        wsum = float(sum(v.double().abs().sum().item() for v in m.state_dict().values()))
+        assert abs(wsum - float(g["wsum"])) < 1e-6 * float(g["wsum"])
+        assert list(m.state_dict().keys()) == [str(k) for k in g["keys"]]
+        m = m.cuda()
+        with torch.no_grad():
+            out = m(torch.from_numpy(g["x"]).cuda())
+        outs = out if isinstance(out, tuple) else (out,)
+        for i, o in enumerate(outs):
+            e = rel_l2(o, torch.from_numpy(g[f"out{i}"]))
+            print(f"[adapter golden {tag}] out{i} rel_l2={e:.3e}")
+            assert e < 1e-2
+
+
+@pytest.mark.parametrize("args", [(128, 192, 256, 128, False), (128, 128, 64, 192, True), (128, 64, 192, None, False)])
+def test_adapter_forward_backward_vs_oracle(gpu, args):
+    from oracle.step_ref import AdapterRef
+    from pea_diffusion_amd.adapter import PEAAdapter
+    torch.manual_seed(3)
+    ref = AdapterRef(*args)
+    hip = PEAAdapter(*args)
+    hip.load_state_dict(ref.state_dict())
+    hip = hip.cuda()
+    round_weights_bf16_(ref)
+    B, L = 3, 11
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(B, L, args[0], generator=g).to(torch.bfloat16).float()
+    out_r = ref(x)
+    out_h = hip(x.cuda())
+    outs_r = out_r if isinstance(out_r, tuple) else (out_r,)
+    outs_h = out_h if isinstance(out_h, tuple) else (out_h,)
+    gs = [torch.randn(o.shape, generator=g) for o in outs_r]
+    for i, (a, b) in enumerate(zip(outs_h, outs_r)):
+        e = rel_l2(a, b)
+        print(f"[adapter {args}] out{i} rel_l2={e:.3e}")
+        assert e < 1e-2
+    torch.autograd.backward(outs_r, gs)
+    torch.autograd.backward(outs_h, [t.cuda() for t in gs])
+    for (k, p), (_, q) in zip(hip.named_parameters(), ref.named_parameters()):
+        e = rel_l2(p.grad, q.grad)
+        print(f"   grad {k}: rel_l2={e:.3e}")
+        assert e < 2e-2, k
+
+
+def _train_pair(B, L, seed=0):
+    from oracle.step_ref import AdapterRef, synthetic_batch
+    from oracle.unet_ref import UNet2DConditionRef, tiny_config
+    from pea_diffusion_amd import config as pc
+    from pea_diffusion_amd.adapter import PEAAdapter
+    from pea_diffusion_amd.train import PEATrainer
+    from pea_diffusion_amd.unet import HipUNet
+    cfg = tiny_config()
+    torch.manual_seed(seed)
+    us, ut = UNet2DConditionRef(cfg), UNet2DConditionRef(cfg)
+    round_weights_bf16_(us)
+    round_weights_bf16_(ut)
+    for p in list(us.parameters()) + list(ut.parameters()):
+        p.requires_grad_(False)
+    ad_ref = AdapterRef(128, cfg.pooled_dim, 192, cfg.cross_attention_dim, False)
+    ad_hip = PEAAdapter(128, cfg.pooled_dim, 192, cfg.cross_attention_dim, False)
+    ad_hip.load_state_dict(ad_ref.state_dict())
+    ad_hip = ad_hip.cuda()
+    round_weights_bf16_(ad_ref)
+    hs = HipUNet(pc.tiny_config(), B, 16, 16, L, needs_grad=True)
+    ht = HipUNet(pc.tiny_config(), B, 16, 16, 77, needs_grad=False)
+    hs.load_state_dict(us.state_dict())
+    ht.load_state_dict(ut.state_dict())
+    batch = synthetic_batch(cfg, B, L=L, enc_dim=128, seed=seed)
+    return cfg, us, ut, ad_ref, ad_hip, hs, ht, batch, PEATrainer(ad_hip, hs, ht)
+
+
+@pytest.mark.parametrize("B,L", [(4, 12), (2, 77)])
+def test_training_step_vs_oracle(gpu, B, L):
+    from oracle.step_ref import training_step_ref
+    from oracle.unet_ref import cast_hook_ref
+    cfg, us, ut, ad_ref, ad_hip, hs, ht, batch, tr = _train_pair(B, L)
+    bq = dict(batch)
+    for k in ("enc", "enc_uncond", "teacher_ehs", "teacher_neg", "teacher_pooled"):
+        bq[k] = batch[k].to(torch.bfloat16).float()
+    out_r = training_step_ref(ad_ref, us, ut, bq, cast_hook_ref)
+    out_r["loss"].backward()
+    out_h = tr.training_step(batch, 0, sync=True)
+    for k in tr.LOG_KEYS:
+        r, h = float(out_r[k]), float(out_h[k])
+        print(f"[train step B{B} L{L}] {k}: hip={h:.6f} oracle={r:.6f}")
+        assert abs(h - r) <= 1e-2 * max(abs(r), 1e-3), k
+    print(f"   eps_student rel_l2={rel_l2(tr.export('eps_student'), out_r['noise_pred']):.3e} "
+          f"eps_teacher rel_l2={rel_l2(tr.export('eps_teacher'), out_r['noise_pred_teacher']):.3e}")
+    for (k, p), (_, q) in zip(ad_hip.named_parameters(), ad_ref.named_parameters()):
+        e = rel_l2(p.grad, q.grad)
+        print(f"   adapter grad {k}: rel_l2={e:.3e} |ref|={q.grad.norm():.3e}")
+        assert e < 4e-2, k
+
+
+def test_training_step_repeatable_and_optimizer(gpu):
+    cfg, us, ut, ad_ref, ad_hip, hs, ht, batch, tr = _train_pair(2, 12)
+    a = tr.training_step(batch, 0, sync=True)
+    g1 = ad_hip.flat_grad.clone()
+    l1 = tr.losses.clone()
+    b = tr.training_step(batch, 0, sync=True)
+    # fp32/fp64 atomics (GroupNorm statistics, temb column sums, LN dgamma) make the last bits order-dependent
+    assert rel_l2(tr.losses, l1) < 1e-5 and rel_l2(ad_hip.flat_grad, g1) < 1e-3, "training step is not reproducible"
+    w0 = ad_hip.flat_param.clone()
+    tr.lr, tr.warmup_steps = 1e-3, 1
+    tr.optimizer_step()
+    assert not torch.equal(w0, ad_hip.flat_param)
+    c = tr.training_step(batch, 0, sync=True)
+    assert float(c["loss"]) != float(a["loss"])   # bf16 working copies were refreshed after the update
