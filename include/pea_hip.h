@@ -66,7 +66,10 @@ int pea_op_conv_out_dgrad(const float* dy_nchw, const float* w_packed, void* dx_
                           int Cout, void* stream);
 int pea_op_pack_conv_out(const float* w, float* out, int Co, int Ci, void* stream);
 
-/* GroupNorm (+ optional SiLU) over x[B][HW][C] bf16; stats fp32 [B][groups][2]; scratch >= 16*B*groups bytes */
+/* GroupNorm (+ optional SiLU) over x[B][HW][C] bf16; stats fp32 [B][groups][2]; scratch: device bytes from
+ * pea_op_groupnorm_scratch_bytes (per-block partial sums: the reduction order is fixed, results are
+ * bit-reproducible)                                                                               */
+long long pea_op_groupnorm_scratch_bytes(int B, int HW, int C, int groups);
 int pea_op_groupnorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* stats, void* scratch,
                          int B, int HW, int C, int groups, float eps, int silu, void* stream);
 int pea_op_groupnorm_bwd(const void* x, const void* dy, const float* gamma, const float* beta, const float* stats,
@@ -103,7 +106,8 @@ int pea_op_cast_bf16_f32(const void* x, float* y, long long n, void* stream);
  * per: HOST array of per-sample element counts.  eps_*: fp32 [B][per_eps].  zh: int64 [B] device.
  * losses: fp32[4] device = (loss, train_loss, train_loss_logits, train_loss_features).
  * dtaps[k] / deps_s receive dL/d(student tap) / dL/d(eps_s) (may be NULL).
- * workspace: >= 256 bytes of device scratch.                                                       */
+ * workspace: device scratch of pea_op_kd_loss_workspace_bytes(...) bytes (per-block partials).           */
+long long pea_op_kd_loss_workspace_bytes(int ntaps, const long long* per, long long per_eps, int B);
 int pea_op_kd_loss(int ntaps, const void* const* taps_s, const void* const* taps_t, void* const* dtaps,
                    const long long* per, const float* eps_s, const float* eps, const float* eps_t, float* deps_s,
                    long long per_eps, const long long* zh, int B, float feat_weight, int nan_guard,

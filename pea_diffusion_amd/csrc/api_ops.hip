@@ -178,6 +178,13 @@ int pea_op_kd_loss(int ntaps, const void* const* taps_s, const void* const* taps
   return launch_kd_loss(p, (hipStream_t)stream);
 }
 
+long long pea_op_groupnorm_scratch_bytes(int B, int HW, int C, int groups) {
+  return (long long)groupnorm_scratch_bytes(B, HW, C, groups);
+}
+long long pea_op_kd_loss_workspace_bytes(int ntaps, const long long* per, long long per_eps, int B) {
+  return (long long)kd_loss_workspace_bytes(ntaps, per, per_eps, B);
+}
+
 int pea_op_adamw(float* w, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2,
                  float eps, float weight_decay, int step, float grad_scale, void* stream) {
   return launch_adamw(w, g, m, v, n, lr, beta1, beta2, eps, weight_decay, step, grad_scale, (hipStream_t)stream);

@@ -431,14 +431,15 @@ int launch_adamw(float* w, const float* g, float* m, float* v, long long n, floa
   return PEA_OK;
 }
 
-// ---- per-batch column sums with fp32 atomics: out[b][c] += sum_p x[b][p][c]
+// ---- per-batch column sums, deterministic two-stage: out[b][c] = sum_p x[b][p][c]
 // (gradient of the per-sample time-embedding row vector added in the ResBlock conv1 epilogue)
-__global__ void colsum_batched_kernel(const bf16* __restrict__ x, float* __restrict__ out, int HW, int C, int ldo,
+__global__ void colsum_batched_kernel(const bf16* __restrict__ x, float* __restrict__ partial, int HW, int C,
                                       int pix_per_block) {
+  extern __shared__ __attribute__((aligned(16))) char csm[];
+  float* tsum = (float*)csm;                       // [ppb][C]
   const int nchunk = C / 8;
   const int ppb = blockDim.x / nchunk;
   const int ck = threadIdx.x % nchunk, pl = threadIdx.x / nchunk;
-  if (pl >= ppb) return;
   const int b = blockIdx.y;
   const int p0 = blockIdx.x * pix_per_block, p1 = min(p0 + pix_per_block, HW);
   float s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -448,16 +449,46 @@ __global__ void colsum_batched_kernel(const bf16* __restrict__ x, float* __restr
     for (int j = 0; j < 8; ++j) s[j] += (float)v[j];
   }
 #pragma unroll
-  for (int j = 0; j < 8; ++j) atomicAdd(&out[(long long)b * ldo + ck * 8 + j], s[j]);
+  for (int j = 0; j < 8; ++j) tsum[(long long)pl * C + ck * 8 + j] = s[j];
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    float a = 0.f;
+    for (int l = 0; l < ppb; ++l) a += tsum[(long long)l * C + c];
+    partial[((long long)b * gridDim.x + blockIdx.x) * C + c] = a;
+  }
 }
-int launch_colsum_batched(const bf16* x, float* out, int B, int HW, int C, int ldo, hipStream_t s) {
-  SHAPECHK(C % 8 == 0 && C / 8 <= 1024, "colsum_batched: C=%d", C);
+__global__ void colsum_batched_reduce_kernel(const float* __restrict__ partial, float* __restrict__ out, int nblk,
+                                             int C, int ldo) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  const int b = blockIdx.y;
+  if (c >= C) return;
+  float a = 0.f;
+  for (int k = 0; k < nblk; ++k) a += partial[((long long)b * nblk + k) * C + c];
+  out[(long long)b * ldo + c] = a;
+}
+static void colsum_geometry(int HW, int C, int* threads, int* per, int* nblk) {
   const int nchunk = C / 8;
   int ppb = 256 / nchunk;
   if (ppb < 1) ppb = 1;
-  int per = ppb * 64;
-  if (per > HW) per = HW;
-  hipLaunchKernelGGL(colsum_batched_kernel, dim3(cdiv(HW, per), B), dim3(nchunk * ppb), 0, s, x, out, HW, C, ldo, per);
+  *threads = nchunk * ppb;
+  int p = ppb * 128;
+  if (p > HW) p = HW;
+  *per = p;
+  *nblk = cdiv(HW, p);
+}
+size_t colsum_batched_scratch_bytes(int B, int HW, int C) {
+  int threads, per, nblk;
+  colsum_geometry(HW, C, &threads, &per, &nblk);
+  return (size_t)B * nblk * C * sizeof(float) + 256;
+}
+int launch_colsum_batched(const bf16* x, float* out, int B, int HW, int C, int ldo, float* scratch, hipStream_t s) {
+  SHAPECHK(C % 8 == 0 && C / 8 <= 1024, "colsum_batched: C=%d", C);
+  int threads, per, nblk;
+  colsum_geometry(HW, C, &threads, &per, &nblk);
+  const int ppb = threads / (C / 8);
+  hipLaunchKernelGGL(colsum_batched_kernel, dim3(nblk, B), dim3(threads), (size_t)ppb * C * 4, s, x, scratch, HW, C,
+                     per);
+  hipLaunchKernelGGL(colsum_batched_reduce_kernel, dim3(cdiv(C, 64), B), dim3(64), 0, s, scratch, out, nblk, C, ldo);
   HIPCHK(hipGetLastError());
   return PEA_OK;
 }

@@ -4,8 +4,8 @@
 // (dL/dF_S^k, dL/d eps_S) so the backward pass starts without another sweep.
 //
 // HBM-bound: per image 2 x 25.56 M tap elements read + 25.56 M written (bf16) for SDXL.
-// 16 bytes per lane, fp32 per-thread accumulation, wave shuffle reduction, one fp64 atomic per
-// block.  Samples whose mask weight is 0 are not read at all (their seeds are zeros).
+// 16 bytes per lane, fp32 per-thread accumulation, wave shuffle reduction, one partial per block summed
+// in fixed order by the finishing kernel (no atomics: bit-reproducible).  Samples whose mask weight is 0 are not read at all (their seeds are zeros).
 #include "pea_kernels.h"
 
 #define KD_CHUNKS_PER_BLOCK 4096   // 16-byte chunks per block (64 KiB of each input)
@@ -18,21 +18,23 @@ struct KdSegs {
   KdSeg s[PEA_MAX_TAPS + 1];
 };
 
-__device__ __forceinline__ void block_accumulate(float v, double* dst) {
+// deterministic block reduction: wave shuffle tree + fixed-order sum of the 4 wave results
+__device__ __forceinline__ float block_sum(float v) {
   __shared__ float wsum[4];
   v = wave_sum(v);
+  __syncthreads();
   if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = v;
   __syncthreads();
-  if (threadIdx.x == 0) atomicAdd(dst, (double)(wsum[0] + wsum[1] + wsum[2] + wsum[3]));
-  __syncthreads();
+  return (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
 }
 
-__global__ __launch_bounds__(256) void kd_loss_kernel(const KdLossP p, const KdSegs segs, double* partial) {
-  // find the segment of this block (<= 13 entries; uniform)
+// partial: fp32 [nblocks][2] (one slot pair per block; no atomics -> bit-reproducible)
+__global__ __launch_bounds__(256) void kd_loss_kernel(const KdLossP p, const KdSegs segs, float* partial) {
   int k = 0;
   while (k < p.ntaps && (long long)blockIdx.x >= segs.s[k + 1].blk0) ++k;
   const long long c0 = ((long long)blockIdx.x - segs.s[k].blk0) * KD_CHUNKS_PER_BLOCK;
   const long long c1 = min(c0 + KD_CHUNKS_PER_BLOCK, segs.s[k].nchunks);
+  float r0 = 0.f, r1 = 0.f;
   if (k < p.ntaps) {
     const bf16* fs = p.fs[k];
     const bf16* ft = p.ft[k];
@@ -59,7 +61,7 @@ __global__ __launch_bounds__(256) void kd_loss_kernel(const KdLossP p, const KdS
       }
       if (dfs) *(bf16x8*)(dfs + c * 8) = g;
     }
-    block_accumulate(acc, &partial[2 + k]);
+    r0 = block_sum(acc);
   } else {
     const long long per4 = p.per_eps / 4;
     const float gsc = p.grad_scale * 2.0f / ((float)p.per_eps * (float)p.B);
@@ -80,20 +82,44 @@ __global__ __launch_bounds__(256) void kd_loss_kernel(const KdLossP p, const KdS
       if (zh) a0 += acc; else a1 += acc;
       if (p.deps_s) *(f32x4*)(p.deps_s + c * 4) = g;
     }
-    block_accumulate(a0, &partial[0]);
-    block_accumulate(a1, &partial[1]);
+    r0 = block_sum(a0);
+    r1 = block_sum(a1);
+  }
+  if (threadIdx.x == 0) {
+    partial[2 * (long long)blockIdx.x] = r0;
+    partial[2 * (long long)blockIdx.x + 1] = r1;
   }
 }
 
+// one block: sums each segment's block partials in fixed order (fp64), then composes the losses.
 // losses[0..3] = total, train_loss, train_loss_logits, train_loss_features; skip[k] = 1 when the SD1.5
 // NaN/Inf guard (train_sd_zh.py:246-268) drops tap k.
-__global__ void kd_finish_kernel(const KdLossP p, const double* partial, float* losses, int* skip) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+__global__ __launch_bounds__(256) void kd_finish_kernel(const KdLossP p, const KdSegs segs, const float* partial,
+                                                        float* losses, int* skip) {
+  __shared__ double red[256];
+  __shared__ double seg_sum[PEA_MAX_TAPS + 2];
+  for (int k = 0; k <= p.ntaps + 1; ++k) {
+    const int seg = k <= p.ntaps ? k : p.ntaps;          // last two entries: eps slot 0 / slot 1
+    const int slot = k == p.ntaps + 1 ? 1 : 0;
+    const long long b0 = segs.s[seg].blk0;
+    const long long b1 = seg < p.ntaps ? segs.s[seg + 1].blk0 : b0 + (segs.s[seg].nchunks + KD_CHUNKS_PER_BLOCK - 1) / KD_CHUNKS_PER_BLOCK;
+    double a = 0.0;
+    for (long long i = b0 + threadIdx.x; i < b1; i += 256) a += (double)partial[2 * i + slot];
+    red[threadIdx.x] = a;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+      if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) seg_sum[k] = red[0];
+    __syncthreads();
+  }
+  if (threadIdx.x != 0) return;
   const double nb = (double)p.per_eps * (double)p.B;
-  const double l0 = partial[0] / nb, l1 = partial[1] / nb;
+  const double l0 = seg_sum[p.ntaps] / nb, l1 = seg_sum[p.ntaps + 1] / nb;
   double lf = 0.0;
   for (int k = 0; k < p.ntaps; ++k) {
-    const double t = partial[2 + k] / ((double)p.per[k] * (double)p.B);
+    const double t = seg_sum[k] / ((double)p.per[k] * (double)p.B);
     const bool bad = p.nan_guard && !isfinite(t);
     if (skip) skip[k] = bad ? 1 : 0;
     if (!bad) lf += t;
@@ -115,6 +141,16 @@ __global__ void kd_zero_skipped_kernel(const KdLossP p, const int* skip) {
     *(bf16x8*)(p.dfs[k] + i * 8) = z;
 }
 
+static long long kd_total_blocks(int ntaps, const long long* per, long long per_eps, int B) {
+  long long blk = 0;
+  for (int k = 0; k < ntaps; ++k) blk += cdivl((long long)B * per[k] / 8, KD_CHUNKS_PER_BLOCK);
+  blk += cdivl((long long)B * per_eps / 4, KD_CHUNKS_PER_BLOCK);
+  return blk;
+}
+size_t kd_loss_workspace_bytes(int ntaps, const long long* per, long long per_eps, int B) {
+  return (size_t)kd_total_blocks(ntaps, per, per_eps, B) * 2 * sizeof(float) + sizeof(int) * PEA_MAX_TAPS + 256;
+}
+
 int launch_kd_loss(const KdLossP& p, hipStream_t s) {
   SHAPECHK(p.ntaps >= 0 && p.ntaps <= PEA_MAX_TAPS, "kd_loss: ntaps=%d", p.ntaps);
   SHAPECHK(p.per_eps % 4 == 0, "kd_loss: per_eps %% 4");
@@ -129,12 +165,11 @@ int launch_kd_loss(const KdLossP& p, hipStream_t s) {
   segs.s[p.ntaps].blk0 = blk;
   segs.s[p.ntaps].nchunks = (long long)p.B * p.per_eps / 4;
   blk += cdivl(segs.s[p.ntaps].nchunks, KD_CHUNKS_PER_BLOCK);
-  // partial: fp64 [2 + ntaps] followed by int skip[ntaps]; caller provides >= 256 bytes in p.partial
-  double* partial = (double*)p.partial;
-  int* skip = (int*)(partial + 2 + PEA_MAX_TAPS);
-  HIPCHK(hipMemsetAsync(partial, 0, sizeof(double) * (2 + PEA_MAX_TAPS) + sizeof(int) * PEA_MAX_TAPS, s));
+  // workspace: int skip[PEA_MAX_TAPS] | float partial[nblocks][2]   (kd_loss_workspace_bytes)
+  int* skip = (int*)p.partial;
+  float* partial = (float*)(skip + PEA_MAX_TAPS);
   hipLaunchKernelGGL(kd_loss_kernel, dim3((unsigned)blk), dim3(256), 0, s, p, segs, partial);
-  hipLaunchKernelGGL(kd_finish_kernel, dim3(1), dim3(64), 0, s, p, partial, p.losses, skip);
+  hipLaunchKernelGGL(kd_finish_kernel, dim3(1), dim3(256), 0, s, p, segs, partial, p.losses, skip);
   if (p.nan_guard && p.ntaps > 0)
     hipLaunchKernelGGL(kd_zero_skipped_kernel, dim3(256, p.ntaps), dim3(256), 0, s, p, skip);
   HIPCHK(hipGetLastError());

@@ -99,7 +99,7 @@ struct Unet {
   char* aarena = nullptr; size_t abytes = 0;
   char* garena = nullptr; size_t gbytes = 0;
   // scratch
-  double* gn_scratch = nullptr; float* delta = nullptr; bf16* ups_tmp = nullptr; float* tproj_grad = nullptr;
+  double* gn_scratch = nullptr; float* cs_scratch = nullptr; float* delta = nullptr; bf16* ups_tmp = nullptr; float* tproj_grad = nullptr;
   float* tmp_f32 = nullptr; size_t tmp_f32_elems = 0;   // load-time staging
   const bf16* zeros = nullptr;
   // per-call externals

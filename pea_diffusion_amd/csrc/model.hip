@@ -371,7 +371,13 @@ int Unet::alloc() {
     if (o.kind == OP_CONV3 && o.p1 && tn[o.a].rg)
       ups_elems = std::max(ups_elems, (size_t)tn[o.out].rows * tn[o.a].cols);
   }
-  HIPCHK(hipMalloc((void**)&gn_scratch, sizeof(double) * 2 * B * cfg.groups));
+  size_t gn_bytes = 256, cs_bytes = 256;
+  for (Op& o : ops) {
+    if (o.kind == OP_GN) gn_bytes = std::max(gn_bytes, groupnorm_scratch_bytes(tn[o.a].B, tn[o.a].H * tn[o.a].W, tn[o.a].cols, cfg.groups));
+    if (o.kind == OP_CONV3 && o.rv >= 0) cs_bytes = std::max(cs_bytes, colsum_batched_scratch_bytes(tn[o.out].B, tn[o.out].H * tn[o.out].W, tn[o.out].cols));
+  }
+  HIPCHK(hipMalloc((void**)&gn_scratch, gn_bytes));
+  if (needs_grad) HIPCHK(hipMalloc((void**)&cs_scratch, cs_bytes));
   if (needs_grad) {
     if (delta_elems) HIPCHK(hipMalloc((void**)&delta, delta_elems * 4));
     if (ups_elems) HIPCHK(hipMalloc((void**)&ups_tmp, ups_elems * 2));
@@ -390,6 +396,7 @@ Unet::~Unet() {
   if (delta) hipFree(delta);
   if (ups_tmp) hipFree(ups_tmp);
   if (tproj_grad) hipFree(tproj_grad);
+  if (cs_scratch) hipFree(cs_scratch);
 }
 
 int Unet::load_weight(const char* name, const float* src, long long numel, hipStream_t s) {
@@ -647,7 +654,7 @@ int Unet::backward(const float* deps, hipStream_t s) {
           a.gw = true;
         }
         if (o.rv >= 0 && tn[o.rv].rg)
-          RC(launch_colsum_batched(out.g, tproj_grad + o.rv_off, out.B, out.H * out.W, out.cols, tproj_total, s));
+          RC(launch_colsum_batched(out.g, tproj_grad + o.rv_off, out.B, out.H * out.W, out.cols, tproj_total, cs_scratch, s));
         if (o.res >= 0 && tn[o.res].rg) {
           Tn& r = tn[o.res];
           RC(launch_accum(out.g, r.g, r.rows * r.cols, r.gw, s));
@@ -822,7 +829,7 @@ int Adapter::backward(float* g, int accumulate, hipStream_t s) {
   RC(launch_gelu_bwd(z0, da0, dz0, (long long)R * hidden, 0, s));
   RC(agemm(dz0, hidden, w0t, hidden, dxn, in_dim, R, in_dim, hidden, 0, nullptr, nullptr, 0, 0, s));
   RC(wgrad(*this, dz0, hidden, xn, in_dim, g + off_w0, 1, s));
-  RC(launch_layernorm_bwd(x, dxn, params + off_lnw, ln_stats, da0 /*unused dx sink*/, g + off_lnw, g + off_lnb, R,
+  RC(launch_layernorm_bwd(x, dxn, params + off_lnw, ln_stats, nullptr /*no input gradient needed*/, g + off_lnw, g + off_lnb, R,
                           in_dim, 0, s));
   return PEA_OK;
 }
@@ -854,7 +861,11 @@ int Trainer::prepare() {
   HIPCHK(hipMalloc((void**)&eps_t, n * 4));
   HIPCHK(hipMalloc((void**)&deps, n * 4));
   HIPCHK(hipMalloc((void**)&losses, 16));
-  HIPCHK(hipMalloc((void**)&kd_ws, 512));
+  {
+    std::vector<long long> per;
+    for (int tid_ : S.taps) per.push_back(S.tn[tid_].rows / S.B * S.tn[tid_].cols);
+    HIPCHK(hipMalloc((void**)&kd_ws, kd_loss_workspace_bytes((int)per.size(), per.data(), (long long)S.cfg.in_channels * S.H * S.W, S.B)));
+  }
   HIPCHK(hipMalloc((void**)&tehs_c, (size_t)Tt.B * Tt.L * Tt.cfg.cross_dim * 2));
   HIPCHK(hipMalloc((void**)&tehs_n, (size_t)Tt.B * Tt.L * Tt.cfg.cross_dim * 2));
   // DDPM alphas_cumprod, scaled_linear betas (train_sdxl_zh.py:140)

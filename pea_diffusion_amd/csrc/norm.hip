@@ -10,20 +10,22 @@
 #define GN_MAX_GROUPS 64
 
 // thread t -> channel chunk (t % nchunk) [8 channels], pixel lane (t / nchunk)
-// grid: (blocks over pixels, B).  scratch: double [B][groups][2], zeroed by the launcher.
+// grid: (blocks over pixels, B).  Deterministic (no atomics): per-thread sums -> LDS -> fixed-order sum over
+// pixel lanes -> per-channel block sums -> fixed-order sum over each group's channels -> partial[b][blk][g][2];
+// gn_finalize_kernel then adds the blocks in order (fp64).
 template <int BWD>
 __global__ void gn_stats_kernel(const bf16* __restrict__ x, const bf16* __restrict__ dy,
                                 const float* __restrict__ gamma, const float* __restrict__ beta,
-                                const float* __restrict__ stats, double* __restrict__ scratch, int HW, int C,
+                                const float* __restrict__ stats, float* __restrict__ partial, int HW, int C,
                                 int groups, int pix_per_block, int silu) {
-  __shared__ float red[2 * GN_MAX_GROUPS];
+  extern __shared__ __attribute__((aligned(16))) char gsm[];
   const int nchunk = C / 8;
   const int ppb = blockDim.x / nchunk;
   const int tid = threadIdx.x;
   const int b = blockIdx.y;
   const int cpg = C / groups;
-  if (tid < 2 * GN_MAX_GROUPS) red[tid] = 0.f;
-  __syncthreads();
+  float* tsum = (float*)gsm;                 // [ppb][nchunk][16]
+  float* csum = tsum + ppb * nchunk * 16;    // [2][C]
   const int ck = tid % nchunk, pl = tid / nchunk;
   float s1[8], s2[8];
 #pragma unroll
@@ -66,37 +68,59 @@ __global__ void gn_stats_kernel(const bf16* __restrict__ x, const bf16* __restri
         }
       }
     }
-    // merge consecutive channels of the same group before touching LDS
-    int gprev = c0 / cpg;
-    float a1 = 0.f, a2 = 0.f;
+    float* dst = tsum + ((long long)pl * nchunk + ck) * 16;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      const int g = (c0 + j) / cpg;
-      if (g != gprev) {
-        atomicAdd(&red[2 * gprev], a1);
-        atomicAdd(&red[2 * gprev + 1], a2);
-        a1 = a2 = 0.f;
-        gprev = g;
-      }
-      a1 += s1[j];
-      a2 += s2[j];
+      dst[j] = s1[j];
+      dst[8 + j] = s2[j];
     }
-    atomicAdd(&red[2 * gprev], a1);
-    atomicAdd(&red[2 * gprev + 1], a2);
   }
   __syncthreads();
-  if (tid < 2 * groups) atomicAdd(&scratch[(long long)b * groups * 2 + tid], (double)red[tid]);
+  for (int c = tid; c < C; c += blockDim.x) {           // per-channel sums over the pixel lanes, fixed order
+    float a1 = 0.f, a2 = 0.f;
+    const int k = c >> 3, j = c & 7;
+    for (int l = 0; l < ppb; ++l) {
+      a1 += tsum[((long long)l * nchunk + k) * 16 + j];
+      a2 += tsum[((long long)l * nchunk + k) * 16 + 8 + j];
+    }
+    csum[c] = a1;
+    csum[C + c] = a2;
+  }
+  __syncthreads();
+  if (tid < groups) {
+    float a1 = 0.f, a2 = 0.f;
+    for (int c = tid * cpg; c < (tid + 1) * cpg; ++c) {
+      a1 += csum[c];
+      a2 += csum[C + c];
+    }
+    float* o = partial + (((long long)b * gridDim.x + blockIdx.x) * groups + tid) * 2;
+    o[0] = a1;
+    o[1] = a2;
+  }
 }
 
-__global__ void gn_finalize_kernel(const double* __restrict__ scratch, float* __restrict__ stats, int n_bg,
-                                   double count, float eps) {
+// sums the per-block partials in block order (fp64); FWD: writes (mean, rstd); BWD: writes (S1, S2) means
+__global__ void gn_finalize_kernel(const float* __restrict__ partial, float* __restrict__ out, int n_bg, int groups,
+                                   int nblk, double count, float eps, int bwd) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n_bg) return;
-  const double m = scratch[2 * i] / count;
-  double var = scratch[2 * i + 1] / count - m * m;
-  if (var < 0) var = 0;
-  stats[2 * i] = (float)m;
-  stats[2 * i + 1] = (float)(1.0 / sqrt(var + (double)eps));
+  const int b = i / groups, g = i - b * groups;
+  double s1 = 0.0, s2 = 0.0;
+  for (int k = 0; k < nblk; ++k) {
+    const float* p = partial + (((long long)b * nblk + k) * groups + g) * 2;
+    s1 += (double)p[0];
+    s2 += (double)p[1];
+  }
+  if (bwd) {
+    out[2 * i] = (float)(s1 / count);
+    out[2 * i + 1] = (float)(s2 / count);
+  } else {
+    const double m = s1 / count;
+    double var = s2 / count - m * m;
+    if (var < 0) var = 0;
+    out[2 * i] = (float)m;
+    out[2 * i + 1] = (float)(1.0 / sqrt(var + (double)eps));
+  }
 }
 
 __global__ void gn_apply_kernel(const bf16* __restrict__ x, const float* __restrict__ gamma,
@@ -127,12 +151,11 @@ __global__ void gn_apply_kernel(const bf16* __restrict__ x, const float* __restr
 
 __global__ void gn_bwd_apply_kernel(const bf16* __restrict__ x, const bf16* __restrict__ dy,
                                     const float* __restrict__ gamma, const float* __restrict__ beta,
-                                    const float* __restrict__ stats, const double* __restrict__ scratch,
+                                    const float* __restrict__ stats, const float* __restrict__ sums,
                                     bf16* __restrict__ dx, int HW, int C, int groups, int silu, int accum,
                                     long long total_chunks) {
   const int nchunk = C / 8;
   const int cpg = C / groups;
-  const float inv_n = 1.0f / ((float)cpg * (float)HW);
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total_chunks;
        i += (long long)gridDim.x * blockDim.x) {
     const int ck = (int)(i % nchunk);
@@ -148,7 +171,7 @@ __global__ void gn_bwd_apply_kernel(const bf16* __restrict__ x, const bf16* __re
       const int g = (c0 + j) / cpg;
       const long long sg = (long long)b * groups + g;
       const float mean = stats[sg * 2], rstd = stats[sg * 2 + 1];
-      const float S1 = (float)scratch[sg * 2] * inv_n, S2 = (float)scratch[sg * 2 + 1] * inv_n;
+      const float S1 = sums[sg * 2], S2 = sums[sg * 2 + 1];
       const float gmm = gamma[c0 + j];
       const float xh = ((float)xv[j] - mean) * rstd;
       float d = (float)dv[j];
@@ -162,30 +185,40 @@ __global__ void gn_bwd_apply_kernel(const bf16* __restrict__ x, const bf16* __re
   }
 }
 
-static int gn_geometry(int HW, int C, int* threads, int* ppblk, int* nblk) {
+static int gn_geometry(int HW, int C, int* threads, int* ppblk, int* nblk, size_t* lds) {
   const int nchunk = C / 8;
   if (nchunk > 1024) return -1;
   int ppb = 256 / nchunk;
   if (ppb < 1) ppb = 1;
   *threads = nchunk * ppb;
-  if (*threads < 128) *threads = 128;     // the LDS clear / final atomics need >= 2*GN_MAX_GROUPS threads
-  int per = ppb * 32;
+  int per = ppb * 64;
   if (per > HW) per = HW;
   *ppblk = per;
   *nblk = cdiv(HW, per);
+  *lds = (size_t)(*threads) * 16 * 4 + (size_t)2 * C * 4;
   return 0;
+}
+
+// scratch layout (floats): partial [B][nblk][groups][2] | sums [B][groups][2]
+size_t groupnorm_scratch_bytes(int B, int HW, int C, int groups) {
+  int threads, ppblk, nblk;
+  size_t lds;
+  if (gn_geometry(HW, C, &threads, &ppblk, &nblk, &lds)) return 0;
+  return ((size_t)B * nblk * groups * 2 + (size_t)B * groups * 2) * sizeof(float) + 256;
 }
 
 int launch_groupnorm_fwd(const bf16* x, const float* gamma, const float* beta, bf16* y, float* stats,
                          double* scratch, int B, int HW, int C, int groups, float eps, int silu, hipStream_t s) {
   SHAPECHK(C % 8 == 0 && C % groups == 0 && groups <= GN_MAX_GROUPS, "groupnorm: C=%d groups=%d", C, groups);
   int threads, ppblk, nblk;
-  SHAPECHK(gn_geometry(HW, C, &threads, &ppblk, &nblk) == 0, "groupnorm: C=%d too wide", C);
-  HIPCHK(hipMemsetAsync(scratch, 0, sizeof(double) * 2 * B * groups, s));
-  hipLaunchKernelGGL(gn_stats_kernel<0>, dim3(nblk, B), dim3(threads), 0, s, x, nullptr, nullptr, nullptr, nullptr,
-                     scratch, HW, C, groups, ppblk, 0);
-  hipLaunchKernelGGL(gn_finalize_kernel, dim3(cdiv(B * groups, 64)), dim3(64), 0, s, scratch, stats, B * groups,
-                     (double)HW * (C / groups), eps);
+  size_t lds;
+  SHAPECHK(gn_geometry(HW, C, &threads, &ppblk, &nblk, &lds) == 0, "groupnorm: C=%d too wide", C);
+  SHAPECHK(threads >= groups, "groupnorm: C=%d too narrow for %d groups", C, groups);
+  float* partial = (float*)scratch;
+  hipLaunchKernelGGL(gn_stats_kernel<0>, dim3(nblk, B), dim3(threads), lds, s, x, nullptr, nullptr, nullptr, nullptr,
+                     partial, HW, C, groups, ppblk, 0);
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(cdiv(B * groups, 64)), dim3(64), 0, s, partial, stats, B * groups,
+                     groups, nblk, (double)HW * (C / groups), eps, 0);
   const long long total = (long long)B * HW * (C / 8);
   const int grid = (int)(cdivl(total, 256) < 4096 ? cdivl(total, 256) : 4096);
   hipLaunchKernelGGL(gn_apply_kernel, dim3(grid), dim3(256), 0, s, x, gamma, beta, stats, y, HW, C, groups, silu,
@@ -199,13 +232,18 @@ int launch_groupnorm_bwd(const bf16* x, const bf16* dy, const float* gamma, cons
                          hipStream_t s) {
   SHAPECHK(C % 8 == 0 && C % groups == 0 && groups <= GN_MAX_GROUPS, "groupnorm: C=%d groups=%d", C, groups);
   int threads, ppblk, nblk;
-  SHAPECHK(gn_geometry(HW, C, &threads, &ppblk, &nblk) == 0, "groupnorm: C=%d too wide", C);
-  HIPCHK(hipMemsetAsync(scratch, 0, sizeof(double) * 2 * B * groups, s));
-  hipLaunchKernelGGL(gn_stats_kernel<1>, dim3(nblk, B), dim3(threads), 0, s, x, dy, gamma, beta, stats, scratch, HW,
+  size_t lds;
+  SHAPECHK(gn_geometry(HW, C, &threads, &ppblk, &nblk, &lds) == 0, "groupnorm: C=%d too wide", C);
+  SHAPECHK(threads >= groups, "groupnorm: C=%d too narrow for %d groups", C, groups);
+  float* partial = (float*)scratch;
+  float* sums = partial + (size_t)B * nblk * groups * 2;
+  hipLaunchKernelGGL(gn_stats_kernel<1>, dim3(nblk, B), dim3(threads), lds, s, x, dy, gamma, beta, stats, partial, HW,
                      C, groups, ppblk, silu);
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(cdiv(B * groups, 64)), dim3(64), 0, s, partial, sums, B * groups, groups,
+                     nblk, (double)HW * (C / groups), 0.f, 1);
   const long long total = (long long)B * HW * (C / 8);
   const int grid = (int)(cdivl(total, 256) < 4096 ? cdivl(total, 256) : 4096);
-  hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(grid), dim3(256), 0, s, x, dy, gamma, beta, stats, scratch, dx, HW, C,
+  hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(grid), dim3(256), 0, s, x, dy, gamma, beta, stats, sums, dx, HW, C,
                      groups, silu, accum, total);
   HIPCHK(hipGetLastError());
   return PEA_OK;
@@ -306,10 +344,6 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16* __restrict__ x,
         float r = rstd * (dyv * gamma[ck * 8 + j] - s1 - xh * s2);
         if (accum) r += (float)o[j];
         o[j] = (bf16)r;
-        if (dgamma) {
-          atomicAdd(&dgamma[ck * 8 + j], dyv * xh);
-          atomicAdd(&dbeta[ck * 8 + j], dyv);
-        }
       }
       *(bf16x8*)(dx + (long long)row * C + ck * 8) = o;
     }
@@ -324,11 +358,30 @@ int launch_layernorm_fwd(const bf16* x, const float* gamma, const float* beta, b
   return PEA_OK;
 }
 
+// dgamma[c] += sum_r dy[r][c] * xhat[r][c]; dbeta[c] += sum_r dy[r][c]; one thread per column, rows in
+// order (deterministic; only the adapter's LayerNorm has trainable affine parameters, R = 2*B*L rows)
+__global__ void ln_param_grad_kernel(const bf16* __restrict__ x, const bf16* __restrict__ dy,
+                                     const float* __restrict__ stats, float* __restrict__ dgamma,
+                                     float* __restrict__ dbeta, int R, int C) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float g = 0.f, b = 0.f;
+  for (int r = 0; r < R; ++r) {
+    const float d = (float)dy[(long long)r * C + c];
+    g += d * ((float)x[(long long)r * C + c] - stats[2 * r]) * stats[2 * r + 1];
+    b += d;
+  }
+  dgamma[c] += g;
+  dbeta[c] += b;
+}
+
 int launch_layernorm_bwd(const bf16* x, const bf16* dy, const float* gamma, const float* stats, bf16* dx,
                          float* dgamma, float* dbeta, int R, int C, int accum, hipStream_t s) {
   SHAPECHK(C % 8 == 0 && C <= 64 * 8 * LN_MAXCH, "layernorm: C=%d unsupported", C);
-  hipLaunchKernelGGL(ln_bwd_kernel, dim3(cdiv(R, 4)), dim3(256), 0, s, x, dy, gamma, stats, dx, dgamma, dbeta, R, C,
-                     accum);
+  if (dx)
+    hipLaunchKernelGGL(ln_bwd_kernel, dim3(cdiv(R, 4)), dim3(256), 0, s, x, dy, gamma, stats, dx, dgamma, dbeta, R, C,
+                       accum);
+  if (dgamma) hipLaunchKernelGGL(ln_param_grad_kernel, dim3(cdiv(C, 64)), dim3(64), 0, s, x, dy, stats, dgamma, dbeta, R, C);
   HIPCHK(hipGetLastError());
   return PEA_OK;
 }

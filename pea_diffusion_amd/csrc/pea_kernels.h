@@ -142,7 +142,10 @@ struct KdLossP {
 int launch_kd_loss(const KdLossP& p, hipStream_t s);
 
 // late additions (elementwise.hip)
-int launch_colsum_batched(const bf16* x, float* out, int B, int HW, int C, int ldo, hipStream_t s);
+int launch_colsum_batched(const bf16* x, float* out, int B, int HW, int C, int ldo, float* scratch, hipStream_t s);
+size_t colsum_batched_scratch_bytes(int B, int HW, int C);
+size_t groupnorm_scratch_bytes(int B, int HW, int C, int groups);
+size_t kd_loss_workspace_bytes(int ntaps, const long long* per, long long per_eps, int B);
 int launch_accum(const bf16* x, bf16* y, long long n, int accum, hipStream_t s);
 int launch_copy2d(const bf16* x, int ldx, bf16* y, int ldy, long long rows, int C, int accum, hipStream_t s);
 int launch_cast_i64_f32(const long long* x, float* y, long long n, hipStream_t s);

@@ -89,7 +89,7 @@ def groupnorm_fwd(x, gamma, beta, groups=32, eps=1e-5, silu=False):
     B, HW, C = x.shape
     y = torch.empty_like(x)
     stats = torch.empty(B, groups, 2, device=x.device, dtype=torch.float32)
-    scratch = torch.empty(B * groups * 2, device=x.device, dtype=torch.float64)
+    scratch = torch.empty(lib().pea_op_groupnorm_scratch_bytes(B, HW, C, groups), device=x.device, dtype=torch.uint8)
     check(lib().pea_op_groupnorm_fwd(ptr(x), ptr(gamma), ptr(beta), ptr(y), ptr(stats), ptr(scratch), B, HW, C, groups,
                                      eps, int(silu), stream_ptr()))
     return y, stats
@@ -98,7 +98,7 @@ def groupnorm_fwd(x, gamma, beta, groups=32, eps=1e-5, silu=False):
 def groupnorm_bwd(x, dy, gamma, beta, stats, groups=32, silu=False, accum_into=None):
     B, HW, C = x.shape
     dx = accum_into if accum_into is not None else torch.empty_like(x)
-    scratch = torch.empty(B * groups * 2, device=x.device, dtype=torch.float64)
+    scratch = torch.empty(lib().pea_op_groupnorm_scratch_bytes(B, HW, C, groups), device=x.device, dtype=torch.uint8)
     check(lib().pea_op_groupnorm_bwd(ptr(x), ptr(dy), ptr(gamma), ptr(beta), ptr(stats), ptr(dx), ptr(scratch), B, HW,
                                      C, groups, int(silu), int(accum_into is not None), stream_ptr()))
     return dx
@@ -192,7 +192,7 @@ def kd_loss(taps_s: Sequence[torch.Tensor], taps_t: Sequence[torch.Tensor], eps_
     a_d = arr(*[t.data_ptr() for t in dt]) if want_grads else None
     per = (ctypes.c_longlong * max(n, 1))(*[t[0].numel() for t in taps_s])
     losses = torch.empty(4, device=dev, dtype=torch.float32)
-    ws = torch.empty(64, device=dev, dtype=torch.float64)
+    ws = torch.empty(lib().pea_op_kd_loss_workspace_bytes(n, per, eps_s[0].numel(), B), device=dev, dtype=torch.uint8)
     check(lib().pea_op_kd_loss(n, a_s, a_t, a_d, per, ptr(eps_s), ptr(eps), ptr(eps_t), ptr(de), eps_s[0].numel(),
                                ptr(zh), B, feat_weight, int(nan_guard), grad_scale, ptr(losses), ptr(ws),
                                stream_ptr()))

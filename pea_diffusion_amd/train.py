@@ -87,7 +87,8 @@ class PEATrainer:
             self.all_reduce_grads()
         for p, o in zip(self.adapter._plist(), self.adapter._offsets):
             p.grad = self.adapter.flat_grad[o:o + p.numel()].view_as(p)
-        out = {k: self.losses[i] for i, k in enumerate(self.LOG_KEYS)}
+        snap = self.losses.clone()          # device-side snapshot: later steps overwrite self.losses
+        out = {k: snap[i] for i, k in enumerate(self.LOG_KEYS)}
         if sync:
             torch.cuda.synchronize()
         return out
