@@ -1,0 +1,218 @@
+#!/usr/bin/env python3
+"""bench.py -- PEA-Diffusion KD training step on MI355X (BASELINE.json metric).
+
+`python bench.py --gpus N --steps K --warmup W` ; for N>1 launched by torch.distributed.run with one
+rank per GPU.  A step = one pass of the hot path over one synthetic batch already resident in HBM:
+add_noise -> adapter (cond|uncond) -> student SDXL UNet fwd (taps) -> teacher SDXL UNet fwd -> fused KD
+loss -> student data-gradient backward -> adapter backward [-> ONE RCCL all-reduce of the flat adapter
+gradient when N>1] -> fused AdamW.  Weak scaling: the per-GPU batch is fixed (BASELINE configs[1]:
+SDXL 1024x1024 bf16, batch 4 per GPU); ranks share nothing but the adapter-gradient all-reduce.
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+TFLOP_PER_IMAGE = {"sdxl": 20.31, "tiny": None}      # 3 x 6.765 + adapter
+MFMA_PEAK_TFLOPS = 2500.0                            # MI355X dense bf16 (MI355X_MICROARCH.md)
+HBM_PEAK_GBS = 8000.0
+
+
+def synthetic_batch(cfg, B, L, enc_dim, hw, device, seed):
+    """post-encoder synthetic batch; generated on the device, resident before timing"""
+    g = torch.Generator(device=device).manual_seed(seed)
+    r = lambda *s: torch.randn(*s, generator=g, device=device)
+    zh = torch.zeros(B, dtype=torch.int64, device=device)
+    zh[: max(1, B // 2)] = 1                                      # half native captions, half translated
+    pm = torch.zeros(B, dtype=torch.uint8, device=device)
+    pm[B - 1] = 1                                                 # one CFG-dropped sample (p = 0.1 in the reference)
+    px = hw * 8
+    return dict(latents=r(B, 4, hw, hw), noise=r(B, 4, hw, hw) + 0.5 * r(B, 4, 1, 1),
+                timesteps=torch.randint(0, 1000, (B,), generator=g, device=device),
+                enc=r(B, L, enc_dim), enc_uncond=r(1, L, enc_dim).repeat(B, 1, 1).contiguous(),
+                prompt_mask=pm, zh_or_not=zh, teacher_ehs=r(B, 77, cfg.cross_attention_dim),
+                teacher_neg=r(1, 77, cfg.cross_attention_dim).repeat(B, 1, 1).contiguous(),
+                teacher_pooled=r(B, cfg.pooled_dim),
+                time_ids=torch.tensor([[px, px, 0, 0, px, px]] * B, dtype=torch.float32, device=device))
+
+
+def cpu_baseline(model_name, budget_s):
+    """The CPU oracle (oracle/*.py, the restatement of the reference's PyTorch path) timed on this box's
+    host cores: one KD step at batch 1 (teacher fwd no_grad + student fwd + adapter-only backward)."""
+    from oracle.step_ref import AdapterRef, synthetic_batch as sb, training_step_ref
+    from oracle.unet_ref import UNet2DConditionRef, cast_hook_ref, sdxl_config, tiny_config
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    cfg = sdxl_config() if model_name == "sdxl" else tiny_config()
+    t0 = time.time()
+    with torch.no_grad():
+        unet = UNet2DConditionRef(cfg)          # teacher == student checkpoint (train_sdxl_zh.py:138,151)
+    for p in unet.parameters():
+        p.requires_grad_(False)
+    enc_dim = 1024 if model_name == "sdxl" else 128
+    ad = AdapterRef(enc_dim, cfg.pooled_dim, 1024 if model_name == "sdxl" else 192, cfg.cross_attention_dim, False)
+    build_s = time.time() - t0
+    best = None
+    for hw in ([64, 128] if model_name == "sdxl" else [16]):
+        batch = sb(cfg, 1, L=77, enc_dim=enc_dim, seed=0, latent_hw=hw)
+        t1 = time.time()
+        out = training_step_ref(ad, unet, unet, batch, cast_hook_ref)
+        out["loss"].backward()
+        dt = time.time() - t1
+        best = (hw, dt)
+        if dt * 4.5 > budget_s:                 # the next resolution costs ~4-5x more
+            break
+    hw, dt = best
+    return {"value": round(1.0 / dt, 5), "unit": "images/s", "cores": cores, "kind": "port",
+            "sample": f"1 KD step, batch 1, {hw * 8}x{hw * 8} px (latent {hw}x{hw}), fp32 torch CPU oracle, "
+                      f"teacher==student weights, {dt:.1f} s (model build {build_s:.0f} s not counted)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=4, help="per-GPU batch (BASELINE configs[1]: 4)")
+    ap.add_argument("--model", default="sdxl", choices=["sdxl", "tiny"])
+    ap.add_argument("--latent", type=int, default=0, help="latent side (default: model sample_size, 128 = 1024 px)")
+    ap.add_argument("--ctx", type=int, default=77, help="student context length (77; cn_clip default is 52)")
+    ap.add_argument("--hidden", type=int, default=1024, help="adapter hidden dim (1024 = the 6M-param adapter)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-budget", type=float, default=45.0)
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--breakdown", action="store_true", help="print the per-kernel-family table to stderr")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    dev = torch.device("cuda", local_rank if world > 1 else 0)
+    torch.cuda.set_device(dev)
+
+    from pea_diffusion_amd import config as pc
+    from pea_diffusion_amd._lib import lib
+    from pea_diffusion_amd.adapter import PEAAdapter
+    from pea_diffusion_amd.train import PEATrainer
+    from pea_diffusion_amd.unet import HipUNet
+
+    cfg = pc.sdxl_config() if args.model == "sdxl" else pc.tiny_config()
+    hw = args.latent or cfg.sample_size
+    B = args.batch
+    enc_dim = 1024 if args.model == "sdxl" else 128
+    hidden = args.hidden if args.model == "sdxl" else 192
+    student = HipUNet(cfg, B, hw, hw, args.ctx, needs_grad=True)
+    student.init_random(seed=7)
+    teacher = HipUNet(cfg, B, hw, hw, 77, needs_grad=False, share_weights_from=student)
+    torch.manual_seed(7)
+    adapter = PEAAdapter(enc_dim, cfg.pooled_dim, hidden, cfg.cross_attention_dim, False).to(dev)
+    trainer = PEATrainer(adapter, student, teacher)
+    batch = synthetic_batch(cfg, B, args.ctx, enc_dim, hw, dev, seed=100 + rank)
+
+    def step():
+        trainer.training_step(batch)          # includes the all-reduce of the flat adapter grad when world > 1
+        trainer.optimizer_step()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    ms = dt / args.steps * 1e3
+    ips = world * B * args.steps / dt
+    loss = float(trainer.losses[0])
+
+    roof = None
+    if not args.no_roofline and rank == 0:
+        L = lib()
+        L.pea_prof_reset()
+        L.pea_prof_enable(1)
+        for _ in range(min(args.steps, 3)):
+            step()
+        torch.cuda.synchronize()
+        L.pea_prof_enable(0)
+        fams = []
+        for f in range(8):
+            t, fl, by, n = ctypes.c_double(), ctypes.c_double(), ctypes.c_double(), ctypes.c_longlong()
+            L.pea_prof_report(f, ctypes.byref(t), ctypes.byref(fl), ctypes.byref(by), ctypes.byref(n))
+            fams.append(dict(name=L.pea_prof_family_name(f).decode(), ms=t.value, flops=fl.value, bytes=by.value,
+                             launches=n.value))
+        L.pea_prof_reset()
+        nprof = min(args.steps, 3)
+        gem = [fams[0], fams[1]]
+        g_ms = sum(x["ms"] for x in gem)
+        g_fl = sum(x["flops"] for x in gem)
+        g_n = sum(x["launches"] for x in gem)
+        ach = g_fl / (g_ms * 1e-3) / 1e12 if g_ms > 0 else 0.0
+        roof = {"bound": "mfma", "kernel": "gemm_bf16_kernel (plain + implicit-GEMM conv3x3)",
+                "achieved": round(ach, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(ach / MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                "launches_per_step": g_n // nprof, "avg_launch_us": round(g_ms * 1e3 / max(g_n, 1), 2),
+                "gflop_per_launch": round(g_fl / max(g_n, 1) / 1e9, 3),
+                "share_of_step_time": round(g_ms / nprof / ms, 3),
+                "method": "hip events around every launch on the launch stream, instrumented replay of the timed steps"}
+        if args.breakdown:
+            tot = sum(x["ms"] for x in fams)
+            for x in fams:
+                tf = x["flops"] / (x["ms"] * 1e-3) / 1e12 if x["ms"] > 0 else 0
+                gb = x["bytes"] / (x["ms"] * 1e-3) / 1e9 if x["ms"] > 0 else 0
+                print(f"  {x['name']:28s} {x['ms'] / nprof:9.2f} ms/step {x['launches'] // nprof:6d} launches "
+                      f"{tf:8.1f} TFLOP/s {gb:8.0f} GB/s(alg)", file=sys.stderr)
+            print(f"  instrumented families total {tot / nprof:.2f} ms/step vs timed step {ms:.2f} ms", file=sys.stderr)
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(args.model, args.cpu_budget)
+
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        mem = student.memory()
+        out = {
+            "metric": "training images/sec (SDXL 1024px bf16, adapter-only bwd)", "value": round(ips, 4),
+            "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": f"{args.model.upper()} {hw * 8}x{hw * 8} KD training step (teacher fwd + student "
+                                   f"fwd + student dgrad bwd + adapter fwd/bwd + AdamW), per-GPU batch {B}",
+                       "global_batch": world * B, "per_gpu_batch": B, "latent": hw, "ctx_len": args.ctx,
+                       "adapter": f"MLP({enc_dim},{cfg.pooled_dim},{hidden},{cfg.cross_attention_dim})",
+                       "parallelism": f"dp{world}", "weights": "random init (teacher == student checkpoint)",
+                       "loss": round(loss, 6)},
+            "tflop_per_image": TFLOP_PER_IMAGE.get(args.model),
+            "achieved_tflops_per_gpu": (round(ips / world * TFLOP_PER_IMAGE[args.model], 1)
+                                        if TFLOP_PER_IMAGE.get(args.model) else None),
+            "hbm_resident_gb": round((mem["weight_bytes"] + 2 * mem["activation_bytes"] + mem["grad_bytes"]) / 2 ** 30, 1),
+            "roofline": roof, "cpu_baseline": cpu,
+        }
+        print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

@@ -207,6 +207,14 @@ int pea_train_step(void* tr, const float* latents, const float* noise, const lon
 /* intermediate results of the last step (fp32 NCHW [B][4][H][W]): which 0 = x_t, 1 = eps_student, 2 = eps_teacher */
 int pea_trainer_export(void* tr, int which, float* out, void* stream);
 
+/* per-launch HIP-event timing by kernel family (bench.py roofline leg); families 0..7:
+ * gemm<plain>, gemm<conv3x3>, attn_fwd, attn_bwd, groupnorm, layernorm, elementwise, kd_loss.
+ * pea_prof_report synchronises the device.                                                       */
+void pea_prof_enable(int on);
+void pea_prof_reset(void);
+const char* pea_prof_family_name(int fam);
+int pea_prof_report(int fam, double* ms, double* flops, double* bytes, long long* launches);
+
 /* debugging aid for the parity tests: 1 = ds_read_b64_tr_b16 transpose reads (default), 0 = scalar gathers */
 void pea_debug_set_attn_tr(int v);
 

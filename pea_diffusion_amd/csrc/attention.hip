@@ -404,10 +404,12 @@ int launch_attention_fwd(const AttnP& p, hipStream_t s) {
   if (rc) return rc;
   SHAPECHK(p.ldo % 4 == 0, "attention: ldo %% 4");
   const dim3 grid(cdiv(p.Sq, 128), p.H, p.B);
+  PROF_BEGIN(2, 4.0 * p.B * p.H * (double)p.Sq * p.Skv * 64, 2.0 * p.B * p.H * 64 * (2.0 * p.Sq + 2.0 * p.Skv), s);
   if (g_attn_use_tr)
     hipLaunchKernelGGL((attn_q_kernel<0, true>), grid, dim3(256), 4 * TILE_BYTES, s, p);
   else
     hipLaunchKernelGGL((attn_q_kernel<0, false>), grid, dim3(256), 4 * TILE_BYTES, s, p);
+  PROF_END(s);
   HIPCHK(hipGetLastError());
   return PEA_OK;
 }
@@ -417,6 +419,8 @@ int launch_attention_bwd(const AttnP& p, hipStream_t s) {
   if (rc) return rc;
   SHAPECHK(p.lse && p.delta && p.dO && p.O, "attention bwd: lse/delta/dO/O required");
   const long long total = (long long)p.B * p.Sq * p.H * 8;
+  // algorithmic: 5 products (S, dP, dV, dK, dQ) = 10*B*H*Sq*Skv*64 flops (the two-kernel form recomputes S and dP)
+  PROF_BEGIN(3, 10.0 * p.B * p.H * (double)p.Sq * p.Skv * 64, 2.0 * p.B * p.H * 64 * (4.0 * p.Sq + 4.0 * p.Skv), s);
   hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)cdivl(total, 256)), dim3(256), 0, s, p);
   if (p.dQ) {
     const dim3 grid(cdiv(p.Sq, 128), p.H, p.B);
@@ -432,6 +436,7 @@ int launch_attention_bwd(const AttnP& p, hipStream_t s) {
     else
       hipLaunchKernelGGL((attn_dkv_kernel<false>), grid, dim3(256), 4 * TILE_BYTES, s, p);
   }
+  PROF_END(s);
   HIPCHK(hipGetLastError());
   return PEA_OK;
 }

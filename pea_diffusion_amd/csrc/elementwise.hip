@@ -50,13 +50,17 @@ __global__ void geglu_bwd_kernel(const bf16* __restrict__ hg, const bf16* __rest
 }
 int launch_geglu_fwd(const bf16* hg, bf16* y, long long rows, int inner, hipStream_t s) {
   SHAPECHK(inner % 8 == 0, "geglu: inner %% 8");
+  PROF_BEGIN(6, 0.0, 2.0 * 3.0 * rows * inner, s);
   hipLaunchKernelGGL(geglu_fwd_kernel, dim3(EW_GRID(rows * (inner / 8))), dim3(256), 0, s, hg, y, rows, inner);
+  PROF_END(s);
   HIPCHK(hipGetLastError());
   return PEA_OK;
 }
 int launch_geglu_bwd(const bf16* hg, const bf16* dy, bf16* dhg, long long rows, int inner, hipStream_t s) {
   SHAPECHK(inner % 8 == 0, "geglu: inner %% 8");
+  PROF_BEGIN(6, 0.0, 2.0 * 5.0 * rows * inner, s);
   hipLaunchKernelGGL(geglu_bwd_kernel, dim3(EW_GRID(rows * (inner / 8))), dim3(256), 0, s, hg, dy, dhg, rows, inner);
+  PROF_END(s);
   HIPCHK(hipGetLastError());
   return PEA_OK;
 }
@@ -133,15 +137,19 @@ __global__ void split2_kernel(const bf16* __restrict__ dy, int C1, int C2, bf16*
 }
 int launch_concat2(const bf16* a, int C1, const bf16* b, int C2, bf16* y, long long rows, hipStream_t s) {
   SHAPECHK(C1 % 8 == 0 && C2 % 8 == 0, "concat: C %% 8");
+  PROF_BEGIN(6, 0.0, 4.0 * rows * (C1 + C2), s);
   hipLaunchKernelGGL(concat2_kernel, dim3(EW_GRID(rows * ((C1 + C2) / 8))), dim3(256), 0, s, a, C1, b, C2, y, rows);
+  PROF_END(s);
   HIPCHK(hipGetLastError());
   return PEA_OK;
 }
 int launch_split2(const bf16* dy, int C1, int C2, bf16* da, int accum_a, bf16* db, int accum_b, long long rows,
                   hipStream_t s) {
   SHAPECHK(C1 % 8 == 0 && C2 % 8 == 0, "split: C %% 8");
+  PROF_BEGIN(6, 0.0, 4.0 * rows * (C1 + C2), s);
   hipLaunchKernelGGL(split2_kernel, dim3(EW_GRID(rows * ((C1 + C2) / 8))), dim3(256), 0, s, dy, C1, C2, da, accum_a,
                      db, accum_b, rows);
+  PROF_END(s);
   HIPCHK(hipGetLastError());
   return PEA_OK;
 }
@@ -173,8 +181,10 @@ __global__ void sumpool2_kernel(const bf16* __restrict__ x, bf16* __restrict__ y
 }
 int launch_sumpool2(const bf16* x, bf16* y, int B, int H, int W, int C, int accum, hipStream_t s) {
   SHAPECHK(C % 8 == 0, "sumpool: C %% 8");
+  PROF_BEGIN(6, 0.0, 2.0 * 5.0 * B * H * W * C, s);
   hipLaunchKernelGGL(sumpool2_kernel, dim3(EW_GRID((long long)B * H * W * (C / 8))), dim3(256), 0, s, x, y, B, H, W,
                      C, accum);
+  PROF_END(s);
   HIPCHK(hipGetLastError());
   return PEA_OK;
 }
@@ -486,9 +496,11 @@ int launch_colsum_batched(const bf16* x, float* out, int B, int HW, int C, int l
   int threads, per, nblk;
   colsum_geometry(HW, C, &threads, &per, &nblk);
   const int ppb = threads / (C / 8);
+  PROF_BEGIN(6, 0.0, 2.0 * B * (double)HW * C, s);
   hipLaunchKernelGGL(colsum_batched_kernel, dim3(nblk, B), dim3(threads), (size_t)ppb * C * 4, s, x, scratch, HW, C,
                      per);
   hipLaunchKernelGGL(colsum_batched_reduce_kernel, dim3(cdiv(C, 64), B), dim3(64), 0, s, scratch, out, nblk, C, ldo);
+  PROF_END(s);
   HIPCHK(hipGetLastError());
   return PEA_OK;
 }
@@ -507,7 +519,9 @@ __global__ void accum_kernel(const bf16* __restrict__ x, bf16* __restrict__ y, l
 }
 int launch_accum(const bf16* x, bf16* y, long long n, int accum, hipStream_t s) {
   SHAPECHK(n % 8 == 0, "accum: n %% 8");
+  PROF_BEGIN(6, 0.0, 2.0 * 3.0 * n, s);
   hipLaunchKernelGGL(accum_kernel, dim3(EW_GRID(n / 8)), dim3(256), 0, s, x, y, n / 8, accum);
+  PROF_END(s);
   HIPCHK(hipGetLastError());
   return PEA_OK;
 }

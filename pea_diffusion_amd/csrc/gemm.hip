@@ -237,10 +237,17 @@ int launch_gemm(const GemmP& p, hipStream_t stream) {
     attr_set = true;
   }
   const int grid = cdiv(p.M, BM) * cdiv(p.N, BN);
+  {
+    // algorithmic work: 2*M*N*K; a transposed (zero-stuffed) conv only has 1/4 of its taps real
+    double fl = 2.0 * p.M * (double)p.N * p.K * (p.parity ? 0.25 : 1.0);
+    double by = 2.0 * ((double)p.M * p.N + (double)p.N * p.K + (p.mode ? (double)p.M * p.K / 9.0 : (double)p.M * p.K));
+    PROF_BEGIN(p.mode ? 1 : 0, fl, by, stream);
+  }
   if (p.mode == 0)
     hipLaunchKernelGGL(gemm_bf16_kernel<0>, dim3(grid), dim3(256), 2 * STAGE_BYTES, stream, p);
   else
     hipLaunchKernelGGL(gemm_bf16_kernel<1>, dim3(grid), dim3(256), 2 * STAGE_BYTES, stream, p);
+  PROF_END(stream);
   HIPCHK(hipGetLastError());
   return PEA_OK;
 }

@@ -168,10 +168,17 @@ int launch_kd_loss(const KdLossP& p, hipStream_t s) {
   // workspace: int skip[PEA_MAX_TAPS] | float partial[nblocks][2]   (kd_loss_workspace_bytes)
   int* skip = (int*)p.partial;
   float* partial = (float*)(skip + PEA_MAX_TAPS);
+  {
+    double by = 0;
+    for (int k = 0; k < p.ntaps; ++k) by += 3.0 * 2.0 * p.B * (double)p.per[k];     // 2 reads + 1 write, bf16
+    by += 4.0 * 4.0 * p.B * (double)p.per_eps;
+    PROF_BEGIN(7, 0.0, by, s);
+  }
   hipLaunchKernelGGL(kd_loss_kernel, dim3((unsigned)blk), dim3(256), 0, s, p, segs, partial);
   hipLaunchKernelGGL(kd_finish_kernel, dim3(1), dim3(256), 0, s, p, segs, partial, p.losses, skip);
   if (p.nan_guard && p.ntaps > 0)
     hipLaunchKernelGGL(kd_zero_skipped_kernel, dim3(256, p.ntaps), dim3(256), 0, s, p, skip);
+  PROF_END(s);
   HIPCHK(hipGetLastError());
   return PEA_OK;
 }

@@ -215,6 +215,7 @@ int launch_groupnorm_fwd(const bf16* x, const float* gamma, const float* beta, b
   SHAPECHK(gn_geometry(HW, C, &threads, &ppblk, &nblk, &lds) == 0, "groupnorm: C=%d too wide", C);
   SHAPECHK(threads >= groups, "groupnorm: C=%d too narrow for %d groups", C, groups);
   float* partial = (float*)scratch;
+  PROF_BEGIN(4, 0.0, 2.0 * 3.0 * B * (double)HW * C, s);
   hipLaunchKernelGGL(gn_stats_kernel<0>, dim3(nblk, B), dim3(threads), lds, s, x, nullptr, nullptr, nullptr, nullptr,
                      partial, HW, C, groups, ppblk, 0);
   hipLaunchKernelGGL(gn_finalize_kernel, dim3(cdiv(B * groups, 64)), dim3(64), 0, s, partial, stats, B * groups,
@@ -223,6 +224,7 @@ int launch_groupnorm_fwd(const bf16* x, const float* gamma, const float* beta, b
   const int grid = (int)(cdivl(total, 256) < 4096 ? cdivl(total, 256) : 4096);
   hipLaunchKernelGGL(gn_apply_kernel, dim3(grid), dim3(256), 0, s, x, gamma, beta, stats, y, HW, C, groups, silu,
                      total);
+  PROF_END(s);
   HIPCHK(hipGetLastError());
   return PEA_OK;
 }
@@ -237,6 +239,7 @@ int launch_groupnorm_bwd(const bf16* x, const bf16* dy, const float* gamma, cons
   SHAPECHK(threads >= groups, "groupnorm: C=%d too narrow for %d groups", C, groups);
   float* partial = (float*)scratch;
   float* sums = partial + (size_t)B * nblk * groups * 2;
+  PROF_BEGIN(4, 0.0, 2.0 * 5.0 * B * (double)HW * C, s);
   hipLaunchKernelGGL(gn_stats_kernel<1>, dim3(nblk, B), dim3(threads), lds, s, x, dy, gamma, beta, stats, partial, HW,
                      C, groups, ppblk, silu);
   hipLaunchKernelGGL(gn_finalize_kernel, dim3(cdiv(B * groups, 64)), dim3(64), 0, s, partial, sums, B * groups, groups,
@@ -245,6 +248,7 @@ int launch_groupnorm_bwd(const bf16* x, const bf16* dy, const float* gamma, cons
   const int grid = (int)(cdivl(total, 256) < 4096 ? cdivl(total, 256) : 4096);
   hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(grid), dim3(256), 0, s, x, dy, gamma, beta, stats, sums, dx, HW, C,
                      groups, silu, accum, total);
+  PROF_END(s);
   HIPCHK(hipGetLastError());
   return PEA_OK;
 }
@@ -353,7 +357,9 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16* __restrict__ x,
 int launch_layernorm_fwd(const bf16* x, const float* gamma, const float* beta, bf16* y, float* stats, int R, int C,
                          float eps, hipStream_t s) {
   SHAPECHK(C % 8 == 0 && C <= 64 * 8 * LN_MAXCH, "layernorm: C=%d unsupported", C);
+  PROF_BEGIN(5, 0.0, 4.0 * R * (double)C, s);
   hipLaunchKernelGGL(ln_fwd_kernel, dim3(cdiv(R, 4)), dim3(256), 0, s, x, gamma, beta, y, stats, R, C, eps);
+  PROF_END(s);
   HIPCHK(hipGetLastError());
   return PEA_OK;
 }
@@ -378,10 +384,12 @@ __global__ void ln_param_grad_kernel(const bf16* __restrict__ x, const bf16* __r
 int launch_layernorm_bwd(const bf16* x, const bf16* dy, const float* gamma, const float* stats, bf16* dx,
                          float* dgamma, float* dbeta, int R, int C, int accum, hipStream_t s) {
   SHAPECHK(C % 8 == 0 && C <= 64 * 8 * LN_MAXCH, "layernorm: C=%d unsupported", C);
+  PROF_BEGIN(5, 0.0, 6.0 * R * (double)C, s);
   if (dx)
     hipLaunchKernelGGL(ln_bwd_kernel, dim3(cdiv(R, 4)), dim3(256), 0, s, x, dy, gamma, stats, dx, dgamma, dbeta, R, C,
                        accum);
   if (dgamma) hipLaunchKernelGGL(ln_param_grad_kernel, dim3(cdiv(C, 64)), dim3(64), 0, s, x, dy, stats, dgamma, dbeta, R, C);
+  PROF_END(s);
   HIPCHK(hipGetLastError());
   return PEA_OK;
 }

@@ -149,3 +149,11 @@ size_t kd_loss_workspace_bytes(int ntaps, const long long* per, long long per_ep
 int launch_accum(const bf16* x, bf16* y, long long n, int accum, hipStream_t s);
 int launch_copy2d(const bf16* x, int ldx, bf16* y, int ldy, long long rows, int C, int accum, hipStream_t s);
 int launch_cast_i64_f32(const long long* x, float* y, long long n, hipStream_t s);
+
+// ---------------------------------------------------------------- prof.hip
+#define PEA_PROF_FAMILIES 8
+extern int g_prof_on;
+void prof_begin_impl(int fam, double flops, double bytes, hipStream_t s);
+void prof_end_impl(hipStream_t s);
+#define PROF_BEGIN(fam, flops, bytes, s) do { if (g_prof_on) prof_begin_impl(fam, flops, bytes, s); } while (0)
+#define PROF_END(s) do { if (g_prof_on) prof_end_impl(s); } while (0)
