@@ -11,6 +11,7 @@ from typing import Dict, Optional
 
 import torch
 
+from . import dist as pdist
 from . import ops
 from ._lib import PeaError, check, lib, ptr, stream_ptr
 from .adapter import PEAAdapter
@@ -96,17 +97,10 @@ class PEATrainer:
     # ---- data parallel: ONE all-reduce over the flat adapter-grad buffer (24-46 MB), averaged
     @property
     def world_size(self) -> int:
-        import torch.distributed as dist
-        return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        return pdist.world_size()
 
     def all_reduce_grads(self, async_op: bool = False):
-        import torch.distributed as dist
-        g = self.adapter.flat_grad
-        work = dist.all_reduce(g, op=dist.ReduceOp.SUM, async_op=async_op)
-        if async_op:
-            return work
-        g.div_(self.world_size)
-        return None
+        return pdist.allreduce_mean_(self.adapter.flat_grad, async_op=async_op)
 
     def export(self, which: str) -> torch.Tensor:
         idx = {"x_t": 0, "eps_student": 1, "eps_teacher": 2}[which]
