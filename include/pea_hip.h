@@ -113,6 +113,9 @@ int pea_op_kd_loss(int ntaps, const void* const* taps_s, const void* const* taps
                    long long per_eps, const long long* zh, int B, float feat_weight, int nan_guard,
                    float grad_scale, float* losses, void* workspace, void* stream);
 
+/* touch `bytes` of a read-only buffer so it becomes resident in the Infinity Cache (side-stream prefetch) */
+int pea_op_prefetch(const void* p, long long bytes, void* stream);
+
 /* fused AdamW over a flat fp32 buffer (DeepSpeed FusedAdam(adam_w_mode=True), utils/model_utils.py:64-67) */
 int pea_op_adamw(float* w, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2,
                  float eps, float weight_decay, int step, float grad_scale, void* stream);
@@ -217,6 +220,8 @@ int pea_prof_report(int fam, double* ms, double* flops, double* bytes, long long
 
 /* debugging aid for the parity tests: 1 = ds_read_b64_tr_b16 transpose reads (default), 0 = scalar gathers */
 void pea_debug_set_attn_tr(int v);
+/* benchmark aid: force GEMM tile variant (>= 0) or restore the shape-based choice (-1) */
+void pea_debug_set_gemm_variant(int v);
 
 #ifdef __cplusplus
 }

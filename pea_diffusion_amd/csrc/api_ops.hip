@@ -185,6 +185,10 @@ long long pea_op_kd_loss_workspace_bytes(int ntaps, const long long* per, long l
   return (long long)kd_loss_workspace_bytes(ntaps, per, per_eps, B);
 }
 
+int pea_op_prefetch(const void* p, long long bytes, void* stream) {
+  return launch_prefetch(p, bytes, nullptr, (hipStream_t)stream);
+}
+
 int pea_op_adamw(float* w, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2,
                  float eps, float weight_decay, int step, float grad_scale, void* stream) {
   return launch_adamw(w, g, m, v, n, lr, beta1, beta2, eps, weight_decay, step, grad_scale, (hipStream_t)stream);

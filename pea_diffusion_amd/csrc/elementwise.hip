@@ -556,3 +556,24 @@ int launch_cast_i64_f32(const long long* x, float* y, long long n, hipStream_t s
   HIPCHK(hipGetLastError());
   return PEA_OK;
 }
+
+// ---- software prefetch of a read-only buffer into the 256 MiB Infinity Cache / L2 (side stream):
+// the frozen UNet weights are streamed once per pass, so a GEMM's first touch of its weight tile is an
+// HBM miss; touching the NEXT op's weights while the current op computes turns those misses into
+// on-die hits.  Reads 16 B per lane, keeps the value alive without storing it.
+__global__ void prefetch_kernel(const uint4* __restrict__ p, long long n16, int* sink) {
+  unsigned acc = 0;
+  EW_LOOP(i, n16) {
+    const uint4 v = p[i];
+    acc ^= v.x ^ v.y ^ v.z ^ v.w;
+  }
+  if (acc == 0x9E3779B9u && sink) *sink = 1;      // practically never; defeats dead-code elimination
+}
+int launch_prefetch(const void* p, long long bytes, int* sink, hipStream_t s) {
+  const long long n16 = bytes / 16;
+  if (n16 <= 0) return PEA_OK;
+  int grid = (int)(cdivl(n16, 256 * 4) < 512 ? cdivl(n16, 256 * 4) : 512);
+  hipLaunchKernelGGL(prefetch_kernel, dim3(grid), dim3(256), 0, s, (const uint4*)p, n16, sink);
+  HIPCHK(hipGetLastError());
+  return PEA_OK;
+}

@@ -16,21 +16,41 @@
 // per N-tile so the 64 tiles resident on one XCD share operand panels.
 #include "pea_kernels.h"
 
-#define BM 128
-#define BN 128
 #define BK 64
-#define STAGE_BYTES (BM * BK * 2 + BN * BK * 2)   // 32 KiB
-#define A_BYTES (BM * BK * 2)
 
 __device__ __forceinline__ int swz_off(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
 
-template <int MODE>
-__global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmP p) {
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+  else if constexpr (N == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+  else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  else if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+  else if constexpr (N == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+  else if constexpr (N == 24) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+  else static_assert(N == 0, "add the vmcnt literal");
+}
+
+// Block tile BM x BN x 64, WM x WN waves (each (BM/WM) x (BN/WN), built from 32x32x16 MFMAs), S-stage LDS
+// ring filled by LDS-DMA with a counted vmcnt: tile t+S-1 is issued while tile t is consumed, ONE raw
+// s_barrier per K-step (it orders "tile t landed for every wave" and "everyone finished tile t-1").
+template <int MODE, int BM, int BN, int WM, int WN, int S>
+__global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmP p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int NW = WM * WN;
+  constexpr int STAGE = (BM + BN) * 128;
+  constexpr int A_BYTES = BM * 128;
+  constexpr int PA = BM / 8 / NW, PB = BN / 8 / NW;     // 1-KiB LDS-DMA pieces per wave per tile
+  constexpr int P = PA + PB;
+  constexpr int MI = BM / WM / 32, NI = BN / WN / 32;
+  static_assert(BM % (8 * NW) == 0 && BN % (8 * NW) == 0, "tile / wave split");
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wr = wave >> 1, wc = wave & 1;
+  const int wr = wave / WN, wc = wave % WN;
 
   // ---- XCD-aware, grouped tile mapping (bijective for any grid size)
   const int nbm = (p.M + BM - 1) / BM, nbn = (p.N + BN - 1) / BN;
@@ -48,15 +68,15 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmP p) {
   const int bm = first_m + (bid % per_group) % gsize;
   const int bn = (bid % per_group) / gsize;
 
-  // ---- per-thread staging descriptors: 4 A rows + 4 W rows, one 16-byte chunk each
-  const int lrow = lane >> 3;              // row within an 8-row glds piece
+  // ---- per-thread staging descriptors: PA A rows + PB W rows, one 16-byte chunk each
+  const int lrow = lane >> 3;              // row within an 8-row LDS-DMA piece
   const int cpos = lane & 7;               // chunk position inside the LDS row
-  const bf16* a_src[4];
-  int a_iy0[4], a_ix0[4];                  // conv: virtual-input origin of the 3x3 window
-  const bf16* w_src[4];
+  const bf16* a_src[PA];
+  int a_iy0[PA], a_ix0[PA];                // conv: virtual-input origin of the 3x3 window
+  const bf16* w_src[PB];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int r = (wave * 4 + j) * 8 + lrow;            // tile row 0..127
+  for (int j = 0; j < PA; ++j) {
+    const int r = (wave * PA + j) * 8 + lrow;
     const int chunk = cpos ^ ((r >> 1) & 7);            // source chunk that lands at position cpos
     int gm = bm * BM + r;
     gm = gm < p.M ? gm : p.M - 1;
@@ -72,6 +92,11 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmP p) {
       a_ix0[j] = ox * p.stride - 1;
       a_src[j] = p.A + (long long)b * p.Hs * p.Ws * p.Cin + chunk * 8;
     }
+  }
+#pragma unroll
+  for (int j = 0; j < PB; ++j) {
+    const int r = (wave * PB + j) * 8 + lrow;
+    const int chunk = cpos ^ ((r >> 1) & 7);
     int gn = bn * BN + r;
     gn = gn < p.N ? gn : p.N - 1;
     w_src[j] = p.W + (long long)gn * p.ldw + chunk * 8;
@@ -79,7 +104,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmP p) {
   const int Hv = p.Hs << p.shift, Wv = p.Ws << p.shift;
 
   auto stage = [&](int st, int k0) {
-    char* base = smem + st * STAGE_BYTES;
+    char* base = smem + st * STAGE;
     int ky = 0, kx = 0, c0 = 0;
     if (MODE == 1) {
       const int tap = k0 / p.Cin;
@@ -88,7 +113,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmP p) {
       kx = tap - ky * 3;
     }
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < PA; ++j) {
       const bf16* src;
       if (MODE == 0) {
         src = a_src[j] + k0;
@@ -99,68 +124,68 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmP p) {
         const int sy = iy >> p.shift, sx = ix >> p.shift;
         src = ok ? a_src[j] + ((long long)sy * p.Ws + sx) * p.Cin + c0 : p.zeros;
       }
-      __builtin_amdgcn_global_load_lds(PEA_GLB(src), PEA_LDS(base + (wave * 4 + j) * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds(PEA_GLB(src), PEA_LDS(base + (wave * PA + j) * 1024), 16, 0, 0);
     }
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      __builtin_amdgcn_global_load_lds(PEA_GLB(w_src[j] + k0), PEA_LDS(base + A_BYTES + (wave * 4 + j) * 1024), 16,
+    for (int j = 0; j < PB; ++j)
+      __builtin_amdgcn_global_load_lds(PEA_GLB(w_src[j] + k0), PEA_LDS(base + A_BYTES + (wave * PB + j) * 1024), 16,
                                        0, 0);
-    }
   };
 
-  f32x16 acc[2][2];   // [ni][mi]
+  f32x16 acc[NI][MI];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < NI; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < MI; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   const int nt = p.K / BK;
-  stage(0, 0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < S - 1; ++i)
+    if (i < nt) stage(i, i * BK);
 
   const int frow = lane & 31, fh = lane >> 5;
+  int cur = 0;
   for (int t = 0; t < nt; ++t) {
-    const int cur = t & 1;
-    if (t + 1 < nt) stage(cur ^ 1, (t + 1) * BK);
-    const char* As = smem + cur * STAGE_BYTES;
+    // tile t must have landed: tiles t+1 .. t+S-2 (P loads each) may stay in flight
+    if (t + S - 2 < nt) wait_vmcnt<(S - 2) * P>();
+    else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    if (t + S - 1 < nt) {
+      int nb = cur + S - 1;
+      nb = nb >= S ? nb - S : nb;
+      stage(nb, (t + S - 1) * BK);
+    }
+    const char* As = smem + cur * STAGE;
     const char* Ws = As + A_BYTES;
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-      bf16x8 af[2], wf[2];
+      bf16x8 af[MI], wf[NI];
 #pragma unroll
-      for (int mi = 0; mi < 2; ++mi) {
-        const int row = wr * 64 + mi * 32 + frow;
-        af[mi] = *(const bf16x8*)(As + swz_off(row, 2 * s + fh));
-      }
+      for (int mi = 0; mi < MI; ++mi) af[mi] = *(const bf16x8*)(As + swz_off(wr * (BM / WM) + mi * 32 + frow, 2 * s + fh));
 #pragma unroll
-      for (int ni = 0; ni < 2; ++ni) {
-        const int row = wc * 64 + ni * 32 + frow;
-        wf[ni] = *(const bf16x8*)(Ws + swz_off(row, 2 * s + fh));
-      }
+      for (int ni = 0; ni < NI; ++ni) wf[ni] = *(const bf16x8*)(Ws + swz_off(wc * (BN / WN) + ni * 32 + frow, 2 * s + fh));
 #pragma unroll
-      for (int ni = 0; ni < 2; ++ni)
+      for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
-        for (int mi = 0; mi < 2; ++mi)
+        for (int mi = 0; mi < MI; ++mi)
           acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ni], af[mi], acc[ni][mi], 0, 0, 0);
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    cur = cur + 1 == S ? 0 : cur + 1;
   }
 
   // ---- epilogue.  acc[ni][mi][4g+j] = D[n = 8g + 4h + j][m = lane&31]
 #pragma unroll
-  for (int mi = 0; mi < 2; ++mi) {
-    const int m = bm * BM + wr * 64 + mi * 32 + frow;
+  for (int mi = 0; mi < MI; ++mi) {
+    const int m = bm * BM + wr * (BM / WM) + mi * 32 + frow;
     if (m >= p.M) continue;
     const int bidx = p.rowvec ? m / p.rows_per_batch : 0;
 #pragma unroll
-    for (int ni = 0; ni < 2; ++ni) {
+    for (int ni = 0; ni < NI; ++ni) {
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        const int n = bn * BN + wc * 64 + ni * 32 + 8 * g + 4 * fh;
+        const int n = bn * BN + wc * (BN / WN) + ni * 32 + 8 * g + 4 * fh;
         if (n >= p.N) continue;
         float v[4];
 #pragma unroll
@@ -216,6 +241,42 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmP p) {
   }
 }
 
+// ---- variant table (tile shape x wave grid x ring depth); the launcher picks one per problem shape
+int g_gemm_variant = -1;   // >= 0: forced (benchmark / debug)
+extern "C" void pea_debug_set_gemm_variant(int v) { g_gemm_variant = v; }
+
+template <int MODE, int BM, int BN, int WM, int WN, int S>
+static int launch_variant(const GemmP& p, hipStream_t stream) {
+  constexpr int lds = S * (BM + BN) * 128;
+  static bool attr_set = false;
+  if (!attr_set) {
+    HIPCHK(hipFuncSetAttribute((const void*)gemm_bf16_kernel<MODE, BM, BN, WM, WN, S>,
+                               hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    attr_set = true;
+  }
+  const int grid = cdiv(p.M, BM) * cdiv(p.N, BN);
+  hipLaunchKernelGGL((gemm_bf16_kernel<MODE, BM, BN, WM, WN, S>), dim3(grid), dim3(WM * WN * 64), lds, stream, p);
+  return PEA_OK;
+}
+
+#define GEMM_VARIANTS(MODE)                                              \
+  switch (v) {                                                           \
+    case 0: rc = launch_variant<MODE, 128, 128, 2, 2, 2>(p, stream); break; \
+    case 1: rc = launch_variant<MODE, 128, 128, 2, 2, 3>(p, stream); break; \
+    case 2: rc = launch_variant<MODE, 128, 128, 2, 2, 4>(p, stream); break; \
+    case 3: rc = launch_variant<MODE, 256, 128, 4, 2, 2>(p, stream); break; \
+    case 4: rc = launch_variant<MODE, 256, 128, 4, 2, 3>(p, stream); break; \
+    case 5: rc = launch_variant<MODE, 256, 256, 2, 4, 2>(p, stream); break; \
+    case 6: rc = launch_variant<MODE, 128, 256, 2, 4, 3>(p, stream); break; \
+    case 7: rc = launch_variant<MODE, 256, 128, 2, 2, 3>(p, stream); break; \
+    default: rc = launch_variant<MODE, 128, 128, 2, 2, 2>(p, stream); break; \
+  }
+
+static int pick_variant(const GemmP& p) {
+  if (g_gemm_variant >= 0) return g_gemm_variant;
+  return 0;
+}
+
 int launch_gemm(const GemmP& p, hipStream_t stream) {
   SHAPECHK(p.M > 0 && p.N > 0 && p.K > 0, "gemm: empty problem M=%d N=%d K=%d", p.M, p.N, p.K);
   SHAPECHK(p.K % BK == 0, "gemm: K=%d must be a multiple of %d", p.K, BK);
@@ -228,26 +289,17 @@ int launch_gemm(const GemmP& p, hipStream_t stream) {
     SHAPECHK(p.zeros != nullptr, "conv: zero page missing");
     SHAPECHK(p.M % (p.Ho * p.Wo) == 0, "conv: M=%d not a multiple of Ho*Wo", p.M);
   }
-  static bool attr_set = false;
-  if (!attr_set) {
-    HIPCHK(hipFuncSetAttribute((const void*)gemm_bf16_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                               2 * STAGE_BYTES));
-    HIPCHK(hipFuncSetAttribute((const void*)gemm_bf16_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                               2 * STAGE_BYTES));
-    attr_set = true;
-  }
-  const int grid = cdiv(p.M, BM) * cdiv(p.N, BN);
   {
     // algorithmic work: 2*M*N*K; a transposed (zero-stuffed) conv only has 1/4 of its taps real
     double fl = 2.0 * p.M * (double)p.N * p.K * (p.parity ? 0.25 : 1.0);
     double by = 2.0 * ((double)p.M * p.N + (double)p.N * p.K + (p.mode ? (double)p.M * p.K / 9.0 : (double)p.M * p.K));
     PROF_BEGIN(p.mode ? 1 : 0, fl, by, stream);
   }
-  if (p.mode == 0)
-    hipLaunchKernelGGL(gemm_bf16_kernel<0>, dim3(grid), dim3(256), 2 * STAGE_BYTES, stream, p);
-  else
-    hipLaunchKernelGGL(gemm_bf16_kernel<1>, dim3(grid), dim3(256), 2 * STAGE_BYTES, stream, p);
+  const int v = pick_variant(p);
+  int rc = PEA_OK;
+  if (p.mode == 0) { GEMM_VARIANTS(0) } else { GEMM_VARIANTS(1) }
   PROF_END(stream);
+  if (rc != PEA_OK) return rc;
   HIPCHK(hipGetLastError());
   return PEA_OK;
 }

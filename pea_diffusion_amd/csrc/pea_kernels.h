@@ -157,3 +157,4 @@ void prof_begin_impl(int fam, double flops, double bytes, hipStream_t s);
 void prof_end_impl(hipStream_t s);
 #define PROF_BEGIN(fam, flops, bytes, s) do { if (g_prof_on) prof_begin_impl(fam, flops, bytes, s); } while (0)
 #define PROF_END(s) do { if (g_prof_on) prof_end_impl(s); } while (0)
+int launch_prefetch(const void* p, long long bytes, int* sink, hipStream_t s);
