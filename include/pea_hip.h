@@ -85,11 +85,14 @@ int pea_op_layernorm_bwd(const void* x, const void* dy, const float* gamma, cons
  * row strides ld* (elements); head h occupies columns [64h, 64h+64).  lse fp32 [B][H][Sq].        */
 int pea_op_attention_fwd(const void* Q, int ldq, const void* K, int ldk, const void* V, int ldv, void* O, int ldo,
                          float* lse, int B, int H, int Sq, int Skv, float scale, void* stream);
-/* dQ/dK/dV (any may be NULL... dK and dV together); delta: fp32 scratch [B][H][Sq] */
+/* dQ/dK/dV (dQ may be NULL; dK and dV together); delta: fp32 scratch [B][H][Sq]; scratch: optional device
+ * buffer of pea_op_attention_bwd_scratch_bytes(...) bytes enabling the query-split dK/dV form used when the
+ * key count is small (cross-attention); NULL = single pass                                            */
+long long pea_op_attention_bwd_scratch_bytes(int B, int H, int Sq, int Skv);
 int pea_op_attention_bwd(const void* Q, int ldq, const void* K, int ldk, const void* V, int ldv, const void* O,
                          int ldo, const void* dO, int lddo, const float* lse, float* delta, void* dQ, int lddq,
                          void* dK, int lddk, void* dV, int lddv, int B, int H, int Sq, int Skv, float scale,
-                         int accum_dq, int accum_dkv, void* stream);
+                         int accum_dq, int accum_dkv, void* scratch, void* stream);
 
 int pea_op_geglu_fwd(const void* hg, void* y, long long rows, int inner, void* stream);
 int pea_op_geglu_bwd(const void* hg, const void* dy, void* dhg, long long rows, int inner, void* stream);

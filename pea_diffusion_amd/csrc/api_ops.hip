@@ -121,14 +121,14 @@ int pea_op_attention_fwd(const void* Q, int ldq, const void* K, int ldk, const v
 int pea_op_attention_bwd(const void* Q, int ldq, const void* K, int ldk, const void* V, int ldv, const void* O,
                          int ldo, const void* dO, int lddo, const float* lse, float* delta, void* dQ, int lddq,
                          void* dK, int lddk, void* dV, int lddv, int B, int H, int Sq, int Skv, float scale,
-                         int accum_dq, int accum_dkv, void* stream) {
+                         int accum_dq, int accum_dkv, void* scratch, void* stream) {
   AttnP p;
   memset(&p, 0, sizeof(p));
   p.Q = (const bf16*)Q; p.K = (const bf16*)K; p.V = (const bf16*)V; p.ldq = ldq; p.ldk = ldk; p.ldv = ldv;
   p.O = (bf16*)O; p.ldo = ldo; p.lse = (float*)lse; p.B = B; p.H = H; p.Sq = Sq; p.Skv = Skv; p.scale = scale;
   p.dO = (const bf16*)dO; p.lddo = lddo; p.delta = delta;
   p.dQ = (bf16*)dQ; p.lddq = lddq; p.dK = (bf16*)dK; p.lddk = lddk; p.dV = (bf16*)dV; p.lddv = lddv;
-  p.accum_dq = accum_dq; p.accum_dkv = accum_dkv;
+  p.accum_dq = accum_dq; p.accum_dkv = accum_dkv; p.dkv_part = (float*)scratch;
   return launch_attention_bwd(p, (hipStream_t)stream);
 }
 
@@ -178,6 +178,9 @@ int pea_op_kd_loss(int ntaps, const void* const* taps_s, const void* const* taps
   return launch_kd_loss(p, (hipStream_t)stream);
 }
 
+long long pea_op_attention_bwd_scratch_bytes(int B, int H, int Sq, int Skv) {
+  return (long long)attention_bwd_scratch_bytes(B, H, Sq, Skv);
+}
 long long pea_op_groupnorm_scratch_bytes(int B, int HW, int C, int groups) {
   return (long long)groupnorm_scratch_bytes(B, HW, C, groups);
 }

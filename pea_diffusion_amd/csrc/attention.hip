@@ -239,13 +239,18 @@ __global__ __launch_bounds__(256) void attn_q_kernel(const AttnP p) {
 
 // ============================================================================= dK / dV
 // workgroup = 4 waves = 128 keys (wave owns 32, key on the lane); loops over 64-query tiles.
+// With p.nsplit > 1 (cross-attention: few keys, many queries) blockIdx.x also enumerates query ranges and the
+// block writes fp32 partial dK/dV to p.dkv_part[split][b][h][key][2][64]; attn_dkv_reduce_kernel adds the
+// splits in order (deterministic, no atomics).
 template <bool USE_TR>
 __global__ __launch_bounds__(256) void attn_dkv_kernel(const AttnP p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 stages][Q tile | dO tile]
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int head = blockIdx.y, b = blockIdx.z;
-  const int k0 = blockIdx.x * 128 + wave * 32;
+  const int nsplit = p.nsplit > 1 ? p.nsplit : 1;
+  const int kblk = blockIdx.x / nsplit, split = blockIdx.x - kblk * nsplit;
+  const int k0 = kblk * 128 + wave * 32;
   const int frow = lane & 31, fh = lane >> 5;
   const float c = p.scale * LOG2E;
 
@@ -272,14 +277,19 @@ __global__ __launch_bounds__(256) void attn_dkv_kernel(const AttnP p) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) dk[i][r] = dv[i][r] = 0.f;
 
-  const int nt = (p.Sq + 63) / 64;
-  stage_tile(Qb, p.ldq, 0, p.Sq, smem, wave, lane);
-  stage_tile(dOb, p.lddo, 0, p.Sq, smem + TILE_BYTES, wave, lane);
+  const int nt_all = (p.Sq + 63) / 64;
+  const int tps = (nt_all + nsplit - 1) / nsplit;            // query tiles per split
+  const int t_begin = split * tps;
+  const int nt = min(nt_all, t_begin + tps);
+  if (t_begin < nt) {
+    stage_tile(Qb, p.ldq, t_begin * 64, p.Sq, smem, wave, lane);
+    stage_tile(dOb, p.lddo, t_begin * 64, p.Sq, smem + TILE_BYTES, wave, lane);
+  }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
-  for (int t = 0; t < nt; ++t) {
-    const int cur = t & 1;
+  for (int t = t_begin; t < nt; ++t) {
+    const int cur = (t - t_begin) & 1;
     if (t + 1 < nt) {
       char* nx = smem + (cur ^ 1) * 2 * TILE_BYTES;
       stage_tile(Qb, p.ldq, (t + 1) * 64, p.Sq, nx, wave, lane);
@@ -341,6 +351,21 @@ __global__ __launch_bounds__(256) void attn_dkv_kernel(const AttnP p) {
     __syncthreads();
   }
   if (!kvalid) return;
+  if (p.nsplit > 1) {
+    float* pr = p.dkv_part + ((((long long)split * p.B + b) * p.H + head) * p.Skv + krow) * 128;
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int d = db * 32 + 8 * g + 4 * fh;
+        f32x4 a, c;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { a[j] = dk[db][4 * g + j]; c[j] = dv[db][4 * g + j]; }
+        *(f32x4*)(pr + d) = a;
+        *(f32x4*)(pr + 64 + d) = c;
+      }
+    return;
+  }
   bf16* dKr = p.dK + ((long long)b * p.Skv + krow) * p.lddk + head * 64;
   bf16* dVr = p.dV + ((long long)b * p.Skv + krow) * p.lddv + head * 64;
 #pragma unroll
@@ -389,6 +414,45 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const AttnP p) {
   }
 }
 
+// out[b][key][h*64+d] (+)= sum_split part[split][b][h][key][{dK,dV}][d]   (splits added in order)
+__global__ void attn_dkv_reduce_kernel(const AttnP p) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;     // (b, h, key, which, d/4)
+  const long long total = (long long)p.B * p.H * p.Skv * 2 * 16;
+  if (idx >= total) return;
+  const int d4 = (int)(idx & 15) * 4;
+  const int which = (int)((idx >> 4) & 1);
+  long long r = idx >> 5;
+  const int key = (int)(r % p.Skv); r /= p.Skv;
+  const int head = (int)(r % p.H);
+  const int b = (int)(r / p.H);
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  for (int s = 0; s < p.nsplit; ++s) {
+    const f32x4 v = *(const f32x4*)(p.dkv_part + ((((long long)s * p.B + b) * p.H + head) * p.Skv + key) * 128 +
+                                    which * 64 + d4);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[j] += v[j];
+  }
+  bf16* dst = which ? p.dV + ((long long)b * p.Skv + key) * p.lddv + head * 64 + d4
+                    : p.dK + ((long long)b * p.Skv + key) * p.lddk + head * 64 + d4;
+  bf16x4 o;
+  if (p.accum_dkv) o = *(const bf16x4*)dst;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) o[j] = (bf16)(acc[j] + (p.accum_dkv ? (float)o[j] : 0.f));
+  *(bf16x4*)dst = o;
+}
+
+// query-range splitting for the dK/dV kernel when the key count gives too few workgroups
+int attention_bwd_nsplit(int B, int H, int Sq, int Skv) {
+  if (Skv > 128 || Sq < 512) return 1;
+  const int nt = (Sq + 63) / 64;
+  int ns = nt / 4;                               // 256 queries per split
+  return ns < 1 ? 1 : ns;
+}
+size_t attention_bwd_scratch_bytes(int B, int H, int Sq, int Skv) {
+  const int ns = attention_bwd_nsplit(B, H, Sq, Skv);
+  return ns > 1 ? (size_t)ns * B * H * Skv * 128 * sizeof(float) : 0;
+}
+
 static int g_attn_use_tr = 1;
 extern "C" void pea_debug_set_attn_tr(int v) { g_attn_use_tr = v; }
 
@@ -414,7 +478,9 @@ int launch_attention_fwd(const AttnP& p, hipStream_t s) {
   return PEA_OK;
 }
 
-int launch_attention_bwd(const AttnP& p, hipStream_t s) {
+int launch_attention_bwd(const AttnP& p0, hipStream_t s) {
+  AttnP p = p0;
+  p.nsplit = p.dkv_part ? attention_bwd_nsplit(p.B, p.H, p.Sq, p.Skv) : 1;
   int rc = attn_check(p);
   if (rc) return rc;
   SHAPECHK(p.lse && p.delta && p.dO && p.O, "attention bwd: lse/delta/dO/O required");
@@ -430,11 +496,15 @@ int launch_attention_bwd(const AttnP& p, hipStream_t s) {
       hipLaunchKernelGGL((attn_q_kernel<1, false>), grid, dim3(256), 4 * TILE_BYTES, s, p);
   }
   if (p.dK && p.dV) {
-    const dim3 grid(cdiv(p.Skv, 128), p.H, p.B);
+    const dim3 grid(cdiv(p.Skv, 128) * (p.nsplit > 1 ? p.nsplit : 1), p.H, p.B);
     if (g_attn_use_tr)
       hipLaunchKernelGGL((attn_dkv_kernel<true>), grid, dim3(256), 4 * TILE_BYTES, s, p);
     else
       hipLaunchKernelGGL((attn_dkv_kernel<false>), grid, dim3(256), 4 * TILE_BYTES, s, p);
+    if (p.nsplit > 1) {
+      const long long total = (long long)p.B * p.H * p.Skv * 2 * 16;
+      hipLaunchKernelGGL(attn_dkv_reduce_kernel, dim3((unsigned)cdivl(total, 256)), dim3(256), 0, s, p);
+    }
   }
   PROF_END(s);
   HIPCHK(hipGetLastError());

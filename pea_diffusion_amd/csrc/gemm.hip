@@ -274,6 +274,16 @@ static int launch_variant(const GemmP& p, hipStream_t stream) {
 
 static int pick_variant(const GemmP& p) {
   if (g_gemm_variant >= 0) return g_gemm_variant;
+  // measured on the step's shapes (scripts/gemm_bench.py / gemm_cold_bench.py):
+  //   0 = 128x128, 4 waves, 2 stages (2 blocks/CU)   4 = 256x128, 8 waves, 3 stages   5 = 256x256, 8 waves, 2 stages
+  if (p.mode == 1) {
+    if (p.N <= 384) return 4;                  // 128^2-level convs (N = 320)
+    if (p.M >= 16384) return 5;                // 64^2-level convs (N = 640)
+    return 4;                                  // 32^2-level convs (M = 4096, N = 1280, K >= 11520)
+  }
+  if (p.M < 1024) return 0;                    // cross-attention K|V projections, embeddings
+  if (p.N <= 1280 && p.M <= 8192 && p.K >= 2560) return 4;
+  if (p.N >= 3840 && p.M >= 8192) return 5;
   return 0;
 }
 
@@ -306,42 +316,69 @@ int launch_gemm(const GemmP& p, hipStream_t stream) {
 
 // ------------------------------------------------------------------------------------------
 // 4-channel ends of the UNet (conv_in: K = 36, conv_out: N = 4): negligible FLOPs, direct form.
-__global__ void conv_in_kernel(const float* __restrict__ x, const float* __restrict__ w,
-                               const float* __restrict__ bias, bf16* __restrict__ y, int B, int Cin, int H, int W,
-                               int Cout) {
-  // one thread per (pixel, 4 output channels)
-  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  const int cq = Cout / 4;
-  const long long total = (long long)B * H * W * cq;
-  if (idx >= total) return;
-  const int co = (int)(idx % cq) * 4;
-  const long long pix = idx / cq;
-  const int xw = (int)(pix % W), yh = (int)((pix / W) % H), b = (int)(pix / ((long long)W * H));
-  float acc[4] = {bias[co], bias[co + 1], bias[co + 2], bias[co + 3]};
-  for (int ci = 0; ci < Cin; ++ci)
-    for (int ky = 0; ky < 3; ++ky) {
-      const int iy = yh + ky - 1;
-      if ((unsigned)iy >= (unsigned)H) continue;
-      for (int kx = 0; kx < 3; ++kx) {
-        const int ix = xw + kx - 1;
-        if ((unsigned)ix >= (unsigned)W) continue;
-        const float v = x[(((long long)b * Cin + ci) * H + iy) * W + ix];
+// conv_in (Cin = 4, K = 36): weights transposed into LDS [36][Cout] fp32; a thread owns 8 output channels and
+// walks pixels; the 36 input taps are read once per pixel (L1-shared by the threads of that pixel).
+__global__ __launch_bounds__(256) void conv_in_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                      const float* __restrict__ bias, bf16* __restrict__ y, int B,
+                                                      int Cin, int H, int W, int Cout, int pix_per_block) {
+  extern __shared__ __attribute__((aligned(16))) char cism[];
+  float* wl = (float*)cism;                       // [Cin*9][Cout]
+  const int K = Cin * 9;
+  for (int i = threadIdx.x; i < K * Cout; i += blockDim.x) {
+    const int co = i / K, k = i - co * K;        // w[co][ci][ky][kx] -> k = ci*9 + ky*3 + kx
+    wl[k * Cout + co] = w[i];
+  }
+  __syncthreads();
+  const int nchunk = Cout / 8;
+  const int ppb = blockDim.x / nchunk;
+  const int ck = threadIdx.x % nchunk, pl = threadIdx.x / nchunk;
+  if (pl >= ppb) return;
+  const int c0 = ck * 8;
+  float bs[8];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[j] += v * w[(((co + j) * Cin + ci) * 3 + ky) * 3 + kx];
+  for (int j = 0; j < 8; ++j) bs[j] = bias[c0 + j];
+  const long long npix = (long long)B * H * W;
+  const long long p0 = (long long)blockIdx.x * pix_per_block;
+  const long long p1 = p0 + pix_per_block < npix ? p0 + pix_per_block : npix;
+  for (long long pix = p0 + pl; pix < p1; pix += ppb) {
+    const int xw = (int)(pix % W), yh = (int)((pix / W) % H), b = (int)(pix / ((long long)W * H));
+    float acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = bs[j];
+    for (int ci = 0; ci < Cin; ++ci)
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky) {
+        const int iy = yh + ky - 1;
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+          const int ix = xw + kx - 1;
+          const bool ok = (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+          const float v = ok ? x[(((long long)b * Cin + ci) * H + iy) * W + ix] : 0.f;
+          const float* wr = wl + (ci * 9 + ky * 3 + kx) * Cout + c0;
+          const f32x4 w0 = *(const f32x4*)wr, w1 = *(const f32x4*)(wr + 4);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            acc[j] += v * w0[j];
+            acc[4 + j] += v * w1[j];
+          }
+        }
       }
-    }
-  bf16x4 o;
+    bf16x8 o;
 #pragma unroll
-  for (int j = 0; j < 4; ++j) o[j] = (bf16)acc[j];
-  *(bf16x4*)(y + pix * Cout + co) = o;
+    for (int j = 0; j < 8; ++j) o[j] = (bf16)acc[j];
+    *(bf16x8*)(y + pix * Cout + c0) = o;
+  }
 }
 
 int launch_conv_in(const float* x, const float* w, const float* bias, bf16* y, int B, int Cin, int H, int W,
                    int Cout, hipStream_t s) {
-  SHAPECHK(Cout % 4 == 0, "conv_in: Cout %% 4");
-  const long long total = (long long)B * H * W * (Cout / 4);
-  hipLaunchKernelGGL(conv_in_kernel, dim3((unsigned)cdivl(total, 256)), dim3(256), 0, s, x, w, bias, y, B, Cin, H,
-                     W, Cout);
+  SHAPECHK(Cout % 8 == 0 && Cout / 8 <= 256 && Cin * 9 * Cout * 4 <= 64 * 1024, "conv_in: Cout=%d Cin=%d", Cout, Cin);
+  const int nchunk = Cout / 8;
+  const int ppb = 256 / nchunk;
+  const int per = ppb * 8;
+  const long long npix = (long long)B * H * W;
+  hipLaunchKernelGGL(conv_in_kernel, dim3((unsigned)cdivl(npix, per)), dim3(256), (size_t)Cin * 9 * Cout * 4, s, x, w,
+                     bias, y, B, Cin, H, W, Cout, per);
   HIPCHK(hipGetLastError());
   return PEA_OK;
 }

@@ -99,7 +99,7 @@ struct Unet {
   char* aarena = nullptr; size_t abytes = 0;
   char* garena = nullptr; size_t gbytes = 0;
   // scratch
-  double* gn_scratch = nullptr; float* cs_scratch = nullptr; float* delta = nullptr; bf16* ups_tmp = nullptr; float* tproj_grad = nullptr;
+  double* gn_scratch = nullptr; float* cs_scratch = nullptr; float* attn_part = nullptr; float* delta = nullptr; bf16* ups_tmp = nullptr; float* tproj_grad = nullptr;
   float* tmp_f32 = nullptr; size_t tmp_f32_elems = 0;   // load-time staging
   const bf16* zeros = nullptr;
   // per-call externals
@@ -153,5 +153,6 @@ struct Trainer {
            const float* teacher_neg, const float* teacher_pooled, const float* time_ids, float grad_scale,
            float* grads, int accumulate, float* losses_out, hipStream_t s);
   float* t_f32 = nullptr;
+  int two_stream = 1; hipStream_t side = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   ~Trainer();
 };

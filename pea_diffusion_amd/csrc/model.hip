@@ -4,6 +4,7 @@
 // diffusers state-dict key names for every weight.
 #include "model.h"
 
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -365,9 +366,12 @@ int Unet::alloc() {
   for (Op& o : ops)
     if (o.aux_bytes) o.aux = (float*)(aarena + o.aux_off);
   // ---- scratch
-  size_t delta_elems = 0, ups_elems = 0;
+  size_t delta_elems = 0, ups_elems = 0, part_bytes = 0;
   for (Op& o : ops) {
-    if (o.kind == OP_ATTN) delta_elems = std::max(delta_elems, (size_t)B * o.p0 * o.p1);
+    if (o.kind == OP_ATTN) {
+      delta_elems = std::max(delta_elems, (size_t)B * o.p0 * o.p1);
+      part_bytes = std::max(part_bytes, attention_bwd_scratch_bytes(B, o.p0, o.p1, o.p2));
+    }
     if (o.kind == OP_CONV3 && o.p1 && tn[o.a].rg)
       ups_elems = std::max(ups_elems, (size_t)tn[o.out].rows * tn[o.a].cols);
   }
@@ -381,6 +385,7 @@ int Unet::alloc() {
   if (needs_grad) {
     if (delta_elems) HIPCHK(hipMalloc((void**)&delta, delta_elems * 4));
     if (ups_elems) HIPCHK(hipMalloc((void**)&ups_tmp, ups_elems * 2));
+    if (part_bytes) HIPCHK(hipMalloc((void**)&attn_part, part_bytes));
     HIPCHK(hipMalloc((void**)&tproj_grad, sizeof(float) * B * tproj_total));
   }
   RC(pea_zero_page(&zeros));
@@ -397,6 +402,7 @@ Unet::~Unet() {
   if (ups_tmp) hipFree(ups_tmp);
   if (tproj_grad) hipFree(tproj_grad);
   if (cs_scratch) hipFree(cs_scratch);
+  if (attn_part) hipFree(attn_part);
 }
 
 int Unet::load_weight(const char* name, const float* src, long long numel, hipStream_t s) {
@@ -685,7 +691,7 @@ int Unet::backward(const float* deps, hipStream_t s) {
         AttnP p; memset(&p, 0, sizeof(p));
         p.Q = q.d + o.acol; p.ldq = q.cols; p.K = k.d + o.bcol; p.ldk = k.cols; p.V = v.d + o.ccol; p.ldv = v.cols;
         p.O = out.d; p.ldo = out.cols; p.lse = o.aux; p.B = B; p.H = o.p0; p.Sq = o.p1; p.Skv = o.p2; p.scale = 0.125f;
-        p.dO = out.g; p.lddo = out.cols; p.delta = delta;
+        p.dO = out.g; p.lddo = out.cols; p.delta = delta; p.dkv_part = attn_part;
         SHAPECHK(!q.gw && !k.gw, "unet: attention operand gradient written twice");
         if (q.rg) { p.dQ = q.g + o.acol; p.lddq = q.cols; }
         if (k.rg) { p.dK = k.g + o.bcol; p.lddk = k.cols; p.dV = v.g + o.ccol; p.lddv = v.cols; }
@@ -836,12 +842,14 @@ int Adapter::backward(float* g, int accumulate, hipStream_t s) {
 
 // ============================================================================ trainer
 Trainer::~Trainer() {
+  if (side) { (void)hipStreamDestroy(side); (void)hipEventDestroy(ev_fork); (void)hipEventDestroy(ev_join); }
   for (void* p : {(void*)xt, (void*)eps_s, (void*)eps_t, (void*)deps, (void*)ac, (void*)t_ehs_sel, (void*)dehs_full, (void*)t_f32,
                   (void*)losses, (void*)kd_ws, (void*)tehs_c, (void*)tehs_n})
     if (p) hipFree(p);
 }
 
 int Trainer::prepare() {
+  if (const char* e = getenv("PEA_TWO_STREAM")) two_stream = atoi(e);
   Unet& S = *student;
   Unet& Tt = *teacher;
   SHAPECHK(S.needs_grad, "trainer: student context needs gradient support");
@@ -900,6 +908,26 @@ int Trainer::step(const float* latents, const float* noise, const long long* tim
   if (!t_f32) HIPCHK(hipMalloc((void**)&t_f32, sizeof(float) * B));
   RC(launch_add_noise(latents, noise, timesteps, ac, xt, B, per_img, s));
   RC(launch_cast_i64_f32(timesteps, t_f32, B, s));
+  // The teacher forward (no_grad, :410-415) is independent of the adapter and of the student forward: it runs
+  // on a side HIP stream so the two UNet passes fill each other's under-occupied launches.
+  hipStream_t ts = s;
+  if (two_stream) {
+    if (!side) {
+      HIPCHK(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
+      HIPCHK(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
+      HIPCHK(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
+    }
+    HIPCHK(hipEventRecord(ev_fork, s));
+    HIPCHK(hipStreamWaitEvent(side, ev_fork, 0));
+    ts = side;
+  }
+  const long long per_tt = (long long)Tt.L * Tt.cfg.cross_dim;
+  RC(launch_cast_f32_bf16(teacher_ehs, tehs_c, B * per_tt, ts));
+  RC(launch_cast_f32_bf16(teacher_neg, tehs_n, B * per_tt, ts));
+  Tn& tehs = Tt.tn[Tt.t_ehs];
+  RC(launch_select_rows(tehs_c, tehs_n, prompt_mask, tehs.d, B, per_tt, ts));                    // :413
+  RC(Tt.forward(xt, t_f32, tehs.d, 1, teacher_pooled, 0, time_ids, eps_t, ts));
+  if (two_stream) HIPCHK(hipEventRecord(ev_join, side));
   // adapter on (cond | uncond) rows; train_sdxl_zh.py:383-384
   RC(A.forward(enc, enc_uncond, 0, s));
   const long long per_tok = (long long)S.L * S.cfg.cross_dim;
@@ -907,13 +935,7 @@ int Trainer::step(const float* latents, const float* noise, const long long* tim
   Tn& ehs = S.tn[S.t_ehs];
   RC(launch_select_rows(tokens, tokens + B * per_tok, prompt_mask, ehs.d, B, per_tok, s));      // :395
   RC(S.forward(xt, t_f32, ehs.d, 1, S.t_text >= 0 ? (const void*)A.pooled : nullptr, 1, time_ids, eps_s, s));
-  // teacher (no grad); :410-415
-  const long long per_tt = (long long)Tt.L * Tt.cfg.cross_dim;
-  RC(launch_cast_f32_bf16(teacher_ehs, tehs_c, B * per_tt, s));
-  RC(launch_cast_f32_bf16(teacher_neg, tehs_n, B * per_tt, s));
-  Tn& tehs = Tt.tn[Tt.t_ehs];
-  RC(launch_select_rows(tehs_c, tehs_n, prompt_mask, tehs.d, B, per_tt, s));                     // :413
-  RC(Tt.forward(xt, t_f32, tehs.d, 1, teacher_pooled, 0, time_ids, eps_t, s));
+  if (two_stream) HIPCHK(hipStreamWaitEvent(s, ev_join, 0));
   // fused KD loss + seeds; :399-441
   KdLossP kp;
   memset(&kp, 0, sizeof(kp));

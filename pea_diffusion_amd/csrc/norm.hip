@@ -99,18 +99,25 @@ __global__ void gn_stats_kernel(const bf16* __restrict__ x, const bf16* __restri
   }
 }
 
-// sums the per-block partials in block order (fp64); FWD: writes (mean, rstd); BWD: writes (S1, S2) means
-__global__ void gn_finalize_kernel(const float* __restrict__ partial, float* __restrict__ out, int n_bg, int groups,
-                                   int nblk, double count, float eps, int bwd) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n_bg) return;
+// one wave per (b, group): lane-strided sums over the block partials + shuffle tree (fixed order, fp64)
+// FWD: writes (mean, rstd); BWD: writes (S1, S2) means
+__global__ __launch_bounds__(64) void gn_finalize_kernel(const float* __restrict__ partial, float* __restrict__ out,
+                                                         int n_bg, int groups, int nblk, double count, float eps,
+                                                         int bwd) {
+  const int i = blockIdx.x;
   const int b = i / groups, g = i - b * groups;
   double s1 = 0.0, s2 = 0.0;
-  for (int k = 0; k < nblk; ++k) {
+  for (int k = threadIdx.x; k < nblk; k += 64) {
     const float* p = partial + (((long long)b * nblk + k) * groups + g) * 2;
     s1 += (double)p[0];
     s2 += (double)p[1];
   }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    s1 += __shfl_xor(s1, o, 64);
+    s2 += __shfl_xor(s2, o, 64);
+  }
+  if (threadIdx.x != 0) return;
   if (bwd) {
     out[2 * i] = (float)(s1 / count);
     out[2 * i + 1] = (float)(s2 / count);
@@ -123,29 +130,37 @@ __global__ void gn_finalize_kernel(const float* __restrict__ partial, float* __r
   }
 }
 
+// apply passes: same (pixel-block, batch) geometry as the statistics pass; a thread keeps ONE channel chunk,
+// so the per-channel affine constants are computed once and the pixel loop is 1 load + 8 FMAs + 1 store
 __global__ void gn_apply_kernel(const bf16* __restrict__ x, const float* __restrict__ gamma,
                                 const float* __restrict__ beta, const float* __restrict__ stats,
-                                bf16* __restrict__ y, int HW, int C, int groups, int silu, long long total_chunks) {
+                                bf16* __restrict__ y, int HW, int C, int groups, int silu, int pix_per_block) {
   const int nchunk = C / 8;
+  const int ppb = blockDim.x / nchunk;
+  const int ck = threadIdx.x % nchunk, pl = threadIdx.x / nchunk;
+  const int b = blockIdx.y;
   const int cpg = C / groups;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total_chunks;
-       i += (long long)gridDim.x * blockDim.x) {
-    const int ck = (int)(i % nchunk);
-    const long long pix = i / nchunk;
-    const int b = (int)(pix / HW);
-    const int c0 = ck * 8;
-    const bf16x8 xv = *(const bf16x8*)(x + pix * C + c0);
+  const int c0 = ck * 8;
+  float sc[8], sh[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int g = (c0 + j) / cpg;
+    const float mean = stats[((long long)b * groups + g) * 2], rstd = stats[((long long)b * groups + g) * 2 + 1];
+    sc[j] = rstd * gamma[c0 + j];
+    sh[j] = beta[c0 + j] - mean * sc[j];
+  }
+  const int p0 = blockIdx.x * pix_per_block, p1 = min(p0 + pix_per_block, HW);
+  for (int p = p0 + pl; p < p1; p += ppb) {
+    const long long off = ((long long)b * HW + p) * C + c0;
+    const bf16x8 xv = *(const bf16x8*)(x + off);
     bf16x8 o;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      const int g = (c0 + j) / cpg;
-      const float mean = stats[((long long)b * groups + g) * 2];
-      const float rstd = stats[((long long)b * groups + g) * 2 + 1];
-      float v = ((float)xv[j] - mean) * rstd * gamma[c0 + j] + beta[c0 + j];
+      float v = (float)xv[j] * sc[j] + sh[j];
       if (silu) v = siluf_(v);
       o[j] = (bf16)v;
     }
-    *(bf16x8*)(y + pix * C + c0) = o;
+    *(bf16x8*)(y + off) = o;
   }
 }
 
@@ -153,35 +168,39 @@ __global__ void gn_bwd_apply_kernel(const bf16* __restrict__ x, const bf16* __re
                                     const float* __restrict__ gamma, const float* __restrict__ beta,
                                     const float* __restrict__ stats, const float* __restrict__ sums,
                                     bf16* __restrict__ dx, int HW, int C, int groups, int silu, int accum,
-                                    long long total_chunks) {
+                                    int pix_per_block) {
   const int nchunk = C / 8;
+  const int ppb = blockDim.x / nchunk;
+  const int ck = threadIdx.x % nchunk, pl = threadIdx.x / nchunk;
+  const int b = blockIdx.y;
   const int cpg = C / groups;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total_chunks;
-       i += (long long)gridDim.x * blockDim.x) {
-    const int ck = (int)(i % nchunk);
-    const long long pix = i / nchunk;
-    const int b = (int)(pix / HW);
-    const int c0 = ck * 8;
-    const bf16x8 xv = *(const bf16x8*)(x + pix * C + c0);
-    const bf16x8 dv = *(const bf16x8*)(dy + pix * C + c0);
+  const int c0 = ck * 8;
+  float mean[8], rstd[8], gm[8], bt[8], S1[8], S2[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const long long sg = (long long)b * groups + (c0 + j) / cpg;
+    mean[j] = stats[sg * 2]; rstd[j] = stats[sg * 2 + 1];
+    S1[j] = sums[sg * 2]; S2[j] = sums[sg * 2 + 1];
+    gm[j] = gamma[c0 + j]; bt[j] = beta[c0 + j];
+  }
+  const int p0 = blockIdx.x * pix_per_block, p1 = min(p0 + pix_per_block, HW);
+  for (int p = p0 + pl; p < p1; p += ppb) {
+    const long long off = ((long long)b * HW + p) * C + c0;
+    const bf16x8 xv = *(const bf16x8*)(x + off);
+    const bf16x8 dv = *(const bf16x8*)(dy + off);
     bf16x8 o;
-    if (accum) o = *(const bf16x8*)(dx + pix * C + c0);
+    if (accum) o = *(const bf16x8*)(dx + off);
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      const int g = (c0 + j) / cpg;
-      const long long sg = (long long)b * groups + g;
-      const float mean = stats[sg * 2], rstd = stats[sg * 2 + 1];
-      const float S1 = sums[sg * 2], S2 = sums[sg * 2 + 1];
-      const float gmm = gamma[c0 + j];
-      const float xh = ((float)xv[j] - mean) * rstd;
+      const float xh = ((float)xv[j] - mean[j]) * rstd[j];
       float d = (float)dv[j];
-      if (silu) d *= silu_grad(xh * gmm + beta[c0 + j]);
-      d *= gmm;
-      float r = rstd * (d - S1 - xh * S2);
+      if (silu) d *= silu_grad(xh * gm[j] + bt[j]);
+      d *= gm[j];
+      float r = rstd[j] * (d - S1[j] - xh * S2[j]);
       if (accum) r += (float)o[j];
       o[j] = (bf16)r;
     }
-    *(bf16x8*)(dx + pix * C + c0) = o;
+    *(bf16x8*)(dx + off) = o;
   }
 }
 
@@ -191,7 +210,7 @@ static int gn_geometry(int HW, int C, int* threads, int* ppblk, int* nblk, size_
   int ppb = 256 / nchunk;
   if (ppb < 1) ppb = 1;
   *threads = nchunk * ppb;
-  int per = ppb * 64;
+  int per = ppb * 16;
   if (per > HW) per = HW;
   *ppblk = per;
   *nblk = cdiv(HW, per);
@@ -218,12 +237,10 @@ int launch_groupnorm_fwd(const bf16* x, const float* gamma, const float* beta, b
   PROF_BEGIN(4, 0.0, 2.0 * 3.0 * B * (double)HW * C, s);
   hipLaunchKernelGGL(gn_stats_kernel<0>, dim3(nblk, B), dim3(threads), lds, s, x, nullptr, nullptr, nullptr, nullptr,
                      partial, HW, C, groups, ppblk, 0);
-  hipLaunchKernelGGL(gn_finalize_kernel, dim3(cdiv(B * groups, 64)), dim3(64), 0, s, partial, stats, B * groups,
-                     groups, nblk, (double)HW * (C / groups), eps, 0);
-  const long long total = (long long)B * HW * (C / 8);
-  const int grid = (int)(cdivl(total, 256) < 4096 ? cdivl(total, 256) : 4096);
-  hipLaunchKernelGGL(gn_apply_kernel, dim3(grid), dim3(256), 0, s, x, gamma, beta, stats, y, HW, C, groups, silu,
-                     total);
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(B * groups), dim3(64), 0, s, partial, stats, B * groups, groups, nblk,
+                     (double)HW * (C / groups), eps, 0);
+  hipLaunchKernelGGL(gn_apply_kernel, dim3(nblk, B), dim3(threads), 0, s, x, gamma, beta, stats, y, HW, C, groups,
+                     silu, ppblk);
   PROF_END(s);
   HIPCHK(hipGetLastError());
   return PEA_OK;
@@ -242,12 +259,10 @@ int launch_groupnorm_bwd(const bf16* x, const bf16* dy, const float* gamma, cons
   PROF_BEGIN(4, 0.0, 2.0 * 5.0 * B * (double)HW * C, s);
   hipLaunchKernelGGL(gn_stats_kernel<1>, dim3(nblk, B), dim3(threads), lds, s, x, dy, gamma, beta, stats, partial, HW,
                      C, groups, ppblk, silu);
-  hipLaunchKernelGGL(gn_finalize_kernel, dim3(cdiv(B * groups, 64)), dim3(64), 0, s, partial, sums, B * groups, groups,
-                     nblk, (double)HW * (C / groups), 0.f, 1);
-  const long long total = (long long)B * HW * (C / 8);
-  const int grid = (int)(cdivl(total, 256) < 4096 ? cdivl(total, 256) : 4096);
-  hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(grid), dim3(256), 0, s, x, dy, gamma, beta, stats, sums, dx, HW, C,
-                     groups, silu, accum, total);
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(B * groups), dim3(64), 0, s, partial, sums, B * groups, groups, nblk,
+                     (double)HW * (C / groups), 0.f, 1);
+  hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(nblk, B), dim3(threads), 0, s, x, dy, gamma, beta, stats, sums, dx, HW,
+                     C, groups, silu, accum, ppblk);
   PROF_END(s);
   HIPCHK(hipGetLastError());
   return PEA_OK;

@@ -68,7 +68,10 @@ struct AttnP {
   bf16 *dQ, *dK, *dV; int lddq, lddk, lddv;
   float* delta;                    // [B][H][Sq] scratch: rowsum(dO * O)
   int accum_dq, accum_dkv;         // += into existing gradients
+  float* dkv_part; int nsplit;     // optional fp32 scratch (attention_bwd_scratch_bytes) enabling the query split
 };
+int attention_bwd_nsplit(int B, int H, int Sq, int Skv);
+size_t attention_bwd_scratch_bytes(int B, int H, int Sq, int Skv);
 int launch_attention_fwd(const AttnP& p, hipStream_t s);
 int launch_attention_bwd(const AttnP& p, hipStream_t s);
 

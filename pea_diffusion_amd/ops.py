@@ -140,9 +140,11 @@ def attention_bwd(q, k, v, o, do, lse, heads, scale=None):
     scale = scale if scale is not None else 64 ** -0.5
     dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
     delta = torch.empty(B, heads, Sq, device=q.device, dtype=torch.float32)
+    nb = lib().pea_op_attention_bwd_scratch_bytes(B, heads, Sq, Skv)
+    scratch = torch.empty(nb, device=q.device, dtype=torch.uint8) if nb else None
     check(lib().pea_op_attention_bwd(ptr(q), q.stride(1), ptr(k), k.stride(1), ptr(v), v.stride(1), ptr(o), C, ptr(do),
                                      C, ptr(lse), ptr(delta), ptr(dq), C, ptr(dk), C, ptr(dv), C, B, heads, Sq, Skv,
-                                     scale, 0, 0, stream_ptr()))
+                                     scale, 0, 0, ptr(scratch), stream_ptr()))
     return dq, dk, dv
 
 

@@ -199,7 +199,7 @@ def _attn_ref(q, k, v, H):
 
 @pytest.mark.parametrize("use_tr", [1, 0])
 @pytest.mark.parametrize("B,H,Sq,Skv", [(2, 2, 256, 256), (1, 3, 128, 77), (2, 2, 16, 16), (1, 2, 1024, 200),
-                                        (1, 1, 64, 7)])
+                                        (1, 1, 64, 7), (2, 2, 1024, 77), (1, 2, 576, 77)])
 def test_attention_fwd_bwd(ops, use_tr, B, H, Sq, Skv):
     from pea_diffusion_amd._lib import lib
     lib().pea_debug_set_attn_tr(use_tr)
