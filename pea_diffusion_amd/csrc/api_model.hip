@@ -238,6 +238,17 @@ int pea_train_step(void* h, const float* latents, const float* noise, const long
                              teacher_neg, teacher_pooled, time_ids, grad_scale, grads, accumulate, losses,
                              (hipStream_t)stream);
 }
+int pea_trainer_set_option(void* h, const char* name, int value) {
+  NOTNULL(h, "pea_trainer_set_option");
+  Trainer* t = (Trainer*)h;
+  if (!strcmp(name, "two_stream")) t->two_stream = value;
+  else if (!strcmp(name, "nan_guard")) t->nan_guard = value;
+  else {
+    pea_set_error("pea_trainer_set_option: unknown option '%s'", name);
+    return PEA_E_INVALID;
+  }
+  return PEA_OK;
+}
 int pea_trainer_export(void* h, int which, float* out, void* stream) {
   NOTNULL(h, "pea_trainer_export");
   Trainer* t = (Trainer*)h;

@@ -30,8 +30,81 @@ __device__ __forceinline__ void wait_vmcnt() {
   else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
   else if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
   else if constexpr (N == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+  else if constexpr (N == 9) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+  else if constexpr (N == 13) asm volatile("s_waitcnt vmcnt(13)" ::: "memory");
+  else if constexpr (N == 18) asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
   else if constexpr (N == 24) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+  else if constexpr (N == 26) asm volatile("s_waitcnt vmcnt(26)" ::: "memory");
   else static_assert(N == 0, "add the vmcnt literal");
+}
+
+// ---- epilogue shared by both kernels.  acc[ni][mi][4g+j] = D[n = 8g + 4h + j][m = lane&31]
+template <int MI, int NI>
+__device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x16 (&acc)[NI][MI], int m_base, int n_base, int frow,
+                                              int fh) {
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi) {
+    const int m = m_base + mi * 32 + frow;
+    if (m >= p.M) continue;
+    const int bidx = p.rowvec ? m / p.rows_per_batch : 0;
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int n = n_base + ni * 32 + 8 * g + 4 * fh;
+        if (n >= p.N) continue;
+        float v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = acc[ni][mi][4 * g + j] * p.alpha;
+        if (p.bias) {
+          const f32x4 b = *(const f32x4*)(p.bias + n);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] += b[j];
+        }
+        if (p.rowvec) {
+          const bf16x4 rv = *(const bf16x4*)(p.rowvec + (long long)bidx * p.ldrv + n);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] += (float)rv[j];
+        }
+        if (p.preact) {
+          bf16x4 o;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) o[j] = (bf16)v[j];
+          *(bf16x4*)(p.preact + (long long)m * p.ldpre + n) = o;
+        }
+        if (p.act == 1) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] = gelu_erf(v[j]);
+        } else if (p.act == 2) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] = siluf_(v[j]);
+        }
+        if (p.res) {
+          const bf16x4 rr = *(const bf16x4*)(p.res + (long long)m * p.ldres + n);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] += (float)rr[j];
+        }
+        if (p.out_f32) {
+          float* cp = (float*)p.C + (long long)m * p.ldc + n;
+          f32x4 o;
+          if (p.accum_f32) {
+            o = *(const f32x4*)cp;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] += v[j];
+          } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] = v[j];
+          }
+          *(f32x4*)cp = o;
+        } else {
+          bf16x4 o;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) o[j] = (bf16)v[j];
+          *(bf16x4*)((bf16*)p.C + (long long)m * p.ldc + n) = o;
+        }
+      }
+    }
+  }
 }
 
 // Block tile BM x BN x 64, WM x WN waves (each (BM/WM) x (BN/WN), built from 32x32x16 MFMAs), S-stage LDS
@@ -175,70 +248,194 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmP p) 
     cur = cur + 1 == S ? 0 : cur + 1;
   }
 
-  // ---- epilogue.  acc[ni][mi][4g+j] = D[n = 8g + 4h + j][m = lane&31]
+  gemm_epilogue<MI, NI>(p, acc, bm * BM + wr * (BM / WM), bn * BN + wc * (BN / WN), frow, fh);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Software-pipelined kernel.  Same tiling / LDS image as above, but inside a K-step (4 k16 sub-steps):
+//   * fragments are double-buffered in registers: sub-step s issues the ds_reads of sub-step s+1
+//     (or of the next tile's sub-step 0) before its own MFMAs, so LDS latency hides under MFMA time;
+//   * the LDS-DMA pieces of tile t+S-1 are spread over sub-steps 0..2 instead of being issued in one
+//     burst, so their issue slots sit behind already-queued MFMAs of the same wave;
+//   * the single barrier of the K-step sits before sub-step 3's prefetch of the NEXT tile: "tile t+1
+//     landed for every wave" and "every wave has issued all its reads of tile t-1 / t".
+// BN may be 160 (5 x 32): every SDXL width is a multiple of 160, so 128x160 / 256x160 tiles cover the
+// M = 4096 / 8192 GEMMs of the 32^2 level with exactly 256 workgroups (one per CU).
+template <int MODE, int BM, int BN, int WM, int WN, int S>
+__global__ __launch_bounds__(WM * WN * 64) void gemm_pipe_kernel(const GemmP p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int NW = WM * WN;
+  constexpr int STAGE = (BM + BN) * 128;
+  constexpr int A_BYTES = BM * 128;
+  constexpr int PA = BM / 8 / NW, PB = BN / 8 / NW;
+  constexpr int PP = PA + PB;
+  constexpr int MI = BM / WM / 32, NI = BN / WN / 32;
+  static_assert(BM % (8 * NW) == 0 && BN % (8 * NW) == 0, "tile / wave split");
+  static_assert((BM / WM) % 32 == 0 && (BN / WN) % 32 == 0, "wave tile");
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave / WN, wc = wave % WN;
+
+  const int nbm = (p.M + BM - 1) / BM, nbn = (p.N + BN - 1) / BN;
+  const int nwg = nbm * nbn;
+  int bid = blockIdx.x;
+  {
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int GROUP = 8;
+  const int per_group = GROUP * nbn;
+  const int gid = bid / per_group;
+  const int first_m = gid * GROUP;
+  const int gsize = min(nbm - first_m, GROUP);
+  const int bm = first_m + (bid % per_group) % gsize;
+  const int bn = (bid % per_group) / gsize;
+
+  const int lrow = lane >> 3, cpos = lane & 7;
+  const bf16* a_src[PA];
+  int a_iy0[PA], a_ix0[PA];
+  const bf16* w_src[PB];
 #pragma unroll
-  for (int mi = 0; mi < MI; ++mi) {
-    const int m = bm * BM + wr * (BM / WM) + mi * 32 + frow;
-    if (m >= p.M) continue;
-    const int bidx = p.rowvec ? m / p.rows_per_batch : 0;
-#pragma unroll
-    for (int ni = 0; ni < NI; ++ni) {
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int n = bn * BN + wc * (BN / WN) + ni * 32 + 8 * g + 4 * fh;
-        if (n >= p.N) continue;
-        float v[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = acc[ni][mi][4 * g + j] * p.alpha;
-        if (p.bias) {
-          const f32x4 b = *(const f32x4*)(p.bias + n);
-#pragma unroll
-          for (int j = 0; j < 4; ++j) v[j] += b[j];
-        }
-        if (p.rowvec) {
-          const bf16x4 rv = *(const bf16x4*)(p.rowvec + (long long)bidx * p.ldrv + n);
-#pragma unroll
-          for (int j = 0; j < 4; ++j) v[j] += (float)rv[j];
-        }
-        if (p.preact) {
-          bf16x4 o;
-#pragma unroll
-          for (int j = 0; j < 4; ++j) o[j] = (bf16)v[j];
-          *(bf16x4*)(p.preact + (long long)m * p.ldpre + n) = o;
-        }
-        if (p.act == 1) {
-#pragma unroll
-          for (int j = 0; j < 4; ++j) v[j] = gelu_erf(v[j]);
-        } else if (p.act == 2) {
-#pragma unroll
-          for (int j = 0; j < 4; ++j) v[j] = siluf_(v[j]);
-        }
-        if (p.res) {
-          const bf16x4 rr = *(const bf16x4*)(p.res + (long long)m * p.ldres + n);
-#pragma unroll
-          for (int j = 0; j < 4; ++j) v[j] += (float)rr[j];
-        }
-        if (p.out_f32) {
-          float* cp = (float*)p.C + (long long)m * p.ldc + n;
-          f32x4 o;
-          if (p.accum_f32) {
-            o = *(const f32x4*)cp;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) o[j] += v[j];
-          } else {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) o[j] = v[j];
-          }
-          *(f32x4*)cp = o;
-        } else {
-          bf16x4 o;
-#pragma unroll
-          for (int j = 0; j < 4; ++j) o[j] = (bf16)v[j];
-          *(bf16x4*)((bf16*)p.C + (long long)m * p.ldc + n) = o;
-        }
-      }
+  for (int j = 0; j < PA; ++j) {
+    const int r = (wave * PA + j) * 8 + lrow;
+    const int chunk = cpos ^ ((r >> 1) & 7);
+    int gm = bm * BM + r;
+    gm = gm < p.M ? gm : p.M - 1;
+    if (MODE == 0) {
+      a_src[j] = p.A + (long long)gm * p.lda + chunk * 8;
+      a_iy0[j] = a_ix0[j] = 0;
+    } else {
+      const int hw = p.Ho * p.Wo;
+      const int b = gm / hw;
+      const int rem = gm - b * hw;
+      const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+      a_iy0[j] = oy * p.stride - 1;
+      a_ix0[j] = ox * p.stride - 1;
+      a_src[j] = p.A + (long long)b * p.Hs * p.Ws * p.Cin + chunk * 8;
     }
   }
+#pragma unroll
+  for (int j = 0; j < PB; ++j) {
+    const int r = (wave * PB + j) * 8 + lrow;
+    const int chunk = cpos ^ ((r >> 1) & 7);
+    int gn = bn * BN + r;
+    gn = gn < p.N ? gn : p.N - 1;
+    w_src[j] = p.W + (long long)gn * p.ldw + chunk * 8;
+  }
+  const int Hv = p.Hs << p.shift, Wv = p.Ws << p.shift;
+
+  // issue the LDS-DMA pieces [j0, j1) of the tile whose K offset is k0 into ring slot `st`
+  auto issue = [&](int st, int k0, int j0, int j1) {
+    char* base = smem + st * STAGE;
+    int ky = 0, kx = 0, c0 = 0;
+    if (MODE == 1) {
+      const int tap = k0 / p.Cin;
+      c0 = k0 - tap * p.Cin;
+      ky = tap / 3;
+      kx = tap - ky * 3;
+    }
+#pragma unroll
+    for (int j = 0; j < PP; ++j) {
+      if (j < j0 || j >= j1) continue;
+      if (j < PA) {
+        const bf16* src;
+        if (MODE == 0) {
+          src = a_src[j] + k0;
+        } else {
+          const int iy = a_iy0[j] + ky, ix = a_ix0[j] + kx;
+          bool ok = ((unsigned)iy < (unsigned)Hv) && ((unsigned)ix < (unsigned)Wv);
+          if (p.parity) ok = ok && (((iy | ix) & 1) == 0);
+          const int sy = iy >> p.shift, sx = ix >> p.shift;
+          src = ok ? a_src[j] + ((long long)sy * p.Ws + sx) * p.Cin + c0 : p.zeros;
+        }
+        __builtin_amdgcn_global_load_lds(PEA_GLB(src), PEA_LDS(base + (wave * PA + j) * 1024), 16, 0, 0);
+      } else {
+        const int jb = j - PA;
+        __builtin_amdgcn_global_load_lds(PEA_GLB(w_src[jb] + k0), PEA_LDS(base + A_BYTES + (wave * PB + jb) * 1024),
+                                         16, 0, 0);
+      }
+    }
+  };
+
+  f32x16 acc[NI][MI];
+#pragma unroll
+  for (int i = 0; i < NI; ++i)
+#pragma unroll
+    for (int j = 0; j < MI; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int nt = p.K / BK;
+  const int frow = lane & 31, fh = lane >> 5;
+  const int a_row0 = wr * (BM / WM) + frow, w_row0 = wc * (BN / WN) + frow;
+#pragma unroll
+  for (int i = 0; i < S - 1; ++i)
+    if (i < nt) issue(i, i * BK, 0, PP);
+  if (nt >= S - 1) wait_vmcnt<(S - 2) * PP>();
+  else wait_vmcnt<0>();
+  __builtin_amdgcn_s_barrier();
+
+  bf16x8 af[2][MI], wf[2][NI];
+  auto load_frags = [&](int which, const char* tile, int s) {
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) af[which][mi] = *(const bf16x8*)(tile + swz_off(a_row0 + mi * 32, 2 * s + fh));
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+      wf[which][ni] = *(const bf16x8*)(tile + A_BYTES + swz_off(w_row0 + ni * 32, 2 * s + fh));
+  };
+  load_frags(0, smem, 0);
+
+  constexpr int J1 = (PP + 2) / 3, J2 = (2 * PP + 2) / 3;     // piece ranges of the three issue slots
+  int cur = 0;
+  for (int t = 0; t < nt; ++t) {
+    const char* tile = smem + cur * STAGE;
+    int nxt = cur + 1 == S ? 0 : cur + 1;
+    int refill = cur == 0 ? S - 1 : cur - 1;                   // ring slot of tile t-1 == slot of tile t+S-1
+    const bool more = t + S - 1 < nt;
+    const int kf = (t + S - 1) * BK;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      if (s == 3) {
+        if (t + 1 < nt) {
+          if (more) wait_vmcnt<(S - 2) * PP>();
+          else wait_vmcnt<0>();
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          __builtin_amdgcn_s_barrier();
+          load_frags((s + 1) & 1, smem + nxt * STAGE, 0);
+        }
+      } else {
+        load_frags((s + 1) & 1, tile, s + 1);
+      }
+      if (more) {
+        if (s == 0) issue(refill, kf, 0, J1);
+        else if (s == 1) issue(refill, kf, J1, J2);
+        else if (s == 2) issue(refill, kf, J2, PP);
+      }
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+          acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[s & 1][ni], af[s & 1][mi], acc[ni][mi], 0, 0, 0);
+    }
+    cur = nxt;
+  }
+  gemm_epilogue<MI, NI>(p, acc, bm * BM + wr * (BM / WM), bn * BN + wc * (BN / WN), frow, fh);
+}
+
+template <int MODE, int BM, int BN, int WM, int WN, int S>
+static int launch_pipe(const GemmP& p, hipStream_t stream) {
+  constexpr int lds = S * (BM + BN) * 128;
+  static_assert(lds <= 160 * 1024, "LDS budget");
+  static bool attr_set = false;
+  if (!attr_set) {
+    HIPCHK(hipFuncSetAttribute((const void*)gemm_pipe_kernel<MODE, BM, BN, WM, WN, S>,
+                               hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    attr_set = true;
+  }
+  const int grid = cdiv(p.M, BM) * cdiv(p.N, BN);
+  hipLaunchKernelGGL((gemm_pipe_kernel<MODE, BM, BN, WM, WN, S>), dim3(grid), dim3(WM * WN * 64), lds, stream, p);
+  return PEA_OK;
 }
 
 // ---- variant table (tile shape x wave grid x ring depth); the launcher picks one per problem shape
@@ -269,22 +466,30 @@ static int launch_variant(const GemmP& p, hipStream_t stream) {
     case 5: rc = launch_variant<MODE, 256, 256, 2, 4, 2>(p, stream); break; \
     case 6: rc = launch_variant<MODE, 128, 256, 2, 4, 3>(p, stream); break; \
     case 7: rc = launch_variant<MODE, 256, 128, 2, 2, 3>(p, stream); break; \
+    case 8: rc = launch_pipe<MODE, 128, 160, 4, 1, 4>(p, stream); break; \
+    case 9: rc = launch_pipe<MODE, 256, 160, 4, 1, 3>(p, stream); break; \
+    case 10: rc = launch_pipe<MODE, 256, 128, 4, 2, 3>(p, stream); break; \
+    case 11: rc = launch_pipe<MODE, 128, 128, 2, 2, 3>(p, stream); break; \
+    case 12: rc = launch_pipe<MODE, 256, 256, 2, 4, 2>(p, stream); break; \
+    case 13: rc = launch_pipe<MODE, 128, 160, 4, 1, 3>(p, stream); break; \
     default: rc = launch_variant<MODE, 128, 128, 2, 2, 2>(p, stream); break; \
   }
 
 static int pick_variant(const GemmP& p) {
   if (g_gemm_variant >= 0) return g_gemm_variant;
-  // measured on the step's shapes (scripts/gemm_bench.py / gemm_cold_bench.py):
-  //   0 = 128x128, 4 waves, 2 stages (2 blocks/CU)   4 = 256x128, 8 waves, 3 stages   5 = 256x256, 8 waves, 2 stages
+  // measured on the step's shapes with scripts/gemm_bench.py (profiles/r01_gemm_variants.log):
+  //   13 = pipelined 128x160, 4 waves, 3 stages     9 = pipelined 256x160, 4 waves, 3 stages
+  //   10 = pipelined 256x128, 8 waves, 3 stages    12 = pipelined 256x256, 8 waves, 2 stages
+  //   11 = pipelined 128x128, 4 waves, 3 stages     5 = 256x256, 8 waves, 2 stages (plain loop)
   if (p.mode == 1) {
-    if (p.N <= 384) return 4;                  // 128^2-level convs (N = 320)
-    if (p.M >= 16384) return 5;                // 64^2-level convs (N = 640)
-    return 4;                                  // 32^2-level convs (M = 4096, N = 1280, K >= 11520)
+    if (p.N <= 384) return p.K >= 5760 ? 9 : 10;   // 128^2-level convs (N = 320)
+    if (p.M >= 16384) return 9;                     // 64^2-level convs (N = 640)
+    return 13;                                      // 32^2-level convs (M = 4096, N = 1280)
   }
-  if (p.M < 1024) return 0;                    // cross-attention K|V projections, embeddings
-  if (p.N <= 1280 && p.M <= 8192 && p.K >= 2560) return 4;
-  if (p.N >= 3840 && p.M >= 8192) return 5;
-  return 0;
+  if (p.M < 1024) return 11;                        // cross-attention K|V projections, embeddings, adapter
+  if (p.N <= 1280) return 13;                       // every N in {640, 1280}: 160-wide tiles fill the chip exactly
+  if (p.M >= 8192) return 12;
+  return p.N >= 8192 ? 10 : 5;
 }
 
 int launch_gemm(const GemmP& p, hipStream_t stream) {

@@ -11,7 +11,8 @@ L = ctypes.CDLL(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__f
 BF = torch.bfloat16
 variants = [int(v) for v in (sys.argv[1].split(",") if len(sys.argv) > 1 else "0,1,2,3,4,5,6,7".split(","))]
 NAMES = {0: "128x128 w2x2 S2", 1: "128x128 w2x2 S3", 2: "128x128 w2x2 S4", 3: "256x128 w4x2 S2", 4: "256x128 w4x2 S3",
-         5: "256x256 w2x4 S2", 6: "128x256 w2x4 S3", 7: "256x128 w2x2 S3"}
+         5: "256x256 w2x4 S2", 6: "128x256 w2x4 S3", 7: "256x128 w2x2 S3", 8: "P128x160 w4x1 S4", 9: "P256x160 w4x1 S3",
+         10: "P256x128 w4x2 S3", 11: "P128x128 w2x2 S3", 12: "P256x256 w2x4 S2", 13: "P128x160 w4x1 S3"}
 
 def timeit(fn, iters=20):
     fn(); torch.cuda.synchronize()
@@ -21,7 +22,7 @@ def timeit(fn, iters=20):
     e.record(); torch.cuda.synchronize()
     return s.elapsed_time(e) / iters * 1e-3
 
-shapes = [(4096, 1280, 1280), (4096, 1280, 5120), (4096, 3840, 1280), (4096, 10240, 1280), (16384, 640, 640),
+shapes = [(8192, 1280, 1280), (8192, 1280, 5120), (8192, 10240, 1280), (4096, 1280, 1280), (4096, 1280, 5120), (4096, 3840, 1280), (4096, 10240, 1280), (16384, 640, 640),
           (16384, 640, 2560), (16384, 1920, 640), (16384, 5120, 640), (308, 2560, 2048), (4096, 1280, 2560), (8192, 8192, 8192)]
 print("variants:", {v: NAMES[v] for v in variants})
 for (M, N, K) in shapes:
