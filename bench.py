@@ -135,6 +135,7 @@ def main():
     ap.add_argument("--cpu-budget", type=float, default=40.0)
     ap.add_argument("--cpu-baseline-worker", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--dump-prof", default="", help="write every profiled launch (shape-tagged) to this CSV")
     ap.add_argument("--breakdown", action="store_true", help="print the per-kernel-family table to stderr")
     args = ap.parse_args()
     if args.cpu_baseline_worker:
@@ -206,6 +207,8 @@ def main():
             step()
         torch.cuda.synchronize()
         L.pea_prof_enable(0)
+        if args.dump_prof:
+            L.pea_prof_dump(args.dump_prof.encode())
         L.pea_trainer_set_option(trainer._h, b"two_stream", 1)
         fams = []
         for f in range(8):

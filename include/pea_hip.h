@@ -221,12 +221,15 @@ int pea_trainer_export(void* tr, int which, float* out, void* stream);
 void pea_prof_enable(int on);
 void pea_prof_reset(void);
 const char* pea_prof_family_name(int fam);
+/* CSV of every recorded launch: family, ms, flops, bytes, shape tags (GEMM: M,N,K,epilogue flags) */
+int pea_prof_dump(const char* path);
 int pea_prof_report(int fam, double* ms, double* flops, double* bytes, long long* launches);
 
 /* debugging aid for the parity tests: 1 = ds_read_b64_tr_b16 transpose reads (default), 0 = scalar gathers */
 void pea_debug_set_attn_tr(int v);
 /* benchmark aid: force GEMM tile variant (>= 0) or restore the shape-based choice (-1) */
 void pea_debug_set_gemm_variant(int v);
+void pea_debug_set_gemm_lds_epilogue(int v);
 
 #ifdef __cplusplus
 }

@@ -143,35 +143,45 @@ __global__ __launch_bounds__(256) void attn_q_kernel(const AttnP p) {
     const int kv0 = t * 64;
     bf16x8 pf[4];   // P^T (fwd) or dS^T (dQ) as B-operand fragments, k-permuted
     if (MODE == 0) {
-      float mx = -INFINITY;
+      // online softmax in the log2 domain: p = exp2(c*s - c*m); the scale rides in the FMA, the running max is kept
+      // on the RAW scores (c > 0), keys beyond Skv are masked only in the tile that contains them, and the O rescale
+      // is skipped when no lane's running max moved (exact: alpha == 1 for every lane).
+      const bool boundary = kv0 + 64 > p.Skv;            // wave-uniform
+      if (boundary) {
 #pragma unroll
-      for (int kb = 0; kb < 2; ++kb)
+        for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int key = kv0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
-          float v = sacc[kb][r] * c;
-          v = key < p.Skv ? v : -INFINITY;
-          sacc[kb][r] = v;
-          mx = fmaxf(mx, v);
-        }
+          for (int r = 0; r < 16; ++r) {
+            const int key = kv0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+            sacc[kb][r] = key < p.Skv ? sacc[kb][r] : -INFINITY;
+          }
+      }
+      float mx = fmaxf(sacc[0][0], sacc[1][0]);
+#pragma unroll
+      for (int r = 1; r < 16; ++r) mx = fmaxf(mx, fmaxf(sacc[0][r], sacc[1][r]));
       mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
       const float m_new = fmaxf(m_run, mx);
-      const float alpha = exp2f(m_run - m_new);
-      m_run = m_new;
+      const bool moved = m_new != m_run;
+      const float mc = m_new * c;
       float ls = 0.f;
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const float e = exp2f(sacc[kb][r] - m_new);
+          const float e = exp2f(fmaf(sacc[kb][r], c, -mc));
           sacc[kb][r] = e;
           ls += e;
         }
-      l_run = l_run * alpha + ls;
+      if (__any(moved)) {
+        const float alpha = exp2f((m_run - m_new) * c);   // m_run = -inf on the first tile -> 0
+        l_run *= alpha;
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) oacc[i][r] *= alpha;
+          for (int r = 0; r < 16; ++r) oacc[i][r] *= alpha;
+      }
+      l_run += ls;
+      m_run = m_new;
     } else {
       // P^T = exp2(c S^T - lse2[q]);  dP^T = V . dO^T;  dS^T = P^T (dP^T - delta[q]) scale
       f32x16 dpacc[2];
@@ -190,7 +200,8 @@ __global__ __launch_bounds__(256) void attn_q_kernel(const AttnP p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int key = kv0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
-          const float pr = key < p.Skv ? exp2f(sacc[kb][r] * c - lse2) : 0.f;
+          float pr = exp2f(fmaf(sacc[kb][r], c, -lse2));
+          if (kv0 + 64 > p.Skv) pr = key < p.Skv ? pr : 0.f;      // uniform branch: only the last key tile masks
           sacc[kb][r] = pr * (dpacc[kb][r] - dlt) * p.scale;
         }
     }
@@ -218,7 +229,7 @@ __global__ __launch_bounds__(256) void attn_q_kernel(const AttnP p) {
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
     inv = 1.f / l_tot;
     if (p.lse && qvalid && fh == 0)
-      p.lse[((long long)b * p.H + head) * p.Sq + qrow] = (m_run + log2f(l_tot)) * 0.6931471805599453f;
+      p.lse[((long long)b * p.H + head) * p.Sq + qrow] = m_run * p.scale + log2f(l_tot) * 0.6931471805599453f;
   }
   if (!qvalid) return;
   bf16* Ob = MODE == 0 ? p.O + (long long)b * p.Sq * p.ldo + head * 64 + (long long)qrow * p.ldo
@@ -236,6 +247,17 @@ __global__ __launch_bounds__(256) void attn_q_kernel(const AttnP p) {
       *(bf16x4*)dst = o;
     }
 }
+
+// per-row constants of a 64-query tile (lse, delta) -> LDS, 4 bytes per lane, issued by wave 0 only
+__device__ __forceinline__ void stage_rowconst(const float* lse, const float* dlt, int r0, int rmax, char* dst,
+                                               int wave, int lane) {
+  if (wave != 0) return;
+  int r = r0 + lane;
+  r = r < rmax ? r : rmax - 1;
+  __builtin_amdgcn_global_load_lds(PEA_GLB(lse + r), PEA_LDS(dst), 4, 0, 0);
+  __builtin_amdgcn_global_load_lds(PEA_GLB(dlt + r), PEA_LDS(dst + 256), 4, 0, 0);
+}
+#define DKV_STAGE (2 * TILE_BYTES + 512)
 
 // ============================================================================= dK / dV
 // workgroup = 4 waves = 128 keys (wave owns 32, key on the lane); loops over 64-query tiles.
@@ -284,6 +306,7 @@ __global__ __launch_bounds__(256) void attn_dkv_kernel(const AttnP p) {
   if (t_begin < nt) {
     stage_tile(Qb, p.ldq, t_begin * 64, p.Sq, smem, wave, lane);
     stage_tile(dOb, p.lddo, t_begin * 64, p.Sq, smem + TILE_BYTES, wave, lane);
+    stage_rowconst(lseb, dltb, t_begin * 64, p.Sq, smem + 2 * TILE_BYTES, wave, lane);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
@@ -291,12 +314,14 @@ __global__ __launch_bounds__(256) void attn_dkv_kernel(const AttnP p) {
   for (int t = t_begin; t < nt; ++t) {
     const int cur = (t - t_begin) & 1;
     if (t + 1 < nt) {
-      char* nx = smem + (cur ^ 1) * 2 * TILE_BYTES;
+      char* nx = smem + (cur ^ 1) * DKV_STAGE;
       stage_tile(Qb, p.ldq, (t + 1) * 64, p.Sq, nx, wave, lane);
       stage_tile(dOb, p.lddo, (t + 1) * 64, p.Sq, nx + TILE_BYTES, wave, lane);
+      stage_rowconst(lseb, dltb, (t + 1) * 64, p.Sq, nx + 2 * TILE_BYTES, wave, lane);
     }
-    const char* Qs = smem + cur * 2 * TILE_BYTES;
+    const char* Qs = smem + cur * DKV_STAGE;
     const char* dOs = Qs + TILE_BYTES;
+    const float* rc = (const float*)(Qs + 2 * TILE_BYTES);
     if (wave_active) {
       // S[q][key] = Q . K^T ; dP[q][key] = dO . V^T   (rows q in registers, key on the lane)
       f32x16 sacc[2], dpacc[2];
@@ -320,8 +345,8 @@ __global__ __launch_bounds__(256) void attn_dkv_kernel(const AttnP p) {
           const int q = t * 64 + qb * 32 + 8 * g + 4 * fh;     // 4 consecutive query rows
           f32x4 l4, d4;
           if (q < p.Sq) {                                      // Sq % 4 == 0: all-or-nothing
-            l4 = *(const f32x4*)(lseb + q);
-            d4 = *(const f32x4*)(dltb + q);
+            l4 = *(const f32x4*)(rc + qb * 32 + 8 * g + 4 * fh);
+            d4 = *(const f32x4*)(rc + 64 + qb * 32 + 8 * g + 4 * fh);
           } else {
             l4 = (f32x4){INFINITY, INFINITY, INFINITY, INFINITY};
             d4 = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -329,7 +354,7 @@ __global__ __launch_bounds__(256) void attn_dkv_kernel(const AttnP p) {
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
             const int r = 4 * g + j;
-            const float pr = kvalid ? exp2f(sacc[qb][r] * c - l4[j] * LOG2E) : 0.f;
+            const float pr = kvalid ? exp2f(fmaf(sacc[qb][r], c, -l4[j] * LOG2E)) : 0.f;
             const float ds = pr * (dpacc[qb][r] - d4[j]) * p.scale;
             const int ks = qb * 2 + (g >> 1), e = (g & 1) * 4 + j;
             pfr[ks][e] = (bf16)pr;
@@ -468,6 +493,7 @@ int launch_attention_fwd(const AttnP& p, hipStream_t s) {
   if (rc) return rc;
   SHAPECHK(p.ldo % 4 == 0, "attention: ldo %% 4");
   const dim3 grid(cdiv(p.Sq, 128), p.H, p.B);
+  if (g_prof_on) { g_prof_tag[0] = p.B * p.H; g_prof_tag[1] = p.Sq; g_prof_tag[2] = p.Skv; }
   PROF_BEGIN(2, 4.0 * p.B * p.H * (double)p.Sq * p.Skv * 64, 2.0 * p.B * p.H * 64 * (2.0 * p.Sq + 2.0 * p.Skv), s);
   if (g_attn_use_tr)
     hipLaunchKernelGGL((attn_q_kernel<0, true>), grid, dim3(256), 4 * TILE_BYTES, s, p);
@@ -486,6 +512,7 @@ int launch_attention_bwd(const AttnP& p0, hipStream_t s) {
   SHAPECHK(p.lse && p.delta && p.dO && p.O, "attention bwd: lse/delta/dO/O required");
   const long long total = (long long)p.B * p.Sq * p.H * 8;
   // algorithmic: 5 products (S, dP, dV, dK, dQ) = 10*B*H*Sq*Skv*64 flops (the two-kernel form recomputes S and dP)
+  if (g_prof_on) { g_prof_tag[0] = p.B * p.H; g_prof_tag[1] = p.Sq; g_prof_tag[2] = p.Skv; }
   PROF_BEGIN(3, 10.0 * p.B * p.H * (double)p.Sq * p.Skv * 64, 2.0 * p.B * p.H * 64 * (4.0 * p.Sq + 4.0 * p.Skv), s);
   hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)cdivl(total, 256)), dim3(256), 0, s, p);
   if (p.dQ) {
@@ -498,9 +525,9 @@ int launch_attention_bwd(const AttnP& p0, hipStream_t s) {
   if (p.dK && p.dV) {
     const dim3 grid(cdiv(p.Skv, 128) * (p.nsplit > 1 ? p.nsplit : 1), p.H, p.B);
     if (g_attn_use_tr)
-      hipLaunchKernelGGL((attn_dkv_kernel<true>), grid, dim3(256), 4 * TILE_BYTES, s, p);
+      hipLaunchKernelGGL((attn_dkv_kernel<true>), grid, dim3(256), 2 * DKV_STAGE, s, p);
     else
-      hipLaunchKernelGGL((attn_dkv_kernel<false>), grid, dim3(256), 4 * TILE_BYTES, s, p);
+      hipLaunchKernelGGL((attn_dkv_kernel<false>), grid, dim3(256), 2 * DKV_STAGE, s, p);
     if (p.nsplit > 1) {
       const long long total = (long long)p.B * p.H * p.Skv * 2 * 16;
       hipLaunchKernelGGL(attn_dkv_reduce_kernel, dim3((unsigned)cdivl(total, 256)), dim3(256), 0, s, p);

@@ -35,6 +35,8 @@ __device__ __forceinline__ void wait_vmcnt() {
   else if constexpr (N == 18) asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
   else if constexpr (N == 24) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
   else if constexpr (N == 26) asm volatile("s_waitcnt vmcnt(26)" ::: "memory");
+  else if constexpr (N == 27) asm volatile("s_waitcnt vmcnt(27)" ::: "memory");
+  else if constexpr (N == 32) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
   else static_assert(N == 0, "add the vmcnt literal");
 }
 
@@ -102,6 +104,100 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x16 (&acc)[NI][
           for (int j = 0; j < 4; ++j) o[j] = (bf16)v[j];
           *(bf16x4*)((bf16*)p.C + (long long)m * p.ldc + n) = o;
         }
+      }
+    }
+  }
+}
+
+// ---- coalesced epilogue: the fp32 accumulator tile (after alpha / bias / row vector / activation) is transposed
+// through LDS (the ring is free after the K loop) so the residual loads and the output stores are row-contiguous,
+// 16 bytes per lane, instead of 8-byte accesses scattered over 32 rows per instruction.  One rounding to bf16.
+// Rows are processed in chunks of CR so that CR x (BN+4) floats fit the ring.  NT = number of consumer threads.
+template <int MI, int NI, int BM, int BN, int WM, int WN>
+__device__ __forceinline__ void gemm_epilogue_lds(const GemmP& p, f32x16 (&acc)[NI][MI], char* smem, int ring_bytes,
+                                                  int bm, int bn, int wr, int wc, int frow, int fh, int ctid) {
+  constexpr int LDT = BN + 4;                       // padded row stride (floats): conflict-free b128 writes
+  constexpr int NT = WM * WN * 64;
+  constexpr int WTM = BM / WM, WTN = BN / WN;
+  float* ct = (float*)smem;
+  int CR = ring_bytes / (LDT * 4);
+  CR = CR >= BM ? BM : (CR / 32) * 32;
+  for (int r0 = 0; r0 < BM; r0 += CR) {
+    __syncthreads();                                // ring (or the previous chunk) no longer read by anyone
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+      const int lrow = wr * WTM + mi * 32 + frow;   // row inside the block tile
+      if (lrow < r0 || lrow >= r0 + CR) continue;
+      const int m = bm * BM + lrow;
+      const int bidx = (p.rowvec && m < p.M) ? m / p.rows_per_batch : 0;
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int lcol = wc * WTN + ni * 32 + 8 * g + 4 * fh;
+          const int n = bn * BN + lcol;
+          f32x4 v;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] = acc[ni][mi][4 * g + j] * p.alpha;
+          if (n < p.N) {
+            if (p.bias) {
+              const f32x4 b = *(const f32x4*)(p.bias + n);
+#pragma unroll
+              for (int j = 0; j < 4; ++j) v[j] += b[j];
+            }
+            if (p.rowvec && m < p.M) {
+              const bf16x4 rv = *(const bf16x4*)(p.rowvec + (long long)bidx * p.ldrv + n);
+#pragma unroll
+              for (int j = 0; j < 4; ++j) v[j] += (float)rv[j];
+            }
+            if (p.act == 1) {
+#pragma unroll
+              for (int j = 0; j < 4; ++j) v[j] = gelu_erf(v[j]);
+            } else if (p.act == 2) {
+#pragma unroll
+              for (int j = 0; j < 4; ++j) v[j] = siluf_(v[j]);
+            }
+          }
+          *(f32x4*)(ct + (lrow - r0) * LDT + lcol) = v;
+        }
+    }
+    __syncthreads();
+    constexpr int CPR = BN / 8;                     // 8-element chunks per row
+    const int rows_here = CR < BM - r0 ? CR : BM - r0;
+    const int nchunks = rows_here * CPR;
+    for (int c = ctid; c < nchunks; c += NT) {
+      const int row = c / CPR, c8 = (c - row * CPR) * 8;
+      const int m = bm * BM + r0 + row, n = bn * BN + c8;
+      if (m >= p.M || n >= p.N) continue;
+      const f32x4 lo = *(const f32x4*)(ct + row * LDT + c8), hi = *(const f32x4*)(ct + row * LDT + c8 + 4);
+      float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      if (p.res) {
+        const bf16x8 rr = *(const bf16x8*)(p.res + (long long)m * p.ldres + n);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] += (float)rr[j];
+      }
+      if (p.out_f32) {
+        float* cp = (float*)p.C + (long long)m * p.ldc + n;
+        f32x4 o0, o1;
+        if (p.accum_f32) {
+          o0 = *(const f32x4*)cp;
+          o1 = *(const f32x4*)(cp + 4);
+        } else {
+          o0 = (f32x4){0.f, 0.f, 0.f, 0.f};
+          o1 = o0;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          o0[j] += v[j];
+          o1[j] += v[4 + j];
+        }
+        *(f32x4*)cp = o0;
+        *(f32x4*)(cp + 4) = o1;
+      } else {
+        bf16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = (bf16)v[j];
+        *(bf16x8*)((bf16*)p.C + (long long)m * p.ldc + n) = o;
       }
     }
   }
@@ -420,7 +516,10 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_pipe_kernel(const GemmP p) 
     }
     cur = nxt;
   }
-  gemm_epilogue<MI, NI>(p, acc, bm * BM + wr * (BM / WM), bn * BN + wc * (BN / WN), frow, fh);
+  if (p.lds_epilogue)
+    gemm_epilogue_lds<MI, NI, BM, BN, WM, WN>(p, acc, smem, S * STAGE, bm, bn, wr, wc, frow, fh, tid);
+  else
+    gemm_epilogue<MI, NI>(p, acc, bm * BM + wr * (BM / WM), bn * BN + wc * (BN / WN), frow, fh);
 }
 
 template <int MODE, int BM, int BN, int WM, int WN, int S>
@@ -435,6 +534,207 @@ static int launch_pipe(const GemmP& p, hipStream_t stream) {
   }
   const int grid = cdiv(p.M, BM) * cdiv(p.N, BN);
   hipLaunchKernelGGL((gemm_pipe_kernel<MODE, BM, BN, WM, WN, S>), dim3(grid), dim3(WM * WN * 64), lds, stream, p);
+  return PEA_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Loader / consumer kernel.  WM x WN consumer waves run ONLY ds_reads + MFMAs (register double-buffered
+// fragments as above); LW extra loader waves run ONLY the LDS-DMA stream (address arithmetic + pieces), so
+// the MFMA waves never spend issue slots on staging and each SIMD interleaves one wave of each kind.
+// One s_barrier per K-step is shared by both roles:
+//   loader  t: wait "tile t+1 landed" (counted vmcnt) -> barrier_t -> refill the slot of tile t with tile t+S
+//   consumer t: sub-steps 0..2 of tile t, lgkmcnt(0) -> barrier_t -> prefetch (t+1, 0), sub-step 3 of tile t
+// After barrier_t every consumer has issued and retired all reads of tile t's LDS slot, so the ring runs S
+// tiles ahead (all S slots in flight).
+template <int MODE, int BM, int BN, int WM, int WN, int LW, int S>
+__global__ __launch_bounds__((WM * WN + LW) * 64) void gemm_lc_kernel(const GemmP p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int NWC = WM * WN;
+  constexpr int STAGE = (BM + BN) * 128;
+  constexpr int A_BYTES = BM * 128;
+  constexpr int PA = BM / 8 / LW, PB = BN / 8 / LW;
+  constexpr int PP = PA + PB;
+  constexpr int MI = BM / WM / 32, NI = BN / WN / 32;
+  static_assert(BM % (8 * LW) == 0 && BN % (8 * LW) == 0, "tile / loader split");
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+  const int nbm = (p.M + BM - 1) / BM, nbn = (p.N + BN - 1) / BN;
+  const int nwg = nbm * nbn;
+  int bid = blockIdx.x;
+  {
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int GROUP = 8;
+  const int per_group = GROUP * nbn;
+  const int gid = bid / per_group;
+  const int first_m = gid * GROUP;
+  const int gsize = min(nbm - first_m, GROUP);
+  const int bm = first_m + (bid % per_group) % gsize;
+  const int bn = (bid % per_group) / gsize;
+  // split-K (p.ksplit > 1): blockIdx.y owns K-steps [kt0, kt0 + nt) and writes its fp32 partial tile to
+  // C + blockIdx.y * split_stride; launch_splitk_reduce adds the partials in order
+  int nt = p.K / BK, kt0 = 0;
+  if (p.ksplit > 1) {
+    const int per = (nt + p.ksplit - 1) / p.ksplit;
+    kt0 = blockIdx.y * per;
+    nt = min(per, nt - kt0);
+    if (nt < 0) nt = 0;
+  }
+  const int kb0 = kt0 * BK;
+
+  if (wave >= NWC) {
+    // ============================== loader waves
+    const int lw = wave - NWC;
+    const int lrow = lane >> 3, cpos = lane & 7;
+    const bf16* a_src[PA];
+    int a_iy0[PA], a_ix0[PA];
+    const bf16* w_src[PB];
+#pragma unroll
+    for (int j = 0; j < PA; ++j) {
+      const int r = (lw * PA + j) * 8 + lrow;
+      const int chunk = cpos ^ ((r >> 1) & 7);
+      int gm = bm * BM + r;
+      gm = gm < p.M ? gm : p.M - 1;
+      if (MODE == 0) {
+        a_src[j] = p.A + (long long)gm * p.lda + chunk * 8;
+        a_iy0[j] = a_ix0[j] = 0;
+      } else {
+        const int hw = p.Ho * p.Wo;
+        const int b = gm / hw;
+        const int rem = gm - b * hw;
+        const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+        a_iy0[j] = oy * p.stride - 1;
+        a_ix0[j] = ox * p.stride - 1;
+        a_src[j] = p.A + (long long)b * p.Hs * p.Ws * p.Cin + chunk * 8;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < PB; ++j) {
+      const int r = (lw * PB + j) * 8 + lrow;
+      const int chunk = cpos ^ ((r >> 1) & 7);
+      int gn = bn * BN + r;
+      gn = gn < p.N ? gn : p.N - 1;
+      w_src[j] = p.W + (long long)gn * p.ldw + chunk * 8;
+    }
+    const int Hv = p.Hs << p.shift, Wv = p.Ws << p.shift;
+    auto issue = [&](int st, int k0) {
+      char* base = smem + st * STAGE;
+      int ky = 0, kx = 0, c0 = 0;
+      if (MODE == 1) {
+        const int tap = k0 / p.Cin;
+        c0 = k0 - tap * p.Cin;
+        ky = tap / 3;
+        kx = tap - ky * 3;
+      }
+#pragma unroll
+      for (int j = 0; j < PA; ++j) {
+        const bf16* src;
+        if (MODE == 0) {
+          src = a_src[j] + k0;
+        } else {
+          const int iy = a_iy0[j] + ky, ix = a_ix0[j] + kx;
+          bool ok = ((unsigned)iy < (unsigned)Hv) && ((unsigned)ix < (unsigned)Wv);
+          if (p.parity) ok = ok && (((iy | ix) & 1) == 0);
+          const int sy = iy >> p.shift, sx = ix >> p.shift;
+          src = ok ? a_src[j] + ((long long)sy * p.Ws + sx) * p.Cin + c0 : p.zeros;
+        }
+        __builtin_amdgcn_global_load_lds(PEA_GLB(src), PEA_LDS(base + (lw * PA + j) * 1024), 16, 0, 0);
+      }
+#pragma unroll
+      for (int j = 0; j < PB; ++j)
+        __builtin_amdgcn_global_load_lds(PEA_GLB(w_src[j] + k0), PEA_LDS(base + A_BYTES + (lw * PB + j) * 1024), 16,
+                                         0, 0);
+    };
+#pragma unroll
+    for (int i = 0; i < S; ++i)
+      if (i < nt) issue(i, kb0 + i * BK);
+    if (nt >= S) wait_vmcnt<(S - 1) * PP>();
+    else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();                              // prologue barrier: tile 0 landed
+    int cur = 0;
+    for (int t = 0; t + 1 < nt; ++t) {
+      // tile t+1 must have landed; tiles t+2 .. t+S-1 may stay in flight (tile t+S is issued after the barrier)
+      if (t + S - 1 < nt) wait_vmcnt<(S - 2) * PP>();
+      else wait_vmcnt<0>();
+      __builtin_amdgcn_s_barrier();                            // barrier_t
+      if (t + S < nt) issue(cur, kb0 + (t + S) * BK);
+      cur = cur + 1 == S ? 0 : cur + 1;
+    }
+    return;
+  }
+
+  // ================================ consumer waves
+  const int wr = wave / WN, wc = wave % WN;
+  const int frow = lane & 31, fh = lane >> 5;
+  const int a_row0 = wr * (BM / WM) + frow, w_row0 = wc * (BN / WN) + frow;
+  f32x16 acc[NI][MI];
+#pragma unroll
+  for (int i = 0; i < NI; ++i)
+#pragma unroll
+    for (int j = 0; j < MI; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  bf16x8 af[2][MI], wf[2][NI];
+  auto load_frags = [&](int which, const char* tile, int s) {
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) af[which][mi] = *(const bf16x8*)(tile + swz_off(a_row0 + mi * 32, 2 * s + fh));
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+      wf[which][ni] = *(const bf16x8*)(tile + A_BYTES + swz_off(w_row0 + ni * 32, 2 * s + fh));
+  };
+  __builtin_amdgcn_s_barrier();                                // prologue barrier
+  load_frags(0, smem, 0);
+  int cur = 0;
+  for (int t = 0; t < nt; ++t) {
+    const char* tile = smem + cur * STAGE;
+    const int nxt = cur + 1 == S ? 0 : cur + 1;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      if (s == 3) {
+        if (t + 1 < nt) {
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          __builtin_amdgcn_s_barrier();                        // barrier_t
+          load_frags(0, smem + nxt * STAGE, 0);
+        }
+      } else {
+        load_frags((s + 1) & 1, tile, s + 1);
+      }
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+          acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[s & 1][ni], af[s & 1][mi], acc[ni][mi], 0, 0, 0);
+    }
+    cur = nxt;
+  }
+  if (p.ksplit > 1) {
+    GemmP q = p;
+    q.C = (float*)p.C + (long long)blockIdx.y * p.split_stride;
+    gemm_epilogue<MI, NI>(q, acc, bm * BM + wr * (BM / WM), bn * BN + wc * (BN / WN), frow, fh);
+    return;
+  }
+  if (p.lds_epilogue)
+    gemm_epilogue_lds<MI, NI, BM, BN, WM, WN>(p, acc, smem, S * STAGE, bm, bn, wr, wc, frow, fh, tid);
+  else
+    gemm_epilogue<MI, NI>(p, acc, bm * BM + wr * (BM / WM), bn * BN + wc * (BN / WN), frow, fh);
+}
+
+template <int MODE, int BM, int BN, int WM, int WN, int LW, int S>
+static int launch_lc(const GemmP& p, hipStream_t stream) {
+  constexpr int lds = S * (BM + BN) * 128;
+  static_assert(lds <= 160 * 1024, "LDS budget");
+  static bool attr_set = false;
+  if (!attr_set) {
+    HIPCHK(hipFuncSetAttribute((const void*)gemm_lc_kernel<MODE, BM, BN, WM, WN, LW, S>,
+                               hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    attr_set = true;
+  }
+  const int grid = cdiv(p.M, BM) * cdiv(p.N, BN);
+  hipLaunchKernelGGL((gemm_lc_kernel<MODE, BM, BN, WM, WN, LW, S>), dim3(grid, p.ksplit > 1 ? p.ksplit : 1),
+                     dim3((WM * WN + LW) * 64), lds, stream, p);
   return PEA_OK;
 }
 
@@ -472,45 +772,63 @@ static int launch_variant(const GemmP& p, hipStream_t stream) {
     case 11: rc = launch_pipe<MODE, 128, 128, 2, 2, 3>(p, stream); break; \
     case 12: rc = launch_pipe<MODE, 256, 256, 2, 4, 2>(p, stream); break; \
     case 13: rc = launch_pipe<MODE, 128, 160, 4, 1, 3>(p, stream); break; \
+    case 14: rc = launch_lc<MODE, 128, 160, 4, 1, 4, 4>(p, stream); break; \
+    case 15: rc = launch_lc<MODE, 256, 160, 4, 1, 4, 3>(p, stream); break; \
+    case 16: rc = launch_lc<MODE, 256, 128, 4, 2, 4, 3>(p, stream); break; \
+    case 18: rc = launch_lc<MODE, 128, 128, 2, 2, 4, 4>(p, stream); break; \
+    case 19: rc = launch_lc<MODE, 128, 160, 4, 1, 4, 3>(p, stream); break; \
     default: rc = launch_variant<MODE, 128, 128, 2, 2, 2>(p, stream); break; \
   }
 
 static int pick_variant(const GemmP& p) {
   if (g_gemm_variant >= 0) return g_gemm_variant;
   // measured on the step's shapes with scripts/gemm_bench.py (profiles/r01_gemm_variants.log):
-  //   13 = pipelined 128x160, 4 waves, 3 stages     9 = pipelined 256x160, 4 waves, 3 stages
-  //   10 = pipelined 256x128, 8 waves, 3 stages    12 = pipelined 256x256, 8 waves, 2 stages
-  //   11 = pipelined 128x128, 4 waves, 3 stages     5 = 256x256, 8 waves, 2 stages (plain loop)
+  //   19 = loader/consumer 128x160 (4 MFMA + 4 DMA waves, 3 stages)   15 = loader/consumer 256x160 (4+4, 3 stages)
+  //   18 = loader/consumer 128x128 (4+4, 4 stages)                     10 = pipelined 256x128, 8 waves, 3 stages
+  //   12 = pipelined 256x256, 8 waves, 2 stages
   if (p.mode == 1) {
-    if (p.N <= 384) return p.K >= 5760 ? 9 : 10;   // 128^2-level convs (N = 320)
-    if (p.M >= 16384) return 9;                     // 64^2-level convs (N = 640)
-    return 13;                                      // 32^2-level convs (M = 4096, N = 1280)
+    if (p.N <= 384) return p.K >= 5760 ? 15 : 19;   // 128^2-level convs (N = 320)
+    if (p.M >= 16384) return 15;                     // 64^2-level convs (N = 640)
+    return 19;                                       // 32^2-level convs (M = 4096, N = 1280)
   }
-  if (p.M < 1024) return 11;                        // cross-attention K|V projections, embeddings, adapter
-  if (p.N <= 1280) return 13;                       // every N in {640, 1280}: 160-wide tiles fill the chip exactly
-  if (p.M >= 8192) return 12;
-  return p.N >= 8192 ? 10 : 5;
+  if (p.M < 1024) return 18;                         // cross-attention K|V projections, embeddings, adapter
+  if (p.N <= 1280) return (p.M >= 8192 && p.K >= 2560) ? 15 : 19;   // 160-wide tiles fill the chip exactly
+  if (p.M <= 4096 && p.N >= 8192) return 10;
+  return 12;
 }
 
-int launch_gemm(const GemmP& p, hipStream_t stream) {
-  SHAPECHK(p.M > 0 && p.N > 0 && p.K > 0, "gemm: empty problem M=%d N=%d K=%d", p.M, p.N, p.K);
-  SHAPECHK(p.K % BK == 0, "gemm: K=%d must be a multiple of %d", p.K, BK);
-  SHAPECHK(p.N % 4 == 0, "gemm: N=%d must be a multiple of 4", p.N);
-  SHAPECHK(p.ldw % 8 == 0 && p.ldc % 4 == 0, "gemm: ldw=%d ldc=%d alignment", p.ldw, p.ldc);
-  if (p.mode == 0) {
-    SHAPECHK(p.lda % 8 == 0, "gemm: lda=%d must be a multiple of 8", p.lda);
+int g_gemm_lds_epilogue = 0;   // measured round 1: a net loss in situ (multi-pass on 256-wide tiles); kept for experiments
+extern "C" void pea_debug_set_gemm_lds_epilogue(int v) { g_gemm_lds_epilogue = v; }
+
+int launch_gemm(const GemmP& p_in, hipStream_t stream) {
+  const GemmP& p0 = p_in;
+  SHAPECHK(p0.M > 0 && p0.N > 0 && p0.K > 0, "gemm: empty problem M=%d N=%d K=%d", p0.M, p0.N, p0.K);
+  SHAPECHK(p0.K % BK == 0, "gemm: K=%d must be a multiple of %d", p0.K, BK);
+  SHAPECHK(p0.N % 4 == 0, "gemm: N=%d must be a multiple of 4", p0.N);
+  SHAPECHK(p0.ldw % 8 == 0 && p0.ldc % 4 == 0, "gemm: ldw=%d ldc=%d alignment", p0.ldw, p0.ldc);
+  if (p0.mode == 0) {
+    SHAPECHK(p0.lda % 8 == 0, "gemm: lda=%d must be a multiple of 8", p0.lda);
   } else {
-    SHAPECHK(p.Cin % BK == 0 && p.K == 9 * p.Cin, "conv: Cin=%d must be a multiple of %d and K=9*Cin", p.Cin, BK);
-    SHAPECHK(p.zeros != nullptr, "conv: zero page missing");
-    SHAPECHK(p.M % (p.Ho * p.Wo) == 0, "conv: M=%d not a multiple of Ho*Wo", p.M);
+    SHAPECHK(p0.Cin % BK == 0 && p0.K == 9 * p0.Cin, "conv: Cin=%d must be a multiple of %d and K=9*Cin", p0.Cin, BK);
+    SHAPECHK(p0.zeros != nullptr, "conv: zero page missing");
+    SHAPECHK(p0.M % (p0.Ho * p0.Wo) == 0, "conv: M=%d not a multiple of Ho*Wo", p0.M);
   }
   {
     // algorithmic work: 2*M*N*K; a transposed (zero-stuffed) conv only has 1/4 of its taps real
-    double fl = 2.0 * p.M * (double)p.N * p.K * (p.parity ? 0.25 : 1.0);
-    double by = 2.0 * ((double)p.M * p.N + (double)p.N * p.K + (p.mode ? (double)p.M * p.K / 9.0 : (double)p.M * p.K));
-    PROF_BEGIN(p.mode ? 1 : 0, fl, by, stream);
+    double fl = 2.0 * p0.M * (double)p0.N * p0.K * (p0.parity ? 0.25 : 1.0);
+    double by = 2.0 * ((double)p0.M * p0.N + (double)p0.N * p0.K + (p0.mode ? (double)p0.M * p0.K / 9.0 : (double)p0.M * p0.K));
+    if (g_prof_on) { g_prof_tag[0] = p0.M; g_prof_tag[1] = p0.N; g_prof_tag[2] = p0.K; g_prof_tag[3] = (p0.res ? 1 : 0) | (p0.bias ? 2 : 0) | (p0.rowvec ? 4 : 0); }
+    PROF_BEGIN(p0.mode ? 1 : 0, fl, by, stream);
   }
-  const int v = pick_variant(p);
+  GemmP p = p_in;
+  p.lds_epilogue = (g_gemm_lds_epilogue && p.N % 8 == 0 && !p.preact && p.ldc % 8 == 0 && (!p.res || p.ldres % 8 == 0)) ? 1 : 0;
+  int v = pick_variant(p);
+  if (p.ksplit > 1) {
+    SHAPECHK(p.out_f32 && !p.accum_f32 && !p.bias && !p.res && !p.rowvec && !p.preact && p.act == 0 && p.mode == 0,
+             "gemm: split-K writes plain fp32 partials");
+    p.lds_epilogue = 0;
+    v = 18;                                         // loader/consumer 128x128 (the only kernel with the K-split path)
+  }
   int rc = PEA_OK;
   if (p.mode == 0) { GEMM_VARIANTS(0) } else { GEMM_VARIANTS(1) }
   PROF_END(stream);
@@ -663,6 +981,36 @@ int launch_conv_out_dgrad(const float* dy, const float* w, bf16* dx, int B, int 
   const long long total = (long long)B * H * W * (Cin / 8);
   hipLaunchKernelGGL(conv_out_dgrad_kernel, dim3((unsigned)cdivl(total, 256)), dim3(256), 0, s, dy, w, dx, B, Cin,
                      H, W, Cout);
+  HIPCHK(hipGetLastError());
+  return PEA_OK;
+}
+
+// out[m][n] (+)= sum_s partial[s][m][n]  (splits added in order: deterministic)
+__global__ void splitk_reduce_kernel(const float* __restrict__ part, int nsplit, long long stride, bf16* __restrict__ out,
+                                     int ldo, int M, int N, int accum) {
+  const long long total = (long long)M * (N / 4);
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int m = (int)(i / (N / 4)), n = (int)(i % (N / 4)) * 4;
+    f32x4 a = {0.f, 0.f, 0.f, 0.f};
+    for (int s = 0; s < nsplit; ++s) {
+      const f32x4 v = *(const f32x4*)(part + s * stride + (long long)m * N + n);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) a[j] += v[j];
+    }
+    bf16* dst = out + (long long)m * ldo + n;
+    bf16x4 o;
+    if (accum) o = *(const bf16x4*)dst;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = (bf16)(a[j] + (accum ? (float)o[j] : 0.f));
+    *(bf16x4*)dst = o;
+  }
+}
+int launch_splitk_reduce(const float* part, int nsplit, long long stride, bf16* out, int ldo, int M, int N, int accum,
+                         hipStream_t s) {
+  const long long total = (long long)M * (N / 4);
+  const int grid = (int)(cdivl(total, 256) < 2048 ? cdivl(total, 256) : 2048);
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3(grid), dim3(256), 0, s, part, nsplit, stride, out, ldo, M, N, accum);
   HIPCHK(hipGetLastError());
   return PEA_OK;
 }

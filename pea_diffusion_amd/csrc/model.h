@@ -92,8 +92,9 @@ struct Unet {
   std::vector<Tn> tn;
   std::vector<Op> ops;
   std::vector<int> taps;          // tensor ids: d0.., m, u0..
-  int t_ehs = -1, t_text = -1, t_tproj = -1, t_out_in = -1;
-  int tproj_total = 0;
+  int t_ehs = -1, t_text = -1, t_tproj = -1, t_out_in = -1, t_kvall = -1;
+  int tproj_total = 0, kvall_total = 0, kv_nsplit = 1;
+  float* kv_part = nullptr;
   // arenas
   char* warena = nullptr; size_t wbytes = 0; bool owns_weights = true;
   char* aarena = nullptr; size_t abytes = 0;

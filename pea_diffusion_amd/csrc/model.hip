@@ -121,7 +121,7 @@ struct Builder {
     return out;
   }
 
-  int tproj_off = 0;
+  int tproj_off = 0, kv_off = 0;
   int resnet(int x, const std::string& pfx, int cout) {
     const int cin = u.tn[x].cols;
     const float eps = u.cfg.eps;
@@ -152,11 +152,13 @@ struct Builder {
       h = linear(a1, bp + ".attn1.to_out.0", C, true, h);
       int n2 = ln(h, bp + ".norm2");
       int q2 = linear(n2, bp + ".attn2.to_q", C, false);
-      int kv = fused_linear(u.t_ehs, {bp + ".attn2.to_k", bp + ".attn2.to_v"}, {C, C}, false);
+      // K|V of every cross-attention layer come from ONE GEMM over encoder_hidden_states (u.t_kvall)
+      const int kv = u.t_kvall, kvo = kv_off;
+      kv_off += 2 * C;
       int a2 = T(t0.rows, C, t0.B, t0.H, t0.W);
       {
         Op& o = push(OP_ATTN);
-        o.a = q2; o.acol = 0; o.b = kv; o.bcol = 0; o.c = kv; o.ccol = C; o.out = a2;
+        o.a = q2; o.acol = 0; o.b = kv; o.bcol = kvo; o.c = kv; o.ccol = kvo + C; o.out = a2;
         o.p0 = heads; o.p1 = S; o.p2 = u.L; o.aux_bytes = sizeof(float) * t0.B * heads * S;
       }
       h = linear(a2, bp + ".attn2.to_out.0", C, true, h);
@@ -172,6 +174,26 @@ struct Builder {
     return linear(h, pfx + ".proj_out", C, true, x);
   }
 };
+
+// (prefix, C) of every BasicTransformerBlock in creation order (to build the stacked K|V projection)
+std::vector<std::pair<std::string, int>> enumerate_cross_attn(const PeaUnetCfg& c) {
+  std::vector<std::pair<std::string, int>> r;
+  const int n = c.n_levels;
+  auto add = [&](const std::string& pfx, int C, int depth) {
+    for (int k = 0; k < depth; ++k) r.push_back({pfx + ".transformer_blocks." + std::to_string(k) + ".attn2", C});
+  };
+  for (int i = 0; i < n; ++i)
+    if (c.down_cross[i])
+      for (int j = 0; j < c.layers_per_block; ++j)
+        add("down_blocks." + std::to_string(i) + ".attentions." + std::to_string(j), c.block_out[i], c.depth[i]);
+  add("mid_block.attentions.0", c.block_out[n - 1], c.depth[n - 1]);
+  for (int i = 0; i < n; ++i)
+    if (c.up_cross[i])
+      for (int j = 0; j < c.layers_per_block + 1; ++j)
+        add("up_blocks." + std::to_string(i) + ".attentions." + std::to_string(j), c.block_out[n - 1 - i],
+            c.depth[n - 1 - i]);
+  return r;
+}
 
 // cout of every ResnetBlock2D in creation order (to size the fused time_emb_proj matrix)
 std::vector<std::pair<std::string, int>> enumerate_resnets(const PeaUnetCfg& c) {
@@ -236,6 +258,18 @@ int Unet::build() {
     tproj_total = tn[t_tproj].cols;
     ops.back().p3 = 1;   // its gradient arrives through the fp32 column-sum scratch
   }
+  {   // every attn2.to_k / attn2.to_v stacked into one GEMM over encoder_hidden_states
+    auto ca = enumerate_cross_attn(c);
+    std::vector<std::string> names;
+    std::vector<int> ns;
+    for (auto& r : ca) {
+      names.push_back(r.first + ".to_k"); ns.push_back(r.second);
+      names.push_back(r.first + ".to_v"); ns.push_back(r.second);
+    }
+    t_kvall = bd.fused_linear(t_ehs, names, ns, false);
+    ops.back().p3 = 2;                      // backward: split-K dgrad (few rows, very deep K)
+    kvall_total = tn[t_kvall].cols;
+  }
   // conv_in
   int x = bd.T((long long)B * H * W, c.block_out[0], B, H, W);
   {
@@ -277,6 +311,7 @@ int Unet::build() {
     taps.push_back(x);
   }
   SHAPECHK(skips.empty(), "unet: skip stack not consumed (%d left)", (int)skips.size());
+  SHAPECHK(bd.kv_off == kvall_total, "unet: stacked K|V projection layout mismatch (%d vs %d)", bd.kv_off, kvall_total);
   x = bd.gn(x, "conv_norm_out", true, c.eps);
   t_out_in = x;
   {
@@ -386,6 +421,11 @@ int Unet::alloc() {
     if (delta_elems) HIPCHK(hipMalloc((void**)&delta, delta_elems * 4));
     if (ups_elems) HIPCHK(hipMalloc((void**)&ups_tmp, ups_elems * 2));
     if (part_bytes) HIPCHK(hipMalloc((void**)&attn_part, part_bytes));
+    {
+      const int ksteps = kvall_total / 64;
+      kv_nsplit = std::max(1, std::min(32, ksteps / 128));
+      HIPCHK(hipMalloc((void**)&kv_part, sizeof(float) * kv_nsplit * (size_t)tn[t_ehs].rows * tn[t_ehs].cols));
+    }
     HIPCHK(hipMalloc((void**)&tproj_grad, sizeof(float) * B * tproj_total));
   }
   RC(pea_zero_page(&zeros));
@@ -403,6 +443,7 @@ Unet::~Unet() {
   if (tproj_grad) hipFree(tproj_grad);
   if (cs_scratch) hipFree(cs_scratch);
   if (attn_part) hipFree(attn_part);
+  if (kv_part) hipFree(kv_part);
 }
 
 int Unet::load_weight(const char* name, const float* src, long long numel, hipStream_t s) {
@@ -609,6 +650,17 @@ int Unet::backward(const float* deps, hipStream_t s) {
     switch (o.kind) {
       case OP_LINEAR: {
         Tn& a = tn[o.a];
+        if (a.rg && o.p3 == 2) {          // stacked K|V projection: M = B*L rows, K = sum(2C) -> split-K + ordered reduce
+          FusedMat& f = fused[o.fused];
+          GemmP p; fill_gemm(p);
+          p.A = out.g; p.lda = out.cols; p.M = (int)out.rows; p.K = out.cols; p.N = a.cols;
+          p.W = f.wt; p.ldw = f.N; p.C = kv_part; p.ldc = a.cols; p.out_f32 = 1;
+          p.ksplit = kv_nsplit; p.split_stride = (long long)out.rows * a.cols;
+          RC(launch_gemm(p, s));
+          RC(launch_splitk_reduce(kv_part, kv_nsplit, p.split_stride, a.g, a.cols, (int)a.rows, a.cols, a.gw, s));
+          a.gw = true;
+          break;
+        }
         if (a.rg) {
           GemmP p; fill_gemm(p);
           p.A = out.g; p.lda = out.cols; p.M = (int)out.rows; p.K = out.cols; p.N = a.cols;
@@ -692,7 +744,7 @@ int Unet::backward(const float* deps, hipStream_t s) {
         p.Q = q.d + o.acol; p.ldq = q.cols; p.K = k.d + o.bcol; p.ldk = k.cols; p.V = v.d + o.ccol; p.ldv = v.cols;
         p.O = out.d; p.ldo = out.cols; p.lse = o.aux; p.B = B; p.H = o.p0; p.Sq = o.p1; p.Skv = o.p2; p.scale = 0.125f;
         p.dO = out.g; p.lddo = out.cols; p.delta = delta; p.dkv_part = attn_part;
-        SHAPECHK(!q.gw && !k.gw, "unet: attention operand gradient written twice");
+        SHAPECHK(!q.gw && (!k.gw || o.b == t_kvall), "unet: attention operand gradient written twice");
         if (q.rg) { p.dQ = q.g + o.acol; p.lddq = q.cols; }
         if (k.rg) { p.dK = k.g + o.bcol; p.lddk = k.cols; p.dV = v.g + o.ccol; p.lddv = v.cols; }
         RC(launch_attention_bwd(p, s));

@@ -26,7 +26,11 @@ struct GemmP {
   int shift;                       // virtual input = source upsampled by 2^shift (nearest) / zero-stuffed
   int parity;                      // 1: only even virtual coordinates are real (transposed stride-2 conv)
   const bf16* zeros;               // >= 16 bytes of zeros (out-of-bounds taps)
+  int lds_epilogue;                // set by launch_gemm: transpose the tile through LDS for coalesced stores
+  int ksplit; long long split_stride;   // split-K: fp32 partial s is written at C + s*split_stride (then launch_splitk_reduce)
 };
+int launch_splitk_reduce(const float* part, int nsplit, long long stride, bf16* out, int ldo, int M, int N, int accum,
+                         hipStream_t s);
 int launch_gemm(const GemmP& p, hipStream_t stream);
 
 // direct (non-MFMA) 3x3 convs for the 4-channel ends of the UNet
@@ -156,6 +160,7 @@ int launch_cast_i64_f32(const long long* x, float* y, long long n, hipStream_t s
 // ---------------------------------------------------------------- prof.hip
 #define PEA_PROF_FAMILIES 8
 extern int g_prof_on;
+extern int g_prof_tag[4];
 void prof_begin_impl(int fam, double flops, double bytes, hipStream_t s);
 void prof_end_impl(hipStream_t s);
 #define PROF_BEGIN(fam, flops, bytes, s) do { if (g_prof_on) prof_begin_impl(fam, flops, bytes, s); } while (0)

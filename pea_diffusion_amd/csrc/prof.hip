@@ -5,7 +5,8 @@
 #include "../../include/pea_hip.h"
 #include "pea_kernels.h"
 
-struct ProfRec { hipEvent_t a, b; int fam; double flops, bytes; };
+struct ProfRec { hipEvent_t a, b; int fam; double flops, bytes; int tag[4]; };
+int g_prof_tag[4] = {0, 0, 0, 0};
 int g_prof_on = 0;
 static std::vector<ProfRec> g_recs;
 static std::vector<hipEvent_t> g_pool;
@@ -24,6 +25,7 @@ static hipEvent_t take_event() {
 void prof_begin_impl(int fam, double flops, double bytes, hipStream_t s) {
   ProfRec r;
   r.a = take_event(); r.b = take_event(); r.fam = fam; r.flops = flops; r.bytes = bytes;
+  for (int i = 0; i < 4; ++i) { r.tag[i] = g_prof_tag[i]; g_prof_tag[i] = 0; }
   (void)hipEventRecord(r.a, s);
   g_recs.push_back(r);
 }
@@ -36,6 +38,19 @@ void pea_prof_reset(void) {
   g_pool_next = 0;
 }
 const char* pea_prof_family_name(int fam) { return fam >= 0 && fam < PEA_PROF_FAMILIES ? kFam[fam] : "?"; }
+int pea_prof_dump(const char* path) {
+  if (hipDeviceSynchronize() != hipSuccess) return PEA_E_HIP;
+  FILE* f = fopen(path, "w");
+  if (!f) return PEA_E_INVALID;
+  fprintf(f, "family,ms,flops,bytes,t0,t1,t2,t3\n");
+  for (const ProfRec& r : g_recs) {
+    float e = 0.f;
+    (void)hipEventElapsedTime(&e, r.a, r.b);
+    fprintf(f, "%s,%.6f,%.0f,%.0f,%d,%d,%d,%d\n", kFam[r.fam], e, r.flops, r.bytes, r.tag[0], r.tag[1], r.tag[2], r.tag[3]);
+  }
+  fclose(f);
+  return PEA_OK;
+}
 int pea_prof_report(int fam, double* ms, double* flops, double* bytes, long long* launches) {
   if (hipDeviceSynchronize() != hipSuccess) return PEA_E_HIP;
   double t = 0, f = 0, by = 0;
