@@ -44,6 +44,16 @@ def synthetic_batch(cfg, B, L, enc_dim, hw, device, seed):
                 time_ids=torch.tensor([[px, px, 0, 0, px, px]] * B, dtype=torch.float32, device=device))
 
 
+def pmc_traffic():
+    """HBM-side bytes per GEMM launch from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this
+    same command (profiles/r01_pmc_traffic.json; gfx950 FETCH_SIZE x2 correction applied); None if absent."""
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+        return {"MB_per_launch": d["gemm_family"]["traffic_MB_per_launch"], "source": "profiles/r01_pmc_traffic.json"}
+    except Exception:
+        return None
+
+
 def _fast_fill_(module):
     """cheap deterministic weights for the CPU timing model (torch's default init of 2.57 B parameters
     is single-threaded and takes about a minute; the values do not affect the timing)"""
@@ -225,7 +235,7 @@ def main():
         ach = g_fl / (g_ms * 1e-3) / 1e12 if g_ms > 0 else 0.0
         roof = {"bound": "mfma", "kernel": "gemm_bf16_kernel (plain + implicit-GEMM conv3x3)",
                 "achieved": round(ach, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(ach / MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                "frac": round(ach / MFMA_PEAK_TFLOPS, 4), "traffic": pmc_traffic(),
                 "launches_per_step": g_n // nprof, "avg_launch_us": round(g_ms * 1e3 / max(g_n, 1), 2),
                 "gflop_per_launch": round(g_fl / max(g_n, 1) / 1e9, 3),
                 "ms_per_step_single_stream": round(g_ms / nprof, 2),

@@ -114,6 +114,7 @@ class PEAAdapter(nn.Module):
         if self._prepared != (batch, L):
             check(lib().pea_adapter_prepare(self._h, batch, L))
             self._prepared = (batch, L)
+            self._synced_version = None      # the arena (incl. the bf16 weight copies) was reallocated
 
     def __del__(self):
         try:

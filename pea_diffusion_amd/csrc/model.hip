@@ -956,6 +956,8 @@ int Trainer::step(const float* latents, const float* noise, const long long* tim
   Unet& Tt = *teacher;
   Adapter& A = *ad;
   const int B = S.B;
+  SHAPECHK(A.B2 == 2 * B && A.L == S.L, "trainer: adapter is prepared for %d x %d rows, the step needs %d x %d", A.B2, A.L,
+           2 * B, S.L);
   const long long per_img = (long long)S.cfg.in_channels * S.H * S.W;
   if (!t_f32) HIPCHK(hipMalloc((void**)&t_f32, sizeof(float) * B));
   RC(launch_add_noise(latents, noise, timesteps, ac, xt, B, per_img, s));

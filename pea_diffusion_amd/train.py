@@ -71,6 +71,7 @@ class PEATrainer:
         enc_uncond, prompt_mask, zh_or_not, teacher_ehs, teacher_neg [, teacher_pooled, time_ids].
         Leaves the adapter gradients in `adapter.flat_grad`; returns {"loss": device scalar, ...}."""
         f32, dev = torch.float32, self._dev
+        self.adapter.prepare(2 * self.student.B, self.student.L)   # a stand-alone proj(x) call may have re-shaped it
         self.adapter._sync()
         b = {k: dev(batch[k], f32) for k in ("latents", "noise", "enc", "enc_uncond", "teacher_ehs", "teacher_neg")}
         ts = dev(batch["timesteps"], torch.int64)
