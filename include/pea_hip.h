@@ -81,18 +81,19 @@ int pea_op_layernorm_fwd(const void* x, const float* gamma, const float* beta, v
 int pea_op_layernorm_bwd(const void* x, const void* dy, const float* gamma, const float* stats, void* dx,
                          float* dgamma, float* dbeta, int R, int C, int accum, void* stream);
 
-/* softmax(scale Q K^T) V, head_dim 64 (diffusers AttnProcessor2_0 -> SDPA).  Q/K/V/O bf16 with
- * row strides ld* (elements); head h occupies columns [64h, 64h+64).  lse fp32 [B][H][Sq].        */
+/* softmax(scale Q K^T) V (diffusers AttnProcessor2_0 -> SDPA).  Q/K/V/O bf16 with row strides ld* (elements);
+ * head h occupies columns [64*nd*h, 64*nd*(h+1)) where nd = ceil(head_dim / 64) in {1,2,3}; a head narrower than
+ * 64*nd is zero padded (SD1.5: 40 -> 64, 80 -> 128, 160 -> 192) and `scale` stays head_dim^-0.5.  lse fp32 [B][H][Sq]. */
 int pea_op_attention_fwd(const void* Q, int ldq, const void* K, int ldk, const void* V, int ldv, void* O, int ldo,
-                         float* lse, int B, int H, int Sq, int Skv, float scale, void* stream);
+                         float* lse, int B, int H, int Sq, int Skv, float scale, int nd, void* stream);
 /* dQ/dK/dV (dQ may be NULL; dK and dV together); delta: fp32 scratch [B][H][Sq]; scratch: optional device
  * buffer of pea_op_attention_bwd_scratch_bytes(...) bytes enabling the query-split dK/dV form used when the
  * key count is small (cross-attention); NULL = single pass                                            */
-long long pea_op_attention_bwd_scratch_bytes(int B, int H, int Sq, int Skv);
+long long pea_op_attention_bwd_scratch_bytes(int B, int H, int Sq, int Skv, int nd);
 int pea_op_attention_bwd(const void* Q, int ldq, const void* K, int ldk, const void* V, int ldv, const void* O,
                          int ldo, const void* dO, int lddo, const float* lse, float* delta, void* dQ, int lddq,
                          void* dK, int lddk, void* dV, int lddv, int B, int H, int Sq, int Skv, float scale,
-                         int accum_dq, int accum_dkv, void* scratch, void* stream);
+                         int accum_dq, int accum_dkv, int nd, void* scratch, void* stream);
 
 int pea_op_geglu_fwd(const void* hg, void* y, long long rows, int inner, void* stream);
 int pea_op_geglu_bwd(const void* hg, const void* dy, void* dhg, long long rows, int inner, void* stream);

@@ -90,6 +90,17 @@ def tiny_config(heads64: bool = True) -> UNetConfig:
         projection_class_embeddings_input_dim=128 + 6 * 32, name="tiny")
 
 
+def tiny15_config() -> UNetConfig:
+    """small SD1.5-shaped config: 4 levels, 8 heads per level (head dims 8 / 16, stored zero-padded to 64 on the
+    HIP path), 1x1-conv projections, no added conditioning"""
+    return UNetConfig(sample_size=16, block_out_channels=(64, 128, 128, 128),
+                      down_block_types=("CrossAttnDownBlock2D",) * 3 + ("DownBlock2D",),
+                      up_block_types=("UpBlock2D",) + ("CrossAttnUpBlock2D",) * 3,
+                      transformer_layers_per_block=(1, 1, 1, 1), num_attention_heads=(8, 8, 8, 8),
+                      cross_attention_dim=128, use_linear_projection=False, addition_embed_type=None,
+                      addition_time_embed_dim=0, projection_class_embeddings_input_dim=0, name="tiny15")
+
+
 # ----------------------------------------------------------------------------- embeddings
 def timestep_embedding(t: torch.Tensor, dim: int, flip_sin_to_cos: bool = True,
                        freq_shift: float = 0.0, max_period: float = 10000.0) -> torch.Tensor:

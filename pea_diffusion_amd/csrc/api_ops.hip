@@ -111,24 +111,24 @@ int pea_op_layernorm_bwd(const void* x, const void* dy, const float* gamma, cons
 }
 
 int pea_op_attention_fwd(const void* Q, int ldq, const void* K, int ldk, const void* V, int ldv, void* O, int ldo,
-                         float* lse, int B, int H, int Sq, int Skv, float scale, void* stream) {
+                         float* lse, int B, int H, int Sq, int Skv, float scale, int nd, void* stream) {
   AttnP p;
   memset(&p, 0, sizeof(p));
   p.Q = (const bf16*)Q; p.K = (const bf16*)K; p.V = (const bf16*)V; p.ldq = ldq; p.ldk = ldk; p.ldv = ldv;
-  p.O = (bf16*)O; p.ldo = ldo; p.lse = lse; p.B = B; p.H = H; p.Sq = Sq; p.Skv = Skv; p.scale = scale;
+  p.O = (bf16*)O; p.ldo = ldo; p.lse = lse; p.B = B; p.H = H; p.Sq = Sq; p.Skv = Skv; p.scale = scale; p.nd = nd;
   return launch_attention_fwd(p, (hipStream_t)stream);
 }
 int pea_op_attention_bwd(const void* Q, int ldq, const void* K, int ldk, const void* V, int ldv, const void* O,
                          int ldo, const void* dO, int lddo, const float* lse, float* delta, void* dQ, int lddq,
                          void* dK, int lddk, void* dV, int lddv, int B, int H, int Sq, int Skv, float scale,
-                         int accum_dq, int accum_dkv, void* scratch, void* stream) {
+                         int accum_dq, int accum_dkv, int nd, void* scratch, void* stream) {
   AttnP p;
   memset(&p, 0, sizeof(p));
   p.Q = (const bf16*)Q; p.K = (const bf16*)K; p.V = (const bf16*)V; p.ldq = ldq; p.ldk = ldk; p.ldv = ldv;
   p.O = (bf16*)O; p.ldo = ldo; p.lse = (float*)lse; p.B = B; p.H = H; p.Sq = Sq; p.Skv = Skv; p.scale = scale;
   p.dO = (const bf16*)dO; p.lddo = lddo; p.delta = delta;
   p.dQ = (bf16*)dQ; p.lddq = lddq; p.dK = (bf16*)dK; p.lddk = lddk; p.dV = (bf16*)dV; p.lddv = lddv;
-  p.accum_dq = accum_dq; p.accum_dkv = accum_dkv; p.dkv_part = (float*)scratch;
+  p.accum_dq = accum_dq; p.accum_dkv = accum_dkv; p.dkv_part = (float*)scratch; p.nd = nd;
   return launch_attention_bwd(p, (hipStream_t)stream);
 }
 
@@ -178,8 +178,8 @@ int pea_op_kd_loss(int ntaps, const void* const* taps_s, const void* const* taps
   return launch_kd_loss(p, (hipStream_t)stream);
 }
 
-long long pea_op_attention_bwd_scratch_bytes(int B, int H, int Sq, int Skv) {
-  return (long long)attention_bwd_scratch_bytes(B, H, Sq, Skv);
+long long pea_op_attention_bwd_scratch_bytes(int B, int H, int Sq, int Skv, int nd) {
+  return (long long)attention_bwd_scratch_bytes(B, H, Sq, Skv, nd);
 }
 long long pea_op_groupnorm_scratch_bytes(int B, int HW, int C, int groups) {
   return (long long)groupnorm_scratch_bytes(B, HW, C, groups);

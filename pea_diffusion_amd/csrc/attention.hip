@@ -75,70 +75,87 @@ __device__ __forceinline__ bf16x8 read_row_frag(const char* tile, int row, int s
 
 // ============================================================================= forward / dQ
 // MODE 0: forward (writes O, lse).  MODE 1: dQ (reads dO, lse, delta; writes dQ).
-template <int MODE, bool USE_TR>
-__global__ __launch_bounds__(256) void attn_q_kernel(const AttnP p) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 stages][K tile | V tile]
+// ND = head_dim / 64 (heads are stored padded to ND*64 columns; the padding columns of Q/K/V are zero).  Every
+// K/V (Q/dO) tile is kept as ND sub-tiles of 64 x 64 so all LDS images stay 128-byte-row images.
+// MODE 0 produces all ND output chunks in one pass; MODE 1 produces ONE 64-wide chunk of dQ per workgroup
+// (blockIdx.x enumerates query blocks x ND chunks) so its register budget does not grow with ND.
+template <int MODE, bool USE_TR, int ND>
+__global__ __launch_bounds__(256, (ND == 1 ? (MODE == 0 ? 4 : 2) : 1)) void attn_q_kernel(const AttnP p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 stages][K sub-tiles ND | V sub-tiles ND]
+  constexpr int STG = 2 * ND * TILE_BYTES;
+  constexpr int NO = MODE == 0 ? ND : 1;                         // output chunks held by this workgroup
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int head = blockIdx.y, b = blockIdx.z;
-  const int q0 = blockIdx.x * 128 + wave * 32;
+  const int qblk = MODE == 0 ? blockIdx.x : blockIdx.x / ND;
+  const int chunk = MODE == 0 ? 0 : blockIdx.x % ND;             // dQ output chunk
+  const int q0 = qblk * 128 + wave * 32;
   const int frow = lane & 31, fh = lane >> 5;
   const float c = p.scale * LOG2E;
 
-  const bf16* Qb = p.Q + (long long)b * p.Sq * p.ldq + head * 64;
-  const bf16* Kb = p.K + (long long)b * p.Skv * p.ldk + head * 64;
-  const bf16* Vb = p.V + (long long)b * p.Skv * p.ldv + head * 64;
+  const bf16* Qb = p.Q + (long long)b * p.Sq * p.ldq + head * 64 * ND;
+  const bf16* Kb = p.K + (long long)b * p.Skv * p.ldk + head * 64 * ND;
+  const bf16* Vb = p.V + (long long)b * p.Skv * p.ldv + head * 64 * ND;
 
   int qrow = q0 + frow;
   const bool qvalid = qrow < p.Sq;
   qrow = qvalid ? qrow : p.Sq - 1;
-  bf16x8 qf[4], dof[4];
+  bf16x8 qf[ND][4], dof[MODE == 1 ? ND : 1][4];
 #pragma unroll
-  for (int s = 0; s < 4; ++s) qf[s] = *(const bf16x8*)(Qb + (long long)qrow * p.ldq + 16 * s + 8 * fh);
+  for (int nd = 0; nd < ND; ++nd)
+#pragma unroll
+    for (int s = 0; s < 4; ++s) qf[nd][s] = *(const bf16x8*)(Qb + (long long)qrow * p.ldq + nd * 64 + 16 * s + 8 * fh);
   float lse2 = 0.f, dlt = 0.f;
   if (MODE == 1) {
-    const bf16* dOb = p.dO + (long long)b * p.Sq * p.lddo + head * 64;
+    const bf16* dOb = p.dO + (long long)b * p.Sq * p.lddo + head * 64 * ND;
 #pragma unroll
-    for (int s = 0; s < 4; ++s) dof[s] = *(const bf16x8*)(dOb + (long long)qrow * p.lddo + 16 * s + 8 * fh);
+    for (int nd = 0; nd < ND; ++nd)
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+        dof[nd][s] = *(const bf16x8*)(dOb + (long long)qrow * p.lddo + nd * 64 + 16 * s + 8 * fh);
     const long long li = ((long long)b * p.H + head) * p.Sq + qrow;
     lse2 = p.lse[li] * LOG2E;
     dlt = p.delta[li];
   }
 
-  f32x16 oacc[2];
+  f32x16 oacc[2 * NO];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < 2 * NO; ++i)
 #pragma unroll
     for (int r = 0; r < 16; ++r) oacc[i][r] = 0.f;
   float m_run = -INFINITY, l_run = 0.f;
 
+  auto stage_kv = [&](char* dst, int r0) {
+#pragma unroll
+    for (int nd = 0; nd < ND; ++nd) {
+      stage_tile(Kb + nd * 64, p.ldk, r0, p.Skv, dst + nd * TILE_BYTES, wave, lane);
+      stage_tile(Vb + nd * 64, p.ldv, r0, p.Skv, dst + (ND + nd) * TILE_BYTES, wave, lane);
+    }
+  };
   const int nt = (p.Skv + 63) / 64;
-  stage_tile(Kb, p.ldk, 0, p.Skv, smem, wave, lane);
-  stage_tile(Vb, p.ldv, 0, p.Skv, smem + TILE_BYTES, wave, lane);
+  stage_kv(smem, 0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
   for (int t = 0; t < nt; ++t) {
     const int cur = t & 1;
-    if (t + 1 < nt) {
-      char* nx = smem + (cur ^ 1) * 2 * TILE_BYTES;
-      stage_tile(Kb, p.ldk, (t + 1) * 64, p.Skv, nx, wave, lane);
-      stage_tile(Vb, p.ldv, (t + 1) * 64, p.Skv, nx + TILE_BYTES, wave, lane);
-    }
-    const char* Ks = smem + cur * 2 * TILE_BYTES;
-    const char* Vs = Ks + TILE_BYTES;
+    if (t + 1 < nt) stage_kv(smem + (cur ^ 1) * STG, (t + 1) * 64);
+    const char* Ks = smem + cur * STG;
+    const char* Vs = Ks + ND * TILE_BYTES;
 
-    // S^T[key][q] = K . Q^T
+    // S^T[key][q] = K . Q^T  (sum over the ND sub-tiles of the head dimension)
     f32x16 sacc[2];
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) sacc[kb][r] = 0.f;
 #pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        const bf16x8 kf = read_row_frag(Ks, kb * 32 + frow, s, fh);
-        sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], sacc[kb], 0, 0, 0);
-      }
+      for (int nd = 0; nd < ND; ++nd)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          const bf16x8 kf = read_row_frag(Ks + nd * TILE_BYTES, kb * 32 + frow, s, fh);
+          sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[nd][s], sacc[kb], 0, 0, 0);
+        }
     }
     const int kv0 = t * 64;
     bf16x8 pf[4];   // P^T (fwd) or dS^T (dQ) as B-operand fragments, k-permuted
@@ -176,7 +193,7 @@ __global__ __launch_bounds__(256) void attn_q_kernel(const AttnP p) {
         const float alpha = exp2f((m_run - m_new) * c);   // m_run = -inf on the first tile -> 0
         l_run *= alpha;
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < 2 * NO; ++i)
 #pragma unroll
           for (int r = 0; r < 16; ++r) oacc[i][r] *= alpha;
       }
@@ -190,10 +207,12 @@ __global__ __launch_bounds__(256) void attn_q_kernel(const AttnP p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) dpacc[kb][r] = 0.f;
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-          const bf16x8 vf = read_row_frag(Vs, kb * 32 + frow, s, fh);
-          dpacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, dof[s], dpacc[kb], 0, 0, 0);
-        }
+        for (int nd = 0; nd < ND; ++nd)
+#pragma unroll
+          for (int s = 0; s < 4; ++s) {
+            const bf16x8 vf = read_row_frag(Vs + nd * TILE_BYTES, kb * 32 + frow, s, fh);
+            dpacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, dof[MODE == 1 ? nd : 0][s], dpacc[kb], 0, 0, 0);
+          }
       }
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb)
@@ -210,20 +229,23 @@ __global__ __launch_bounds__(256) void attn_q_kernel(const AttnP p) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) pf[ks][j] = (bf16)sacc[ks >> 1][8 * (ks & 1) + j];
 
-    // fwd: O^T[d][q] += V^T[d][key] P^T[key][q];   dQ: dQ^T[d][q] += K^T[d][key] dS^T[key][q]
-    const char* Ts = MODE == 0 ? Vs : Ks;
+    // fwd: O^T[d][q] += V^T[d][key] P^T[key][q]  (all chunks);   dQ: dQ^T[d][q] += K^T[d][key] dS^T[key][q]  (one chunk)
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks)
+    for (int no = 0; no < NO; ++no) {
+      const char* Ts = MODE == 0 ? Vs + no * TILE_BYTES : Ks + chunk * TILE_BYTES;
 #pragma unroll
-      for (int db = 0; db < 2; ++db) {
-        const bf16x8 tf = read_transposed_frag<USE_TR>(Ts, ks * 16, db * 32, lane);
-        oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tf, pf[ks], oacc[db], 0, 0, 0);
-      }
+      for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+        for (int db = 0; db < 2; ++db) {
+          const bf16x8 tf = read_transposed_frag<USE_TR>(Ts, ks * 16, db * 32, lane);
+          oacc[2 * no + db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tf, pf[ks], oacc[2 * no + db], 0, 0, 0);
+        }
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
   }
 
-  // epilogue: oacc[db][4g+j] = X^T[d = db*32 + 8g + 4h + j][q = lane&31]
+  // epilogue: oacc[2*no+db][4g+j] = X^T[d = no*64 + db*32 + 8g + 4h + j][q = lane&31]
   float inv = 1.f;
   if (MODE == 0) {
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
@@ -232,20 +254,22 @@ __global__ __launch_bounds__(256) void attn_q_kernel(const AttnP p) {
       p.lse[((long long)b * p.H + head) * p.Sq + qrow] = m_run * p.scale + log2f(l_tot) * 0.6931471805599453f;
   }
   if (!qvalid) return;
-  bf16* Ob = MODE == 0 ? p.O + (long long)b * p.Sq * p.ldo + head * 64 + (long long)qrow * p.ldo
-                       : p.dQ + (long long)b * p.Sq * p.lddq + head * 64 + (long long)qrow * p.lddq;
+  bf16* Ob = MODE == 0 ? p.O + (long long)b * p.Sq * p.ldo + head * 64 * ND + (long long)qrow * p.ldo
+                       : p.dQ + (long long)b * p.Sq * p.lddq + head * 64 * ND + chunk * 64 + (long long)qrow * p.lddq;
   const bool accum = MODE == 1 && p.accum_dq;
 #pragma unroll
-  for (int db = 0; db < 2; ++db)
+  for (int no = 0; no < NO; ++no)
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      bf16* dst = Ob + db * 32 + 8 * g + 4 * fh;
-      bf16x4 o;
-      if (accum) o = *(const bf16x4*)dst;
+    for (int db = 0; db < 2; ++db)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) o[j] = (bf16)(oacc[db][4 * g + j] * inv + (accum ? (float)o[j] : 0.f));
-      *(bf16x4*)dst = o;
-    }
+      for (int g = 0; g < 4; ++g) {
+        bf16* dst = Ob + no * 64 + db * 32 + 8 * g + 4 * fh;
+        bf16x4 o;
+        if (accum) o = *(const bf16x4*)dst;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = (bf16)(oacc[2 * no + db][4 * g + j] * inv + (accum ? (float)o[j] : 0.f));
+        *(bf16x4*)dst = o;
+      }
 }
 
 // per-row constants of a 64-query tile (lse, delta) -> LDS, 4 bytes per lane, issued by wave 0 only
@@ -257,29 +281,32 @@ __device__ __forceinline__ void stage_rowconst(const float* lse, const float* dl
   __builtin_amdgcn_global_load_lds(PEA_GLB(lse + r), PEA_LDS(dst), 4, 0, 0);
   __builtin_amdgcn_global_load_lds(PEA_GLB(dlt + r), PEA_LDS(dst + 256), 4, 0, 0);
 }
-#define DKV_STAGE (2 * TILE_BYTES + 512)
 
 // ============================================================================= dK / dV
-// workgroup = 4 waves = 128 keys (wave owns 32, key on the lane); loops over 64-query tiles.
+// workgroup = 4 waves = 128 keys (wave owns 32, key on the lane); loops over 64-query tiles.  ONE 64-wide chunk of
+// dK/dV per workgroup: blockIdx.x enumerates (key block, query split, chunk).
 // With p.nsplit > 1 (cross-attention: few keys, many queries) blockIdx.x also enumerates query ranges and the
-// block writes fp32 partial dK/dV to p.dkv_part[split][b][h][key][2][64]; attn_dkv_reduce_kernel adds the
+// block writes fp32 partial dK/dV to p.dkv_part[split][b][h][key][2][64*ND]; attn_dkv_reduce_kernel adds the
 // splits in order (deterministic, no atomics).
-template <bool USE_TR>
-__global__ __launch_bounds__(256) void attn_dkv_kernel(const AttnP p) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 stages][Q tile | dO tile]
+template <bool USE_TR, int ND>
+__global__ __launch_bounds__(256, (ND == 1 ? 2 : 1)) void attn_dkv_kernel(const AttnP p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 stages][Q sub-tiles | dO sub-tiles | lse,delta]
+  constexpr int STG = 2 * ND * TILE_BYTES + 512;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int head = blockIdx.y, b = blockIdx.z;
   const int nsplit = p.nsplit > 1 ? p.nsplit : 1;
-  const int kblk = blockIdx.x / nsplit, split = blockIdx.x - kblk * nsplit;
+  const int chunk = blockIdx.x % ND;
+  const int bx = blockIdx.x / ND;
+  const int kblk = bx / nsplit, split = bx - kblk * nsplit;
   const int k0 = kblk * 128 + wave * 32;
   const int frow = lane & 31, fh = lane >> 5;
   const float c = p.scale * LOG2E;
 
-  const bf16* Qb = p.Q + (long long)b * p.Sq * p.ldq + head * 64;
-  const bf16* dOb = p.dO + (long long)b * p.Sq * p.lddo + head * 64;
-  const bf16* Kb = p.K + (long long)b * p.Skv * p.ldk + head * 64;
-  const bf16* Vb = p.V + (long long)b * p.Skv * p.ldv + head * 64;
+  const bf16* Qb = p.Q + (long long)b * p.Sq * p.ldq + head * 64 * ND;
+  const bf16* dOb = p.dO + (long long)b * p.Sq * p.lddo + head * 64 * ND;
+  const bf16* Kb = p.K + (long long)b * p.Skv * p.ldk + head * 64 * ND;
+  const bf16* Vb = p.V + (long long)b * p.Skv * p.ldv + head * 64 * ND;
   const float* lseb = p.lse + ((long long)b * p.H + head) * p.Sq;
   const float* dltb = p.delta + ((long long)b * p.H + head) * p.Sq;
 
@@ -287,41 +314,42 @@ __global__ __launch_bounds__(256) void attn_dkv_kernel(const AttnP p) {
   const bool kvalid = krow < p.Skv;
   krow = kvalid ? krow : p.Skv - 1;
   const bool wave_active = k0 < p.Skv;       // wave-uniform
-  bf16x8 kf[4], vf[4];
+  bf16x8 kf[ND][4], vf[ND][4];
 #pragma unroll
-  for (int s = 0; s < 4; ++s) {
-    kf[s] = *(const bf16x8*)(Kb + (long long)krow * p.ldk + 16 * s + 8 * fh);
-    vf[s] = *(const bf16x8*)(Vb + (long long)krow * p.ldv + 16 * s + 8 * fh);
-  }
+  for (int nd = 0; nd < ND; ++nd)
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      kf[nd][s] = *(const bf16x8*)(Kb + (long long)krow * p.ldk + nd * 64 + 16 * s + 8 * fh);
+      vf[nd][s] = *(const bf16x8*)(Vb + (long long)krow * p.ldv + nd * 64 + 16 * s + 8 * fh);
+    }
   f32x16 dk[2], dv[2];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int r = 0; r < 16; ++r) dk[i][r] = dv[i][r] = 0.f;
 
+  auto stage_q = [&](char* dst, int r0) {
+#pragma unroll
+    for (int nd = 0; nd < ND; ++nd) {
+      stage_tile(Qb + nd * 64, p.ldq, r0, p.Sq, dst + nd * TILE_BYTES, wave, lane);
+      stage_tile(dOb + nd * 64, p.lddo, r0, p.Sq, dst + (ND + nd) * TILE_BYTES, wave, lane);
+    }
+    stage_rowconst(lseb, dltb, r0, p.Sq, dst + 2 * ND * TILE_BYTES, wave, lane);
+  };
   const int nt_all = (p.Sq + 63) / 64;
   const int tps = (nt_all + nsplit - 1) / nsplit;            // query tiles per split
   const int t_begin = split * tps;
   const int nt = min(nt_all, t_begin + tps);
-  if (t_begin < nt) {
-    stage_tile(Qb, p.ldq, t_begin * 64, p.Sq, smem, wave, lane);
-    stage_tile(dOb, p.lddo, t_begin * 64, p.Sq, smem + TILE_BYTES, wave, lane);
-    stage_rowconst(lseb, dltb, t_begin * 64, p.Sq, smem + 2 * TILE_BYTES, wave, lane);
-  }
+  if (t_begin < nt) stage_q(smem, t_begin * 64);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
   for (int t = t_begin; t < nt; ++t) {
     const int cur = (t - t_begin) & 1;
-    if (t + 1 < nt) {
-      char* nx = smem + (cur ^ 1) * DKV_STAGE;
-      stage_tile(Qb, p.ldq, (t + 1) * 64, p.Sq, nx, wave, lane);
-      stage_tile(dOb, p.lddo, (t + 1) * 64, p.Sq, nx + TILE_BYTES, wave, lane);
-      stage_rowconst(lseb, dltb, (t + 1) * 64, p.Sq, nx + 2 * TILE_BYTES, wave, lane);
-    }
-    const char* Qs = smem + cur * DKV_STAGE;
-    const char* dOs = Qs + TILE_BYTES;
-    const float* rc = (const float*)(Qs + 2 * TILE_BYTES);
+    if (t + 1 < nt) stage_q(smem + (cur ^ 1) * STG, (t + 1) * 64);
+    const char* Qs = smem + cur * STG;
+    const char* dOs = Qs + ND * TILE_BYTES;
+    const float* rc = (const float*)(Qs + 2 * ND * TILE_BYTES);
     if (wave_active) {
       // S[q][key] = Q . K^T ; dP[q][key] = dO . V^T   (rows q in registers, key on the lane)
       f32x16 sacc[2], dpacc[2];
@@ -330,12 +358,14 @@ __global__ __launch_bounds__(256) void attn_dkv_kernel(const AttnP p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) sacc[qb][r] = dpacc[qb][r] = 0.f;
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-          const bf16x8 qfr = read_row_frag(Qs, qb * 32 + frow, s, fh);
-          sacc[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qfr, kf[s], sacc[qb], 0, 0, 0);
-          const bf16x8 dfr = read_row_frag(dOs, qb * 32 + frow, s, fh);
-          dpacc[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dfr, vf[s], dpacc[qb], 0, 0, 0);
-        }
+        for (int nd = 0; nd < ND; ++nd)
+#pragma unroll
+          for (int s = 0; s < 4; ++s) {
+            const bf16x8 qfr = read_row_frag(Qs + nd * TILE_BYTES, qb * 32 + frow, s, fh);
+            sacc[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qfr, kf[nd][s], sacc[qb], 0, 0, 0);
+            const bf16x8 dfr = read_row_frag(dOs + nd * TILE_BYTES, qb * 32 + frow, s, fh);
+            dpacc[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dfr, vf[nd][s], dpacc[qb], 0, 0, 0);
+          }
       }
       bf16x8 pfr[4], dsfr[4];
 #pragma unroll
@@ -361,14 +391,14 @@ __global__ __launch_bounds__(256) void attn_dkv_kernel(const AttnP p) {
             dsfr[ks][e] = (bf16)ds;
           }
         }
-      // dV^T[d][key] += dO^T[d][q] P[q][key] ;  dK^T[d][key] += Q^T[d][q] dS[q][key]
+      // dV^T[d][key] += dO^T[d][q] P[q][key] ;  dK^T[d][key] += Q^T[d][q] dS[q][key]   (d in this block's chunk)
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
         for (int db = 0; db < 2; ++db) {
-          const bf16x8 dot = read_transposed_frag<USE_TR>(dOs, ks * 16, db * 32, lane);
+          const bf16x8 dot = read_transposed_frag<USE_TR>(dOs + chunk * TILE_BYTES, ks * 16, db * 32, lane);
           dv[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dot, pfr[ks], dv[db], 0, 0, 0);
-          const bf16x8 qt = read_transposed_frag<USE_TR>(Qs, ks * 16, db * 32, lane);
+          const bf16x8 qt = read_transposed_frag<USE_TR>(Qs + chunk * TILE_BYTES, ks * 16, db * 32, lane);
           dk[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qt, dsfr[ks], dk[db], 0, 0, 0);
         }
     }
@@ -376,23 +406,24 @@ __global__ __launch_bounds__(256) void attn_dkv_kernel(const AttnP p) {
     __syncthreads();
   }
   if (!kvalid) return;
+  const int D = 64 * ND;
   if (p.nsplit > 1) {
-    float* pr = p.dkv_part + ((((long long)split * p.B + b) * p.H + head) * p.Skv + krow) * 128;
+    float* pr = p.dkv_part + ((((long long)split * p.B + b) * p.H + head) * p.Skv + krow) * 2 * D + chunk * 64;
 #pragma unroll
     for (int db = 0; db < 2; ++db)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const int d = db * 32 + 8 * g + 4 * fh;
-        f32x4 a, c;
+        f32x4 a, cc;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { a[j] = dk[db][4 * g + j]; c[j] = dv[db][4 * g + j]; }
+        for (int j = 0; j < 4; ++j) { a[j] = dk[db][4 * g + j]; cc[j] = dv[db][4 * g + j]; }
         *(f32x4*)(pr + d) = a;
-        *(f32x4*)(pr + 64 + d) = c;
+        *(f32x4*)(pr + D + d) = cc;
       }
     return;
   }
-  bf16* dKr = p.dK + ((long long)b * p.Skv + krow) * p.lddk + head * 64;
-  bf16* dVr = p.dV + ((long long)b * p.Skv + krow) * p.lddv + head * 64;
+  bf16* dKr = p.dK + ((long long)b * p.Skv + krow) * p.lddk + head * D + chunk * 64;
+  bf16* dVr = p.dV + ((long long)b * p.Skv + krow) * p.lddv + head * D + chunk * 64;
 #pragma unroll
   for (int db = 0; db < 2; ++db)
 #pragma unroll
@@ -413,20 +444,23 @@ __global__ __launch_bounds__(256) void attn_dkv_kernel(const AttnP p) {
     }
 }
 
-// delta[b][h][q] = sum_d dO[q][h*64+d] * O[q][h*64+d]; one wave per 8 (q,head) rows
+// delta[b][h][q] = sum_d dO[q][h*D+d] * O[q][h*D+d]; 8 lanes per (row, head), each sums D/8 elements
 __global__ __launch_bounds__(256) void attn_delta_kernel(const AttnP p) {
-  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;   // one thread per (b, q, head, 8-chunk)
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;   // one thread per (b, q, head, 8-lane slot)
   const long long total = (long long)p.B * p.Sq * p.H * 8;
   const int sub = (int)(idx & 7);
+  const int D = 64 * p.nd;
   float s = 0.f;
   long long row = idx >> 3;
   if (idx < total) {
     const int head = (int)(row % p.H);
     const long long bq = row / p.H;
-    const bf16x8 a = *(const bf16x8*)(p.dO + bq * p.lddo + head * 64 + sub * 8);
-    const bf16x8 o = *(const bf16x8*)(p.O + bq * p.ldo + head * 64 + sub * 8);
+    for (int nd = 0; nd < p.nd; ++nd) {
+      const bf16x8 a = *(const bf16x8*)(p.dO + bq * p.lddo + head * D + nd * 64 + sub * 8);
+      const bf16x8 o = *(const bf16x8*)(p.O + bq * p.ldo + head * D + nd * 64 + sub * 8);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) s += (float)a[j] * (float)o[j];
+      for (int j = 0; j < 8; ++j) s += (float)a[j] * (float)o[j];
+    }
   }
   s += __shfl_xor(s, 1, 64);
   s += __shfl_xor(s, 2, 64);
@@ -439,26 +473,27 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const AttnP p) {
   }
 }
 
-// out[b][key][h*64+d] (+)= sum_split part[split][b][h][key][{dK,dV}][d]   (splits added in order)
+// out[b][key][h*D+d] (+)= sum_split part[split][b][h][key][{dK,dV}][d]   (splits added in order)
 __global__ void attn_dkv_reduce_kernel(const AttnP p) {
+  const int D = 64 * p.nd, D4 = D / 4;
   const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;     // (b, h, key, which, d/4)
-  const long long total = (long long)p.B * p.H * p.Skv * 2 * 16;
+  const long long total = (long long)p.B * p.H * p.Skv * 2 * D4;
   if (idx >= total) return;
-  const int d4 = (int)(idx & 15) * 4;
-  const int which = (int)((idx >> 4) & 1);
-  long long r = idx >> 5;
+  const int d4 = (int)(idx % D4) * 4;
+  long long r = idx / D4;
+  const int which = (int)(r & 1); r >>= 1;
   const int key = (int)(r % p.Skv); r /= p.Skv;
   const int head = (int)(r % p.H);
   const int b = (int)(r / p.H);
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
   for (int s = 0; s < p.nsplit; ++s) {
-    const f32x4 v = *(const f32x4*)(p.dkv_part + ((((long long)s * p.B + b) * p.H + head) * p.Skv + key) * 128 +
-                                    which * 64 + d4);
+    const f32x4 v = *(const f32x4*)(p.dkv_part + ((((long long)s * p.B + b) * p.H + head) * p.Skv + key) * 2 * D +
+                                    which * D + d4);
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[j] += v[j];
   }
-  bf16* dst = which ? p.dV + ((long long)b * p.Skv + key) * p.lddv + head * 64 + d4
-                    : p.dK + ((long long)b * p.Skv + key) * p.lddk + head * 64 + d4;
+  bf16* dst = which ? p.dV + ((long long)b * p.Skv + key) * p.lddv + head * D + d4
+                    : p.dK + ((long long)b * p.Skv + key) * p.lddk + head * D + d4;
   bf16x4 o;
   if (p.accum_dkv) o = *(const bf16x4*)dst;
 #pragma unroll
@@ -473,9 +508,9 @@ int attention_bwd_nsplit(int B, int H, int Sq, int Skv) {
   int ns = nt / 4;                               // 256 queries per split
   return ns < 1 ? 1 : ns;
 }
-size_t attention_bwd_scratch_bytes(int B, int H, int Sq, int Skv) {
+size_t attention_bwd_scratch_bytes(int B, int H, int Sq, int Skv, int nd) {
   const int ns = attention_bwd_nsplit(B, H, Sq, Skv);
-  return ns > 1 ? (size_t)ns * B * H * Skv * 128 * sizeof(float) : 0;
+  return ns > 1 ? (size_t)ns * B * H * Skv * 128 * nd * sizeof(float) : 0;
 }
 
 static int g_attn_use_tr = 1;
@@ -483,57 +518,90 @@ extern "C" void pea_debug_set_attn_tr(int v) { g_attn_use_tr = v; }
 
 static int attn_check(const AttnP& p) {
   SHAPECHK(p.B > 0 && p.H > 0 && p.Sq > 0 && p.Skv > 0, "attention: empty problem");
+  SHAPECHK(p.nd >= 1 && p.nd <= 3, "attention: padded head_dim must be 64, 128 or 192 (nd=%d)", p.nd);
   SHAPECHK(p.Sq % 4 == 0, "attention: Sq=%d must be a multiple of 4", p.Sq);
   SHAPECHK(p.ldq % 8 == 0 && p.ldk % 8 == 0 && p.ldv % 8 == 0, "attention: leading dims must be multiples of 8");
   return PEA_OK;
 }
 
-int launch_attention_fwd(const AttnP& p, hipStream_t s) {
+#define ATTN_DISPATCH(KERNEL_TR, KERNEL_NOTR, grid, lds)                                        \
+  do {                                                                                          \
+    if (g_attn_use_tr) hipLaunchKernelGGL(KERNEL_TR, grid, dim3(256), lds, s, p);               \
+    else hipLaunchKernelGGL(KERNEL_NOTR, grid, dim3(256), lds, s, p);                           \
+  } while (0)
+
+template <int ND>
+static int attn_set_lds_attr() {
+  static bool done = false;
+  if (done) return PEA_OK;
+  const int lq = 2 * 2 * ND * TILE_BYTES, lk = 2 * (2 * ND * TILE_BYTES + 512);
+  HIPCHK(hipFuncSetAttribute((const void*)attn_q_kernel<0, true, ND>, hipFuncAttributeMaxDynamicSharedMemorySize, lq));
+  HIPCHK(hipFuncSetAttribute((const void*)attn_q_kernel<0, false, ND>, hipFuncAttributeMaxDynamicSharedMemorySize, lq));
+  HIPCHK(hipFuncSetAttribute((const void*)attn_q_kernel<1, true, ND>, hipFuncAttributeMaxDynamicSharedMemorySize, lq));
+  HIPCHK(hipFuncSetAttribute((const void*)attn_q_kernel<1, false, ND>, hipFuncAttributeMaxDynamicSharedMemorySize, lq));
+  HIPCHK(hipFuncSetAttribute((const void*)attn_dkv_kernel<true, ND>, hipFuncAttributeMaxDynamicSharedMemorySize, lk));
+  HIPCHK(hipFuncSetAttribute((const void*)attn_dkv_kernel<false, ND>, hipFuncAttributeMaxDynamicSharedMemorySize, lk));
+  done = true;
+  return PEA_OK;
+}
+
+template <int ND>
+static int attn_fwd_nd(const AttnP& p, hipStream_t s) {
+  int rc = attn_set_lds_attr<ND>();
+  if (rc) return rc;
+  const dim3 grid(cdiv(p.Sq, 128), p.H, p.B);
+  ATTN_DISPATCH((attn_q_kernel<0, true, ND>), (attn_q_kernel<0, false, ND>), grid, 2 * 2 * ND * TILE_BYTES);
+  return PEA_OK;
+}
+template <int ND>
+static int attn_bwd_nd(const AttnP& p, hipStream_t s) {
+  int rc = attn_set_lds_attr<ND>();
+  if (rc) return rc;
+  if (p.dQ) {
+    const dim3 grid(cdiv(p.Sq, 128) * ND, p.H, p.B);
+    ATTN_DISPATCH((attn_q_kernel<1, true, ND>), (attn_q_kernel<1, false, ND>), grid, 2 * 2 * ND * TILE_BYTES);
+  }
+  if (p.dK && p.dV) {
+    const dim3 grid(cdiv(p.Skv, 128) * (p.nsplit > 1 ? p.nsplit : 1) * ND, p.H, p.B);
+    ATTN_DISPATCH((attn_dkv_kernel<true, ND>), (attn_dkv_kernel<false, ND>), grid, 2 * (2 * ND * TILE_BYTES + 512));
+    if (p.nsplit > 1) {
+      const long long total = (long long)p.B * p.H * p.Skv * 2 * 16 * ND;
+      hipLaunchKernelGGL(attn_dkv_reduce_kernel, dim3((unsigned)cdivl(total, 256)), dim3(256), 0, s, p);
+    }
+  }
+  return PEA_OK;
+}
+
+int launch_attention_fwd(const AttnP& p0, hipStream_t s) {
+  AttnP p = p0;
+  if (p.nd == 0) p.nd = 1;
   int rc = attn_check(p);
   if (rc) return rc;
   SHAPECHK(p.ldo % 4 == 0, "attention: ldo %% 4");
-  const dim3 grid(cdiv(p.Sq, 128), p.H, p.B);
-  if (g_prof_on) { g_prof_tag[0] = p.B * p.H; g_prof_tag[1] = p.Sq; g_prof_tag[2] = p.Skv; }
-  PROF_BEGIN(2, 4.0 * p.B * p.H * (double)p.Sq * p.Skv * 64, 2.0 * p.B * p.H * 64 * (2.0 * p.Sq + 2.0 * p.Skv), s);
-  if (g_attn_use_tr)
-    hipLaunchKernelGGL((attn_q_kernel<0, true>), grid, dim3(256), 4 * TILE_BYTES, s, p);
-  else
-    hipLaunchKernelGGL((attn_q_kernel<0, false>), grid, dim3(256), 4 * TILE_BYTES, s, p);
+  if (g_prof_on) { g_prof_tag[0] = p.B * p.H; g_prof_tag[1] = p.Sq; g_prof_tag[2] = p.Skv; g_prof_tag[3] = p.nd; }
+  PROF_BEGIN(2, 4.0 * p.B * p.H * (double)p.Sq * p.Skv * 64 * p.nd, 2.0 * p.B * p.H * 64 * p.nd * (2.0 * p.Sq + 2.0 * p.Skv), s);
+  rc = p.nd == 1 ? attn_fwd_nd<1>(p, s) : p.nd == 2 ? attn_fwd_nd<2>(p, s) : attn_fwd_nd<3>(p, s);
   PROF_END(s);
+  if (rc) return rc;
   HIPCHK(hipGetLastError());
   return PEA_OK;
 }
 
 int launch_attention_bwd(const AttnP& p0, hipStream_t s) {
   AttnP p = p0;
+  if (p.nd == 0) p.nd = 1;
   p.nsplit = p.dkv_part ? attention_bwd_nsplit(p.B, p.H, p.Sq, p.Skv) : 1;
   int rc = attn_check(p);
   if (rc) return rc;
   SHAPECHK(p.lse && p.delta && p.dO && p.O, "attention bwd: lse/delta/dO/O required");
   const long long total = (long long)p.B * p.Sq * p.H * 8;
-  // algorithmic: 5 products (S, dP, dV, dK, dQ) = 10*B*H*Sq*Skv*64 flops (the two-kernel form recomputes S and dP)
-  if (g_prof_on) { g_prof_tag[0] = p.B * p.H; g_prof_tag[1] = p.Sq; g_prof_tag[2] = p.Skv; }
-  PROF_BEGIN(3, 10.0 * p.B * p.H * (double)p.Sq * p.Skv * 64, 2.0 * p.B * p.H * 64 * (4.0 * p.Sq + 4.0 * p.Skv), s);
+  // algorithmic: 5 products (S, dP, dV, dK, dQ) = 10*B*H*Sq*Skv*D flops (the two-kernel form recomputes S and dP)
+  if (g_prof_on) { g_prof_tag[0] = p.B * p.H; g_prof_tag[1] = p.Sq; g_prof_tag[2] = p.Skv; g_prof_tag[3] = p.nd; }
+  PROF_BEGIN(3, 10.0 * p.B * p.H * (double)p.Sq * p.Skv * 64 * p.nd, 2.0 * p.B * p.H * 64 * p.nd * (4.0 * p.Sq + 4.0 * p.Skv), s);
   hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)cdivl(total, 256)), dim3(256), 0, s, p);
-  if (p.dQ) {
-    const dim3 grid(cdiv(p.Sq, 128), p.H, p.B);
-    if (g_attn_use_tr)
-      hipLaunchKernelGGL((attn_q_kernel<1, true>), grid, dim3(256), 4 * TILE_BYTES, s, p);
-    else
-      hipLaunchKernelGGL((attn_q_kernel<1, false>), grid, dim3(256), 4 * TILE_BYTES, s, p);
-  }
-  if (p.dK && p.dV) {
-    const dim3 grid(cdiv(p.Skv, 128) * (p.nsplit > 1 ? p.nsplit : 1), p.H, p.B);
-    if (g_attn_use_tr)
-      hipLaunchKernelGGL((attn_dkv_kernel<true>), grid, dim3(256), 2 * DKV_STAGE, s, p);
-    else
-      hipLaunchKernelGGL((attn_dkv_kernel<false>), grid, dim3(256), 2 * DKV_STAGE, s, p);
-    if (p.nsplit > 1) {
-      const long long total = (long long)p.B * p.H * p.Skv * 2 * 16;
-      hipLaunchKernelGGL(attn_dkv_reduce_kernel, dim3((unsigned)cdivl(total, 256)), dim3(256), 0, s, p);
-    }
-  }
+  rc = p.nd == 1 ? attn_bwd_nd<1>(p, s) : p.nd == 2 ? attn_bwd_nd<2>(p, s) : attn_bwd_nd<3>(p, s);
   PROF_END(s);
+  if (rc) return rc;
   HIPCHK(hipGetLastError());
   return PEA_OK;
 }

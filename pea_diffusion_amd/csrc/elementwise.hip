@@ -577,3 +577,27 @@ int launch_prefetch(const void* p, long long bytes, int* sink, hipStream_t s) {
   HIPCHK(hipGetLastError());
   return PEA_OK;
 }
+
+// ---- Linear weight [N_t][K_t] fp32 (torch) -> bf16 forward layout w[st_n][ldw] and dgrad layout wt[st_k][ldwt] with the
+// per-head dimension padded from d to dp: mode 1 pads ROWS (to_q/to_k/to_v: row = head*d + j), mode 2 pads COLUMNS
+// (to_out: input feature = head*d + j).  Padding entries are zeros; every stored element is written exactly once.
+__global__ void pad_gather_kernel(const float* __restrict__ src, int N_t, int K_t, int mode, int d, int dp,
+                                  bf16* __restrict__ w, int ldw, bf16* __restrict__ wt, int ldwt, int st_n, int st_k) {
+  EW_LOOP(i, (long long)st_n * st_k) {
+    const int rp = (int)(i / st_k), kp = (int)(i % st_k);
+    int r = rp, k = kp;
+    bool pad = false;
+    if (mode == 1) { const int h = rp / dp, j = rp - h * dp; pad = j >= d; r = h * d + j; }
+    else if (mode == 2) { const int h = kp / dp, j = kp - h * dp; pad = j >= d; k = h * d + j; }
+    const float v = pad ? 0.f : src[(long long)r * K_t + k];
+    w[(long long)rp * ldw + kp] = (bf16)v;
+    if (wt) wt[(long long)kp * ldwt + rp] = (bf16)v;
+  }
+}
+int launch_pad_gather(const float* src, int N_t, int K_t, int mode, int d, int dp, bf16* w, int ldw, bf16* wt, int ldwt,
+                      int st_n, int st_k, hipStream_t s) {
+  hipLaunchKernelGGL(pad_gather_kernel, dim3(EW_GRID((long long)st_n * st_k)), dim3(256), 0, s, src, N_t, K_t, mode, d,
+                     dp, w, ldw, wt, ldwt, st_n, st_k);
+  HIPCHK(hipGetLastError());
+  return PEA_OK;
+}

@@ -45,6 +45,9 @@ struct WSlot {
   size_t off_f32 = (size_t)-1, off_w = (size_t)-1, off_wt = (size_t)-1;
   int fused_parent = -1;     // index of the fused matrix this slot is a row block of
   int row_off = 0;
+  // head padding (heads whose width d is not a multiple of 64 are stored dp = 64*ceil(d/64) wide, zero filled)
+  int pad_mode = 0, pad_d = 0, pad_dp = 0;   // 1: rows (to_q/k/v), 2: columns (to_out)
+  int st_n = 0, st_k = 0;    // stored (padded) dims of a LINEAR weight
 };
 
 struct FusedMat {            // several Linear weights stacked along N sharing one input

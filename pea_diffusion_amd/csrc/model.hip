@@ -40,7 +40,16 @@ struct Builder {
     return id;
   }
   int vec(const std::string& n, int d) { return slot(n, W_VEC, d, 0, d); }
-  int lin(const std::string& n, int N, int K) { return slot(n, W_LINEAR, N, K, (long long)N * K); }
+  // N, K: stored dims; pad_mode/d/dp describe how they relate to the torch tensor (see WSlot)
+  int lin(const std::string& n, int N, int K, int pad_mode = 0, int d = 0, int dp = 0) {
+    int Nt = N, Kt = K;
+    if (pad_mode == 1) Nt = N / dp * d;
+    if (pad_mode == 2) Kt = K / dp * d;
+    const int id = slot(n, W_LINEAR, Nt, Kt, (long long)Nt * Kt);
+    WSlot& s = u.slots[id];
+    s.st_n = N; s.st_k = K; s.pad_mode = pad_mode; s.pad_d = d; s.pad_dp = dp;
+    return id;
+  }
   int conv3(const std::string& n, int Co, int Ci) { return slot(n, W_CONV3, Co, Ci, 9LL * Co * Ci); }
 
   Op& push(int kind) {
@@ -49,9 +58,9 @@ struct Builder {
     u.ops.push_back(o);
     return u.ops.back();
   }
-  int linear(int x, const std::string& pfx, int N, bool bias, int res = -1) {
+  int linear(int x, const std::string& pfx, int N, bool bias, int res = -1, int pad_mode = 0, int d = 0, int dp = 0) {
     const int K = u.tn[x].cols;
-    const int w = lin(pfx + ".weight", N, K);
+    const int w = lin(pfx + ".weight", N, K, pad_mode, d, dp);
     const int b = bias ? vec(pfx + ".bias", N) : -1;
     const int out = T(u.tn[x].rows, N, u.tn[x].B, u.tn[x].H, u.tn[x].W);
     Op& o = push(OP_LINEAR);
@@ -59,7 +68,8 @@ struct Builder {
     return out;
   }
   // several Linear layers over the same input, stacked along N (one GEMM)
-  int fused_linear(int x, const std::vector<std::string>& pfx, const std::vector<int>& Ns, bool bias) {
+  int fused_linear(int x, const std::vector<std::string>& pfx, const std::vector<int>& Ns, bool bias,
+                   const std::vector<int>* pad_d = nullptr, const std::vector<int>* pad_dp = nullptr) {
     const int K = u.tn[x].cols;
     FusedMat f;
     f.K = K; f.has_bias = bias;
@@ -67,7 +77,8 @@ struct Builder {
     const int fi = (int)u.fused.size() - 1;
     int off = 0;
     for (size_t i = 0; i < pfx.size(); ++i) {
-      const int w = lin(pfx[i] + ".weight", Ns[i], K);
+      const bool padded = pad_d && (*pad_d)[i] != (*pad_dp)[i];
+      const int w = padded ? lin(pfx[i] + ".weight", Ns[i], K, 1, (*pad_d)[i], (*pad_dp)[i]) : lin(pfx[i] + ".weight", Ns[i], K);
       u.slots[w].fused_parent = fi; u.slots[w].row_off = off;
       if (bias) {
         const int b = vec(pfx[i] + ".bias", Ns[i]);
@@ -137,31 +148,37 @@ struct Builder {
     const int C = u.tn[x].cols;
     const Tn t0 = u.tn[x];
     const int S = t0.H * t0.W;
+    const int d = C / heads, nd = (d + 63) / 64, dp = 64 * nd, Cp = heads * dp;   // heads stored dp wide (zero padded)
+    const bool padded = dp != d;
+    const std::vector<int> vd3{d, d, d}, vdp3{dp, dp, dp};
     int h = gn(x, pfx + ".norm", false, 1e-6f);
     h = linear(h, pfx + ".proj_in", C, true);
     for (int i = 0; i < depth; ++i) {
       const std::string bp = pfx + ".transformer_blocks." + std::to_string(i);
       int n1 = ln(h, bp + ".norm1");
-      int qkv = fused_linear(n1, {bp + ".attn1.to_q", bp + ".attn1.to_k", bp + ".attn1.to_v"}, {C, C, C}, false);
-      int a1 = T(t0.rows, C, t0.B, t0.H, t0.W);
+      int qkv = fused_linear(n1, {bp + ".attn1.to_q", bp + ".attn1.to_k", bp + ".attn1.to_v"}, {Cp, Cp, Cp}, false, &vd3,
+                             &vdp3);
+      int a1 = T(t0.rows, Cp, t0.B, t0.H, t0.W);
       {
         Op& o = push(OP_ATTN);
-        o.a = qkv; o.acol = 0; o.b = qkv; o.bcol = C; o.c = qkv; o.ccol = 2 * C; o.out = a1;
-        o.p0 = heads; o.p1 = S; o.p2 = S; o.aux_bytes = sizeof(float) * t0.B * heads * S;
+        o.a = qkv; o.acol = 0; o.b = qkv; o.bcol = Cp; o.c = qkv; o.ccol = 2 * Cp; o.out = a1;
+        o.p0 = heads; o.p1 = S; o.p2 = S; o.p3 = nd; o.f0 = 1.0f / sqrtf((float)d);
+        o.aux_bytes = sizeof(float) * t0.B * heads * S;
       }
-      h = linear(a1, bp + ".attn1.to_out.0", C, true, h);
+      h = linear(a1, bp + ".attn1.to_out.0", C, true, h, padded ? 2 : 0, d, dp);
       int n2 = ln(h, bp + ".norm2");
-      int q2 = linear(n2, bp + ".attn2.to_q", C, false);
+      int q2 = linear(n2, bp + ".attn2.to_q", Cp, false, -1, padded ? 1 : 0, d, dp);
       // K|V of every cross-attention layer come from ONE GEMM over encoder_hidden_states (u.t_kvall)
       const int kv = u.t_kvall, kvo = kv_off;
-      kv_off += 2 * C;
-      int a2 = T(t0.rows, C, t0.B, t0.H, t0.W);
+      kv_off += 2 * Cp;
+      int a2 = T(t0.rows, Cp, t0.B, t0.H, t0.W);
       {
         Op& o = push(OP_ATTN);
-        o.a = q2; o.acol = 0; o.b = kv; o.bcol = kvo; o.c = kv; o.ccol = kvo + C; o.out = a2;
-        o.p0 = heads; o.p1 = S; o.p2 = u.L; o.aux_bytes = sizeof(float) * t0.B * heads * S;
+        o.a = q2; o.acol = 0; o.b = kv; o.bcol = kvo; o.c = kv; o.ccol = kvo + Cp; o.out = a2;
+        o.p0 = heads; o.p1 = S; o.p2 = u.L; o.p3 = nd; o.f0 = 1.0f / sqrtf((float)d);
+        o.aux_bytes = sizeof(float) * t0.B * heads * S;
       }
-      h = linear(a2, bp + ".attn2.to_out.0", C, true, h);
+      h = linear(a2, bp + ".attn2.to_out.0", C, true, h, padded ? 2 : 0, d, dp);
       int n3 = ln(h, bp + ".norm3");
       int hg = linear(n3, bp + ".ff.net.0.proj", 8 * C, true);
       int g = T(t0.rows, 4 * C, t0.B, t0.H, t0.W);
@@ -176,22 +193,29 @@ struct Builder {
 };
 
 // (prefix, C) of every BasicTransformerBlock in creation order (to build the stacked K|V projection)
-std::vector<std::pair<std::string, int>> enumerate_cross_attn(const PeaUnetCfg& c) {
-  std::vector<std::pair<std::string, int>> r;
+struct CrossAttnInfo { std::string pfx; int C, heads; };
+std::vector<CrossAttnInfo> enumerate_cross_attn(const PeaUnetCfg& c) {
+  std::vector<CrossAttnInfo> r;
   const int n = c.n_levels;
+  int cur_heads = 0;
   auto add = [&](const std::string& pfx, int C, int depth) {
-    for (int k = 0; k < depth; ++k) r.push_back({pfx + ".transformer_blocks." + std::to_string(k) + ".attn2", C});
+    for (int k = 0; k < depth; ++k) r.push_back({pfx + ".transformer_blocks." + std::to_string(k) + ".attn2", C, cur_heads});
   };
   for (int i = 0; i < n; ++i)
     if (c.down_cross[i])
-      for (int j = 0; j < c.layers_per_block; ++j)
+      for (int j = 0; j < c.layers_per_block; ++j) {
+        cur_heads = c.heads[i];
         add("down_blocks." + std::to_string(i) + ".attentions." + std::to_string(j), c.block_out[i], c.depth[i]);
+      }
+  cur_heads = c.heads[n - 1];
   add("mid_block.attentions.0", c.block_out[n - 1], c.depth[n - 1]);
   for (int i = 0; i < n; ++i)
     if (c.up_cross[i])
-      for (int j = 0; j < c.layers_per_block + 1; ++j)
+      for (int j = 0; j < c.layers_per_block + 1; ++j) {
+        cur_heads = c.heads[n - 1 - i];
         add("up_blocks." + std::to_string(i) + ".attentions." + std::to_string(j), c.block_out[n - 1 - i],
             c.depth[n - 1 - i]);
+      }
   return r;
 }
 
@@ -217,9 +241,10 @@ int Unet::build() {
   for (int i = 0; i < c.n_levels; ++i) {
     SHAPECHK(c.block_out[i] % 64 == 0, "unet: block_out_channels[%d]=%d must be a multiple of 64", i, c.block_out[i]);
     if (c.down_cross[i] || c.up_cross[c.n_levels - 1 - i] || i == c.n_levels - 1)
-      SHAPECHK(c.heads[i] * 64 == c.block_out[i],
-               "unet: level %d has %d heads over %d channels; only head_dim 64 is implemented in HIP", i, c.heads[i],
-               c.block_out[i]);
+      SHAPECHK(c.heads[i] > 0 && c.block_out[i] % c.heads[i] == 0 && c.block_out[i] / c.heads[i] <= 192 &&
+                   (c.block_out[i] / c.heads[i]) % 8 == 0,
+               "unet: level %d has %d heads over %d channels; head_dim must be a multiple of 8 and <= 192", i,
+               c.heads[i], c.block_out[i]);
   }
   SHAPECHK(c.cross_dim % 64 == 0, "unet: cross_attention_dim %% 64");
   SHAPECHK((H % (1 << (c.n_levels - 1))) == 0 && (W % (1 << (c.n_levels - 1))) == 0, "unet: latent %dx%d", H, W);
@@ -261,12 +286,14 @@ int Unet::build() {
   {   // every attn2.to_k / attn2.to_v stacked into one GEMM over encoder_hidden_states
     auto ca = enumerate_cross_attn(c);
     std::vector<std::string> names;
-    std::vector<int> ns;
+    std::vector<int> ns, pd, pdp;
     for (auto& r : ca) {
-      names.push_back(r.first + ".to_k"); ns.push_back(r.second);
-      names.push_back(r.first + ".to_v"); ns.push_back(r.second);
+      const int d = r.C / r.heads, dp = (d + 63) / 64 * 64, Cp = r.heads * dp;
+      for (const char* nm : {".to_k", ".to_v"}) {
+        names.push_back(r.pfx + nm); ns.push_back(Cp); pd.push_back(d); pdp.push_back(dp);
+      }
     }
-    t_kvall = bd.fused_linear(t_ehs, names, ns, false);
+    t_kvall = bd.fused_linear(t_ehs, names, ns, false, &pd, &pdp);
     ops.back().p3 = 2;                      // backward: split-K dgrad (few rows, very deep K)
     kvall_total = tn[t_kvall].cols;
   }
@@ -349,8 +376,9 @@ int Unet::alloc() {
       if (s.fused_parent >= 0) continue;
       if (s.kind == W_VEC || s.kind == W_CONV_IN || s.kind == W_CONV_OUT) { s.off_f32 = off; off += al256(s.numel * 4); }
       else {
-        s.off_w = off; off += al256(s.numel * 2);
-        if (s.need_wt) { s.off_wt = off; off += al256(s.numel * 2); }
+        const size_t st = s.kind == W_LINEAR ? (size_t)s.st_n * s.st_k : (size_t)s.numel;
+        s.off_w = off; off += al256(st * 2);
+        if (s.need_wt) { s.off_wt = off; off += al256(st * 2); }
       }
     }
     wbytes = off;
@@ -373,11 +401,11 @@ int Unet::alloc() {
       if (s.off_f32 != (size_t)-1) s.f32 = (float*)(warena + s.off_f32);
       if (s.off_w != (size_t)-1) {
         s.w = (bf16*)(warena + s.off_w);
-        s.ldw = s.kind == W_CONV3 ? 9 * s.d1 : s.d1;
+        s.ldw = s.kind == W_CONV3 ? 9 * s.d1 : s.st_k;
       }
       if (s.off_wt != (size_t)-1) {
         s.wt = (bf16*)(warena + s.off_wt);
-        s.ldwt = s.kind == W_CONV3 ? 9 * s.d0 : s.d0;
+        s.ldwt = s.kind == W_CONV3 ? 9 * s.d0 : s.st_n;
       }
     }
     tmp_f32_elems = max_numel;
@@ -405,7 +433,7 @@ int Unet::alloc() {
   for (Op& o : ops) {
     if (o.kind == OP_ATTN) {
       delta_elems = std::max(delta_elems, (size_t)B * o.p0 * o.p1);
-      part_bytes = std::max(part_bytes, attention_bwd_scratch_bytes(B, o.p0, o.p1, o.p2));
+      part_bytes = std::max(part_bytes, attention_bwd_scratch_bytes(B, o.p0, o.p1, o.p2, o.p3));
     }
     if (o.kind == OP_CONV3 && o.p1 && tn[o.a].rg)
       ups_elems = std::max(ups_elems, (size_t)tn[o.out].rows * tn[o.a].cols);
@@ -463,8 +491,12 @@ int Unet::load_weight(const char* name, const float* src, long long numel, hipSt
       RC(launch_pack_conv_out(src, w.f32, w.d0, w.d1, s));
       break;
     case W_LINEAR:
-      RC(launch_cast_f32_bf16(src, w.w, numel, s));
-      if (w.wt) RC(launch_transpose_f32_bf16(src, w.wt, w.d0, w.d1, w.ldwt, s));
+      if (w.pad_mode) {
+        RC(launch_pad_gather(src, w.d0, w.d1, w.pad_mode, w.pad_d, w.pad_dp, w.w, w.ldw, w.wt, w.ldwt, w.st_n, w.st_k, s));
+      } else {
+        RC(launch_cast_f32_bf16(src, w.w, numel, s));
+        if (w.wt) RC(launch_transpose_f32_bf16(src, w.wt, w.d0, w.d1, w.ldwt, s));
+      }
       break;
     case W_CONV3:
       RC(launch_pack_conv_fwd(src, w.w, w.d0, w.d1, s));
@@ -605,7 +637,7 @@ int Unet::forward(const float* x, const float* t, const void* ehs, int ehs_dtype
         AttnP p; memset(&p, 0, sizeof(p));
         p.Q = tn[o.a].d + o.acol; p.ldq = tn[o.a].cols; p.K = tn[o.b].d + o.bcol; p.ldk = tn[o.b].cols;
         p.V = tn[o.c].d + o.ccol; p.ldv = tn[o.c].cols; p.O = tn[o.out].d; p.ldo = tn[o.out].cols; p.lse = o.aux;
-        p.B = B; p.H = o.p0; p.Sq = o.p1; p.Skv = o.p2; p.scale = 0.125f;
+        p.B = B; p.H = o.p0; p.Sq = o.p1; p.Skv = o.p2; p.scale = o.f0; p.nd = o.p3;
         RC(launch_attention_fwd(p, s));
         break;
       }
@@ -742,7 +774,8 @@ int Unet::backward(const float* deps, hipStream_t s) {
         Tn &q = tn[o.a], &k = tn[o.b], &v = tn[o.c];
         AttnP p; memset(&p, 0, sizeof(p));
         p.Q = q.d + o.acol; p.ldq = q.cols; p.K = k.d + o.bcol; p.ldk = k.cols; p.V = v.d + o.ccol; p.ldv = v.cols;
-        p.O = out.d; p.ldo = out.cols; p.lse = o.aux; p.B = B; p.H = o.p0; p.Sq = o.p1; p.Skv = o.p2; p.scale = 0.125f;
+        p.O = out.d; p.ldo = out.cols; p.lse = o.aux; p.B = B; p.H = o.p0; p.Sq = o.p1; p.Skv = o.p2; p.scale = o.f0;
+        p.nd = o.p3;
         p.dO = out.g; p.lddo = out.cols; p.delta = delta; p.dkv_part = attn_part;
         SHAPECHK(!q.gw && (!k.gw || o.b == t_kvall), "unet: attention operand gradient written twice");
         if (q.rg) { p.dQ = q.g + o.acol; p.lddq = q.cols; }

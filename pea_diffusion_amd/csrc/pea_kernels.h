@@ -59,7 +59,8 @@ int launch_layernorm_bwd(const bf16* x, const bf16* dy, const float* gamma, cons
                          float* dgamma, float* dbeta, int R, int C, int accum, hipStream_t s);
 
 // ---------------------------------------------------------------- attention.hip
-// O[b][q][h*64+d] = softmax(scale * Q K^T) V per (b, head); head_dim = 64.
+// O[b][q][h*D+d] = softmax(scale * Q K^T) V per (b, head); D = 64*nd (nd = 1, 2, 3); heads whose true width is
+// not a multiple of 64 are stored zero-padded (the scale stays that of the true width).
 // Q rows stride ldq elements, batch stride = Sq*ldq (same for K,V with Skv, ldk/ldv).
 struct AttnP {
   const bf16 *Q, *K, *V; int ldq, ldk, ldv;
@@ -73,9 +74,10 @@ struct AttnP {
   float* delta;                    // [B][H][Sq] scratch: rowsum(dO * O)
   int accum_dq, accum_dkv;         // += into existing gradients
   float* dkv_part; int nsplit;     // optional fp32 scratch (attention_bwd_scratch_bytes) enabling the query split
+  int nd;                          // padded head_dim / 64 (0 is read as 1)
 };
 int attention_bwd_nsplit(int B, int H, int Sq, int Skv);
-size_t attention_bwd_scratch_bytes(int B, int H, int Sq, int Skv);
+size_t attention_bwd_scratch_bytes(int B, int H, int Sq, int Skv, int nd = 1);
 int launch_attention_fwd(const AttnP& p, hipStream_t s);
 int launch_attention_bwd(const AttnP& p, hipStream_t s);
 
@@ -166,3 +168,5 @@ void prof_end_impl(hipStream_t s);
 #define PROF_BEGIN(fam, flops, bytes, s) do { if (g_prof_on) prof_begin_impl(fam, flops, bytes, s); } while (0)
 #define PROF_END(s) do { if (g_prof_on) prof_end_impl(s); } while (0)
 int launch_prefetch(const void* p, long long bytes, int* sink, hipStream_t s);
+int launch_pad_gather(const float* src, int N_t, int K_t, int mode, int d, int dp, bf16* w, int ldw, bf16* wt, int ldwt,
+                      int st_n, int st_k, hipStream_t s);

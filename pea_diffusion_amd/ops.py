@@ -123,28 +123,30 @@ def layernorm_bwd(x, dy, gamma, stats, want_param_grads=False, accum_into=None):
 
 
 def attention_fwd(q, k, v, heads, scale=None):
-    """q [B,Sq,H*64], k/v [B,Skv,H*64] bf16 -> (o [B,Sq,H*64], lse [B,H,Sq])."""
+    """q [B,Sq,H*D], k/v [B,Skv,H*D] bf16 (D = 64, 128 or 192: zero-padded heads) -> (o, lse [B,H,Sq])."""
     B, Sq, C = q.shape
     Skv = k.shape[1]
-    scale = scale if scale is not None else 64 ** -0.5
+    nd = C // heads // 64
+    scale = scale if scale is not None else (C // heads) ** -0.5
     o = torch.empty(B, Sq, C, device=q.device, dtype=BF)
     lse = torch.empty(B, heads, Sq, device=q.device, dtype=torch.float32)
     check(lib().pea_op_attention_fwd(ptr(q), q.stride(1), ptr(k), k.stride(1), ptr(v), v.stride(1), ptr(o), C, ptr(lse),
-                                     B, heads, Sq, Skv, scale, stream_ptr()))
+                                     B, heads, Sq, Skv, scale, nd, stream_ptr()))
     return o, lse
 
 
 def attention_bwd(q, k, v, o, do, lse, heads, scale=None):
     B, Sq, C = q.shape
     Skv = k.shape[1]
-    scale = scale if scale is not None else 64 ** -0.5
+    nd = C // heads // 64
+    scale = scale if scale is not None else (C // heads) ** -0.5
     dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
     delta = torch.empty(B, heads, Sq, device=q.device, dtype=torch.float32)
-    nb = lib().pea_op_attention_bwd_scratch_bytes(B, heads, Sq, Skv)
+    nb = lib().pea_op_attention_bwd_scratch_bytes(B, heads, Sq, Skv, nd)
     scratch = torch.empty(nb, device=q.device, dtype=torch.uint8) if nb else None
     check(lib().pea_op_attention_bwd(ptr(q), q.stride(1), ptr(k), k.stride(1), ptr(v), v.stride(1), ptr(o), C, ptr(do),
                                      C, ptr(lse), ptr(delta), ptr(dq), C, ptr(dk), C, ptr(dv), C, B, heads, Sq, Skv,
-                                     scale, 0, 0, ptr(scratch), stream_ptr()))
+                                     scale, 0, 0, nd, ptr(scratch), stream_ptr()))
     return dq, dk, dv
 
 

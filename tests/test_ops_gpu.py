@@ -292,3 +292,30 @@ def test_adamw(ops):
         opt.step()
         ops.adamw_(wd, gr.cuda(), m, v, 1e-2, step, weight_decay=0.01)
     close_f32("adamw", wd, p.detach(), rtol=1e-4, atol=1e-6)
+
+
+@pytest.mark.parametrize("d,H,Sq,Skv", [(40, 8, 256, 256), (80, 4, 128, 77), (160, 2, 64, 64), (128, 2, 192, 200), (16, 8, 64, 20)])
+def test_attention_padded_heads(ops, d, H, Sq, Skv):
+    """SD1.5 head widths (40 / 80 / 160) are stored zero-padded to 64 / 128 / 192 columns; scale = d^-0.5"""
+    B = 2
+    dp = (d + 63) // 64 * 64
+    def padded(x):                       # [B,S,H,d] -> [B,S,H*dp] with zero padding
+        out = torch.zeros(B, x.shape[1], H, dp, dtype=BF)
+        out[..., :d] = x
+        return out.reshape(B, x.shape[1], H * dp)
+    q, k, v, do = [bfr(B, s_, H, d, seed=i) for i, s_ in enumerate((Sq, Skv, Skv, Sq))]
+    qr, kr, vr = [t_.float().requires_grad_(True) for t_ in (q, k, v)]
+    s = torch.einsum("bqhd,bkhd->bhqk", qr, kr) * d ** -0.5
+    oref = torch.einsum("bhqk,bkhd->bqhd", torch.softmax(s, -1), vr)
+    o, lse = ops.attention_fwd(padded(q).cuda(), padded(k).cuda(), padded(v).cuda(), H, scale=d ** -0.5)
+    og = o.float().cpu().view(B, Sq, H, dp)
+    close_bf16(f"attn d{d} O", og[..., :d], oref, ulps=2.0)
+    assert d == dp or og[..., d:].abs().max() == 0
+    close_f32(f"attn d{d} lse", lse, torch.logsumexp(s, -1), rtol=1e-3, atol=2e-3)
+    oref.backward(do.float())
+    dq, dk, dv = ops.attention_bwd(padded(q).cuda(), padded(k).cuda(), padded(v).cuda(), o, padded(do).cuda(), lse, H,
+                                   scale=d ** -0.5)
+    for name, g, r, S in (("dQ", dq, qr.grad, Sq), ("dK", dk, kr.grad, Skv), ("dV", dv, vr.grad, Skv)):
+        gg = g.float().cpu().view(B, S, H, dp)
+        close_bf16(f"attn d{d} {name}", gg[..., :d], r, ulps=4.0)
+        assert d == dp or gg[..., d:].abs().max() == 0
