@@ -18,6 +18,9 @@
 #include "pea_kernels.h"
 
 #define TILE_BYTES 8192   // 64 rows x 128 bytes
+// raw v_exp_f32: exp2f() expands to a denormal-safe 5-instruction sequence; every argument here is <= 0 (scores
+// minus a running max / the log-sum-exp), so a flushed denormal result is an exact zero after bf16 rounding anyway
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 #define LOG2E 1.4426950408889634f
 
 __device__ __forceinline__ int swz_rc(int row, int col) {   // byte offset of element (row, col) in a tile
@@ -185,12 +188,12 @@ __global__ __launch_bounds__(256, (ND == 1 ? (MODE == 0 ? 4 : 2) : 1)) void attn
       for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const float e = exp2f(fmaf(sacc[kb][r], c, -mc));
+          const float e = fast_exp2(fmaf(sacc[kb][r], c, -mc));
           sacc[kb][r] = e;
           ls += e;
         }
       if (__any(moved)) {
-        const float alpha = exp2f((m_run - m_new) * c);   // m_run = -inf on the first tile -> 0
+        const float alpha = fast_exp2((m_run - m_new) * c);   // m_run = -inf on the first tile -> 0
         l_run *= alpha;
 #pragma unroll
         for (int i = 0; i < 2 * NO; ++i)
@@ -219,7 +222,7 @@ __global__ __launch_bounds__(256, (ND == 1 ? (MODE == 0 ? 4 : 2) : 1)) void attn
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int key = kv0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
-          float pr = exp2f(fmaf(sacc[kb][r], c, -lse2));
+          float pr = fast_exp2(fmaf(sacc[kb][r], c, -lse2));
           if (kv0 + 64 > p.Skv) pr = key < p.Skv ? pr : 0.f;      // uniform branch: only the last key tile masks
           sacc[kb][r] = pr * (dpacc[kb][r] - dlt) * p.scale;
         }
@@ -384,7 +387,7 @@ __global__ __launch_bounds__(256, (ND == 1 ? 2 : 1)) void attn_dkv_kernel(const 
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
             const int r = 4 * g + j;
-            const float pr = kvalid ? exp2f(fmaf(sacc[qb][r], c, -l4[j] * LOG2E)) : 0.f;
+            const float pr = kvalid ? fast_exp2(fmaf(sacc[qb][r], c, -l4[j] * LOG2E)) : 0.f;
             const float ds = pr * (dpacc[qb][r] - d4[j]) * p.scale;
             const int ks = qb * 2 + (g >> 1), e = (g & 1) * 4 + j;
             pfr[ks][e] = (bf16)pr;
