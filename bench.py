@@ -145,6 +145,7 @@ def main():
     ap.add_argument("--cpu-budget", type=float, default=40.0)
     ap.add_argument("--cpu-baseline-worker", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--force-collective", action="store_true", help="init RCCL and all-reduce even with one rank (path test)")
     ap.add_argument("--dump-prof", default="", help="write every profiled launch (shape-tagged) to this CSV")
     ap.add_argument("--breakdown", action="store_true", help="print the per-kernel-family table to stderr")
     args = ap.parse_args()
@@ -152,15 +153,24 @@ def main():
         cpu_baseline_worker(args.model, args.cpu_budget)
         return
 
+    # stdout carries exactly ONE line (the JSON result); libraries that print to fd 1 (the RCCL banner) go to stderr
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     import torch.distributed as dist
-    if world > 1:
+    use_dist = world > 1 or args.force_collective        # --force-collective: exercise the RCCL path with one rank
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    dev = torch.device("cuda", local_rank if world > 1 else 0)
+    dev = torch.device("cuda", local_rank if use_dist else 0)
     torch.cuda.set_device(dev)
 
     from pea_diffusion_amd import config as pc
@@ -182,12 +192,19 @@ def main():
     trainer = PEATrainer(adapter, student, teacher)
     batch = synthetic_batch(cfg, B, args.ctx, enc_dim, hw, dev, seed=100 + rank)
 
+    if use_dist:
+        from pea_diffusion_amd import dist as pdist
+        pdist.broadcast_params_(adapter.flat_param, src=0)      # identical replicas
+        adapter.mark_updated()
+
     def step():
         trainer.training_step(batch)          # includes the all-reduce of the flat adapter grad when world > 1
+        if args.force_collective and world == 1:
+            dist.all_reduce(adapter.flat_grad)
         trainer.optimizer_step()
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -199,7 +216,7 @@ def main():
         step()
     barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
@@ -255,7 +272,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(args.model, args.cpu_budget)
 
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
@@ -277,7 +294,8 @@ def main():
             "hbm_resident_gb": round((mem["weight_bytes"] + 2 * mem["activation_bytes"] + mem["grad_bytes"]) / 2 ** 30, 1),
             "roofline": roof, "cpu_baseline": cpu,
         }
-        print(json.dumps(out))
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
 
 
 if __name__ == "__main__":

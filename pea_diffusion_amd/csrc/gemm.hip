@@ -659,8 +659,8 @@ __global__ __launch_bounds__((WM * WN + LW) * 64) void gemm_lc_kernel(const Gemm
       // tile t+1 must have landed; tiles t+2 .. t+S-1 may stay in flight (tile t+S is issued after the barrier)
       if (t + S - 1 < nt) wait_vmcnt<(S - 2) * PP>();
       else wait_vmcnt<0>();
-      __builtin_amdgcn_s_barrier();                            // barrier_t
-      if (t + S < nt) issue(cur, kb0 + (t + S) * BK);
+      if (!(p.debug & 2)) __builtin_amdgcn_s_barrier();        // barrier_t
+      if (t + S < nt && !(p.debug & 1)) issue(cur, kb0 + (t + S) * BK);
       cur = cur + 1 == S ? 0 : cur + 1;
     }
     return;
@@ -696,11 +696,11 @@ __global__ __launch_bounds__((WM * WN + LW) * 64) void gemm_lc_kernel(const Gemm
       if (s == 3) {
         if (t + 1 < nt) {
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-          __builtin_amdgcn_s_barrier();                        // barrier_t
-          load_frags(0, smem + nxt * STAGE, 0);
+          if (!(p.debug & 2)) __builtin_amdgcn_s_barrier();    // barrier_t
+          if (!(p.debug & 4)) load_frags(0, smem + nxt * STAGE, 0);
         }
       } else {
-        load_frags((s + 1) & 1, tile, s + 1);
+        if (!(p.debug & 4)) load_frags((s + 1) & 1, tile, s + 1);
       }
 #pragma unroll
       for (int ni = 0; ni < NI; ++ni)
@@ -797,6 +797,8 @@ static int pick_variant(const GemmP& p) {
   return 12;
 }
 
+int g_gemm_debug = 0;
+extern "C" void pea_debug_set_gemm_debug(int v) { g_gemm_debug = v; }
 int g_gemm_lds_epilogue = 0;   // measured round 1: a net loss in situ (multi-pass on 256-wide tiles); kept for experiments
 extern "C" void pea_debug_set_gemm_lds_epilogue(int v) { g_gemm_lds_epilogue = v; }
 
@@ -821,6 +823,7 @@ int launch_gemm(const GemmP& p_in, hipStream_t stream) {
     PROF_BEGIN(p0.mode ? 1 : 0, fl, by, stream);
   }
   GemmP p = p_in;
+  p.debug = g_gemm_debug;
   p.lds_epilogue = (g_gemm_lds_epilogue && p.N % 8 == 0 && !p.preact && p.ldc % 8 == 0 && (!p.res || p.ldres % 8 == 0)) ? 1 : 0;
   int v = pick_variant(p);
   if (p.ksplit > 1) {

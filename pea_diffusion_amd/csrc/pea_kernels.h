@@ -27,6 +27,7 @@ struct GemmP {
   int parity;                      // 1: only even virtual coordinates are real (transposed stride-2 conv)
   const bf16* zeros;               // >= 16 bytes of zeros (out-of-bounds taps)
   int lds_epilogue;                // set by launch_gemm: transpose the tile through LDS for coalesced stores
+  int debug;                       // timing experiments only (scripts/gemm_loop_probe.py)
   int ksplit; long long split_stride;   // split-K: fp32 partial s is written at C + s*split_stride (then launch_splitk_reduce)
 };
 int launch_splitk_reduce(const float* part, int nsplit, long long stride, bf16* out, int ldo, int M, int N, int accum,
