@@ -203,6 +203,72 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmP& p, f32x16 (&acc)[
   }
 }
 
+// ---- epilogue for the 16x16x32 accumulator layout: acc[nt][mt][j] = D[n = 4*(lane>>4) + j][m = lane&15]
+template <int MT, int NT>
+__device__ __forceinline__ void gemm_epilogue16(const GemmP& p, f32x4 (&acc)[NT][MT], int m_base, int n_base, int r16,
+                                                int q4) {
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    const int m = m_base + mt * 16 + r16;
+    if (m >= p.M) continue;
+    const int bidx = p.rowvec ? m / p.rows_per_batch : 0;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int n = n_base + nt * 16 + 4 * q4;
+      if (n >= p.N) continue;
+      float v[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] = acc[nt][mt][j] * p.alpha;
+      if (p.bias) {
+        const f32x4 b = *(const f32x4*)(p.bias + n);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] += b[j];
+      }
+      if (p.rowvec) {
+        const bf16x4 rv = *(const bf16x4*)(p.rowvec + (long long)bidx * p.ldrv + n);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] += (float)rv[j];
+      }
+      if (p.preact) {
+        bf16x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = (bf16)v[j];
+        *(bf16x4*)(p.preact + (long long)m * p.ldpre + n) = o;
+      }
+      if (p.act == 1) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = gelu_erf(v[j]);
+      } else if (p.act == 2) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = siluf_(v[j]);
+      }
+      if (p.res) {
+        const bf16x4 rr = *(const bf16x4*)(p.res + (long long)m * p.ldres + n);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] += (float)rr[j];
+      }
+      if (p.out_f32) {
+        float* cp = (float*)p.C + (long long)m * p.ldc + n;
+        f32x4 o;
+        if (p.accum_f32) {
+          o = *(const f32x4*)cp;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) o[j] += v[j];
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) o[j] = v[j];
+        }
+        *(f32x4*)cp = o;
+      } else {
+        bf16x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = (bf16)v[j];
+        *(bf16x4*)((bf16*)p.C + (long long)m * p.ldc + n) = o;
+      }
+    }
+  }
+}
+
 // Block tile BM x BN x 64, WM x WN waves (each (BM/WM) x (BN/WN), built from 32x32x16 MFMAs), S-stage LDS
 // ring filled by LDS-DMA with a counted vmcnt: tile t+S-1 is issued while tile t is consumed, ONE raw
 // s_barrier per K-step (it orders "tile t landed for every wave" and "everyone finished tile t-1").
@@ -546,7 +612,7 @@ static int launch_pipe(const GemmP& p, hipStream_t stream) {
 //   consumer t: sub-steps 0..2 of tile t, lgkmcnt(0) -> barrier_t -> prefetch (t+1, 0), sub-step 3 of tile t
 // After barrier_t every consumer has issued and retired all reads of tile t's LDS slot, so the ring runs S
 // tiles ahead (all S slots in flight).
-template <int MODE, int BM, int BN, int WM, int WN, int LW, int S>
+template <int MODE, int BM, int BN, int WM, int WN, int LW, int S, bool PROBE16 = false, bool M16 = false>
 __global__ __launch_bounds__((WM * WN + LW) * 64) void gemm_lc_kernel(const GemmP p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int NWC = WM * WN;
@@ -667,6 +733,57 @@ __global__ __launch_bounds__((WM * WN + LW) * 64) void gemm_lc_kernel(const Gemm
   }
 
   // ================================ consumer waves
+  if constexpr (M16) {
+    // 16x16x32 MFMAs (sustain a higher clock than 32x32x16 on this chip) with a (BM/WM) x (BN/WN) wave tile built
+    // from 16-row fragments: e.g. 2 x 2 waves of 64 x 80 on the 128 x 160 tile -> 9 fragment reads per 20 MFMAs
+    // instead of 12, the fragment ds_reads being the main in-loop loss of the 32x32 form.
+    constexpr int MT = BM / WM / 16, NT = BN / WN / 16;
+    const int wr = wave / WN, wc = wave % WN;
+    const int r16 = lane & 15, q4 = lane >> 4;
+    const int a_row0 = wr * (BM / WM) + r16, w_row0 = wc * (BN / WN) + r16;
+    f32x4 acc[NT][MT];
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+#pragma unroll
+      for (int j = 0; j < MT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    bf16x8 af[2][MT], wf[2][NT];
+    auto load_frags = [&](int which, const char* tile, int s2) {
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) af[which][mt] = *(const bf16x8*)(tile + swz_off(a_row0 + mt * 16, 4 * s2 + q4));
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+        wf[which][nt] = *(const bf16x8*)(tile + A_BYTES + swz_off(w_row0 + nt * 16, 4 * s2 + q4));
+    };
+    __builtin_amdgcn_s_barrier();                              // prologue barrier
+    load_frags(0, smem, 0);
+    int cur = 0;
+    for (int t = 0; t < nt; ++t) {
+      const char* tile = smem + cur * STAGE;
+      const int nxt = cur + 1 == S ? 0 : cur + 1;
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        if (s2 == 1) {
+          if (t + 1 < nt) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                      // barrier_t
+            load_frags(0, smem + nxt * STAGE, 0);
+          }
+        } else {
+          load_frags(1, tile, 1);
+        }
+#pragma unroll
+        for (int nt_ = 0; nt_ < NT; ++nt_)
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt)
+            acc[nt_][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[s2][nt_], af[s2][mt], acc[nt_][mt], 0, 0, 0);
+      }
+      cur = nxt;
+    }
+    GemmP q = p;
+    if (p.ksplit > 1) q.C = (float*)p.C + (long long)blockIdx.y * p.split_stride;
+    gemm_epilogue16<MT, NT>(q, acc, bm * BM + wr * (BM / WM), bn * BN + wc * (BN / WN), r16, q4);
+    return;
+  }
   const int wr = wave / WN, wc = wave % WN;
   const int frow = lane & 31, fh = lane >> 5;
   const int a_row0 = wr * (BM / WM) + frow, w_row0 = wc * (BN / WN) + frow;
@@ -702,11 +819,25 @@ __global__ __launch_bounds__((WM * WN + LW) * 64) void gemm_lc_kernel(const Gemm
       } else {
         if (!(p.debug & 4)) load_frags((s + 1) & 1, tile, s + 1);
       }
+      if constexpr (PROBE16) {    // timing probe: same FLOPs as 16x16x32 MFMAs (2 per 32x32x16), results meaningless
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+          for (int mi = 0; mi < MI; ++mi) {
+            f32x4 q0 = {acc[ni][mi][0], acc[ni][mi][1], acc[ni][mi][2], acc[ni][mi][3]};
+            f32x4 q1 = {acc[ni][mi][4], acc[ni][mi][5], acc[ni][mi][6], acc[ni][mi][7]};
+            q0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[s & 1][ni], af[s & 1][mi], q0, 0, 0, 0);
+            q1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[s & 1][ni], af[s & 1][mi], q1, 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { acc[ni][mi][j] = q0[j]; acc[ni][mi][4 + j] = q1[j]; }
+          }
+      } else {
 #pragma unroll
       for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi)
           acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[s & 1][ni], af[s & 1][mi], acc[ni][mi], 0, 0, 0);
+      }
     }
     cur = nxt;
   }
@@ -722,18 +853,18 @@ __global__ __launch_bounds__((WM * WN + LW) * 64) void gemm_lc_kernel(const Gemm
     gemm_epilogue<MI, NI>(p, acc, bm * BM + wr * (BM / WM), bn * BN + wc * (BN / WN), frow, fh);
 }
 
-template <int MODE, int BM, int BN, int WM, int WN, int LW, int S>
+template <int MODE, int BM, int BN, int WM, int WN, int LW, int S, bool PROBE16 = false, bool M16 = false>
 static int launch_lc(const GemmP& p, hipStream_t stream) {
   constexpr int lds = S * (BM + BN) * 128;
   static_assert(lds <= 160 * 1024, "LDS budget");
   static bool attr_set = false;
   if (!attr_set) {
-    HIPCHK(hipFuncSetAttribute((const void*)gemm_lc_kernel<MODE, BM, BN, WM, WN, LW, S>,
+    HIPCHK(hipFuncSetAttribute((const void*)gemm_lc_kernel<MODE, BM, BN, WM, WN, LW, S, PROBE16, M16>,
                                hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     attr_set = true;
   }
   const int grid = cdiv(p.M, BM) * cdiv(p.N, BN);
-  hipLaunchKernelGGL((gemm_lc_kernel<MODE, BM, BN, WM, WN, LW, S>), dim3(grid, p.ksplit > 1 ? p.ksplit : 1),
+  hipLaunchKernelGGL((gemm_lc_kernel<MODE, BM, BN, WM, WN, LW, S, PROBE16, M16>), dim3(grid, p.ksplit > 1 ? p.ksplit : 1),
                      dim3((WM * WN + LW) * 64), lds, stream, p);
   return PEA_OK;
 }
@@ -777,24 +908,33 @@ static int launch_variant(const GemmP& p, hipStream_t stream) {
     case 16: rc = launch_lc<MODE, 256, 128, 4, 2, 4, 3>(p, stream); break; \
     case 18: rc = launch_lc<MODE, 128, 128, 2, 2, 4, 4>(p, stream); break; \
     case 19: rc = launch_lc<MODE, 128, 160, 4, 1, 4, 3>(p, stream); break; \
+    case 20: rc = launch_lc<MODE, 128, 160, 4, 1, 4, 3, true>(p, stream); break; /* timing probe only */ \
+    case 21: rc = launch_lc<MODE, 128, 160, 2, 2, 4, 3, false, true>(p, stream); break; \
+    case 22: rc = launch_lc<MODE, 128, 160, 2, 2, 4, 4, false, true>(p, stream); break; \
+    case 23: rc = launch_lc<MODE, 128, 128, 2, 2, 4, 4, false, true>(p, stream); break; \
+    case 24: rc = launch_lc<MODE, 256, 160, 4, 2, 4, 3, false, true>(p, stream); break; \
+    case 25: rc = launch_lc<MODE, 128, 160, 4, 2, 4, 3, false, true>(p, stream); break; \
+    case 26: rc = launch_lc<MODE, 128, 160, 4, 2, 4, 4, false, true>(p, stream); break; \
     default: rc = launch_variant<MODE, 128, 128, 2, 2, 2>(p, stream); break; \
   }
 
 static int pick_variant(const GemmP& p) {
   if (g_gemm_variant >= 0) return g_gemm_variant;
-  // measured on the step's shapes with scripts/gemm_bench.py (profiles/r01_gemm_variants.log):
-  //   19 = loader/consumer 128x160 (4 MFMA + 4 DMA waves, 3 stages)   15 = loader/consumer 256x160 (4+4, 3 stages)
-  //   18 = loader/consumer 128x128 (4+4, 4 stages)                     10 = pipelined 256x128, 8 waves, 3 stages
-  //   12 = pipelined 256x256, 8 waves, 2 stages
+  // measured on the step's shapes with scripts/gemm_bench.py (profiles/r01_gemm_variants.log); all loader/consumer
+  // kernels with 16x16x32 MFMAs unless noted:
+  //   25    = 128x160 tile, 4x2 consumer waves (32x80 each) + 4 DMA waves, 3 stages (two MFMA waves per SIMD)
+  //   22    = 128x160 tile, 2x2 consumer waves (64x80 each) + 4 DMA waves, 4 stages
+  //   24    = 256x160 tile, 4x2 consumer waves (64x80 each) + 4 DMA waves, 3 stages
+  //   23    = 128x128 tile, 2x2 consumer waves + 4 DMA waves, 4 stages
+  //   12    = software-pipelined 256x256, 8 waves, 32x32x16 MFMAs, 2 stages
   if (p.mode == 1) {
-    if (p.N <= 384) return p.K >= 5760 ? 15 : 19;   // 128^2-level convs (N = 320)
-    if (p.M >= 16384) return 15;                     // 64^2-level convs (N = 640)
-    return 19;                                       // 32^2-level convs (M = 4096, N = 1280)
+    if (p.M >= 16384) return 24;                     // 128^2- and 64^2-level convs (N = 320 / 640)
+    return 22;                                       // 32^2-level convs (M = 4096, N = 1280)
   }
-  if (p.M < 1024) return 18;                         // cross-attention K|V projections, embeddings, adapter
-  if (p.N <= 1280) return (p.M >= 8192 && p.K >= 2560) ? 15 : 19;   // 160-wide tiles fill the chip exactly
-  if (p.M <= 4096 && p.N >= 8192) return 10;
-  return 12;
+  if (p.M < 1024) return 23;                         // embeddings, adapter, stacked K|V projection (tall-skinny)
+  if (p.N <= 1280) return p.M >= 8192 ? 24 : 25;     // 160-wide tiles fill the chip exactly
+  if (p.N >= 8192) return 24;
+  return p.M <= 4096 ? 25 : 12;
 }
 
 int g_gemm_debug = 0;

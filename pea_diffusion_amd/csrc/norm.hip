@@ -272,6 +272,7 @@ int launch_groupnorm_bwd(const bf16* x, const bf16* dy, const float* gamma, cons
 // one wave per row, the whole row lives in registers (C <= 4096 -> <= 8 chunks of 8 per lane)
 #define LN_MAXCH 8
 
+template <int NCH>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const bf16* __restrict__ x, const float* __restrict__ gamma,
                                                      const float* __restrict__ beta, bf16* __restrict__ y,
                                                      float* __restrict__ stats, int R, int C, float eps) {
@@ -279,10 +280,10 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const bf16* __restrict__ x,
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= R) return;
   const int nchunk = C / 8;
-  bf16x8 v[LN_MAXCH];
+  bf16x8 v[NCH];
   float s = 0.f;
 #pragma unroll
-  for (int i = 0; i < LN_MAXCH; ++i) {
+  for (int i = 0; i < NCH; ++i) {
     const int ck = lane + 64 * i;
     if (ck < nchunk) {
       v[i] = *(const bf16x8*)(x + (long long)row * C + ck * 8);
@@ -293,7 +294,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const bf16* __restrict__ x,
   const float mean = wave_sum(s) / (float)C;
   float q = 0.f;
 #pragma unroll
-  for (int i = 0; i < LN_MAXCH; ++i) {
+  for (int i = 0; i < NCH; ++i) {
     const int ck = lane + 64 * i;
     if (ck < nchunk) {
 #pragma unroll
@@ -309,7 +310,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const bf16* __restrict__ x,
     stats[2 * (long long)row + 1] = rstd;
   }
 #pragma unroll
-  for (int i = 0; i < LN_MAXCH; ++i) {
+  for (int i = 0; i < NCH; ++i) {
     const int ck = lane + 64 * i;
     if (ck < nchunk) {
       bf16x8 o;
@@ -321,6 +322,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const bf16* __restrict__ x,
   }
 }
 
+template <int NCH>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16* __restrict__ x, const bf16* __restrict__ dy,
                                                      const float* __restrict__ gamma,
                                                      const float* __restrict__ stats, bf16* __restrict__ dx,
@@ -331,10 +333,10 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16* __restrict__ x,
   if (row >= R) return;
   const int nchunk = C / 8;
   const float mean = stats[2 * (long long)row], rstd = stats[2 * (long long)row + 1];
-  bf16x8 xv[LN_MAXCH], dv[LN_MAXCH];
+  bf16x8 xv[NCH], dv[NCH];
   float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-  for (int i = 0; i < LN_MAXCH; ++i) {
+  for (int i = 0; i < NCH; ++i) {
     const int ck = lane + 64 * i;
     if (ck < nchunk) {
       xv[i] = *(const bf16x8*)(x + (long long)row * C + ck * 8);
@@ -351,7 +353,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16* __restrict__ x,
   s1 = wave_sum(s1) / (float)C;
   s2 = wave_sum(s2) / (float)C;
 #pragma unroll
-  for (int i = 0; i < LN_MAXCH; ++i) {
+  for (int i = 0; i < NCH; ++i) {
     const int ck = lane + 64 * i;
     if (ck < nchunk) {
       bf16x8 o;
@@ -373,7 +375,10 @@ int launch_layernorm_fwd(const bf16* x, const float* gamma, const float* beta, b
                          float eps, hipStream_t s) {
   SHAPECHK(C % 8 == 0 && C <= 64 * 8 * LN_MAXCH, "layernorm: C=%d unsupported", C);
   PROF_BEGIN(5, 0.0, 4.0 * R * (double)C, s);
-  hipLaunchKernelGGL(ln_fwd_kernel, dim3(cdiv(R, 4)), dim3(256), 0, s, x, gamma, beta, y, stats, R, C, eps);
+  const int nch = cdiv(C / 8, 64);          // 16-byte chunks per lane: the row lives in registers
+#define LN_FWD(N) hipLaunchKernelGGL(ln_fwd_kernel<N>, dim3(cdiv(R, 4)), dim3(256), 0, s, x, gamma, beta, y, stats, R, C, eps)
+  if (nch <= 1) LN_FWD(1); else if (nch == 2) LN_FWD(2); else if (nch == 3) LN_FWD(3); else if (nch == 4) LN_FWD(4); else LN_FWD(8);
+#undef LN_FWD
   PROF_END(s);
   HIPCHK(hipGetLastError());
   return PEA_OK;
@@ -400,9 +405,10 @@ int launch_layernorm_bwd(const bf16* x, const bf16* dy, const float* gamma, cons
                          float* dgamma, float* dbeta, int R, int C, int accum, hipStream_t s) {
   SHAPECHK(C % 8 == 0 && C <= 64 * 8 * LN_MAXCH, "layernorm: C=%d unsupported", C);
   PROF_BEGIN(5, 0.0, 6.0 * R * (double)C, s);
-  if (dx)
-    hipLaunchKernelGGL(ln_bwd_kernel, dim3(cdiv(R, 4)), dim3(256), 0, s, x, dy, gamma, stats, dx, dgamma, dbeta, R, C,
-                       accum);
+  const int nch = cdiv(C / 8, 64);
+#define LN_BWD(N) hipLaunchKernelGGL(ln_bwd_kernel<N>, dim3(cdiv(R, 4)), dim3(256), 0, s, x, dy, gamma, stats, dx, dgamma, dbeta, R, C, accum)
+  if (dx) { if (nch <= 1) LN_BWD(1); else if (nch == 2) LN_BWD(2); else if (nch == 3) LN_BWD(3); else if (nch == 4) LN_BWD(4); else LN_BWD(8); }
+#undef LN_BWD
   if (dgamma) hipLaunchKernelGGL(ln_param_grad_kernel, dim3(cdiv(C, 64)), dim3(64), 0, s, x, dy, stats, dgamma, dbeta, R, C);
   PROF_END(s);
   HIPCHK(hipGetLastError());

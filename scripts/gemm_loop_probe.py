@@ -12,12 +12,12 @@ def timeit(fn, iters=30):
     for _ in range(iters): fn()
     e.record(); torch.cuda.synchronize()
     return s.elapsed_time(e) / iters * 1e3
-for (M, N, K, v) in [(4096, 1280, 5120, 19), (4096, 1280, 1280, 19), (8192, 1280, 5120, 15), (16384, 640, 2560, 19)]:
+for (M, N, K, v) in [(4096, 1280, 5120, 19), (4096, 1280, 5120, 20), (4096, 1280, 1280, 19), (4096, 1280, 1280, 20), (16384, 640, 2560, 19), (16384, 640, 2560, 20)]:
     a = torch.randn(M, K, device="cuda").to(BF); w = (torch.randn(N, K, device="cuda") * K ** -0.5).to(BF)
     out = torch.empty(M, N, device="cuda", dtype=BF)
     L.pea_debug_set_gemm_variant(v)
     line = f"M{M} N{N} K{K} v{v}: "
-    for dbg, name in [(0, "full"), (1, "noDMA"), (3, "noDMA+noBarrier"), (7, "MFMA only"), (2, "noBarrier"), (4, "no ds_read")]:
+    for dbg, name in [(0, "full"), (1, "noDMA"), (3, "noDMA+noBarrier"), (7, "MFMA only"), (2, "noBarrier")]:
         L.pea_debug_set_gemm_debug(dbg)
         t = timeit(lambda: ops.gemm(a, w, out=out))
         line += f"{name} {t:6.1f}us ({2*M*N*K/t/1e6:5.0f} TF) | "
