@@ -934,7 +934,7 @@ static int pick_variant(const GemmP& p) {
   if (p.M < 1024) return 23;                         // embeddings, adapter, stacked K|V projection (tall-skinny)
   if (p.N <= 1280) return p.M >= 8192 ? 24 : 25;     // 160-wide tiles fill the chip exactly
   if (p.N >= 8192) return 24;
-  return p.M <= 4096 ? 25 : 12;
+  return p.M <= 4096 ? 25 : 24;
 }
 
 int g_gemm_debug = 0;
