@@ -589,6 +589,7 @@ __global__ void pad_gather_kernel(const float* __restrict__ src, int N_t, int K_
     bool pad = false;
     if (mode == 1) { const int h = rp / dp, j = rp - h * dp; pad = j >= d; r = h * d + j; }
     else if (mode == 2) { const int h = kp / dp, j = kp - h * dp; pad = j >= d; k = h * d + j; }
+    else if (mode == 3) { r = (rp & 1) ? (st_n >> 1) + (rp >> 1) : (rp >> 1); }   // GEGLU proj: rows interleaved (h_i, gate_i)
     const float v = pad ? 0.f : src[(long long)r * K_t + k];
     w[(long long)rp * ldw + kp] = (bf16)v;
     if (wt) wt[(long long)kp * ldwt + rp] = (bf16)v;
@@ -598,6 +599,57 @@ int launch_pad_gather(const float* src, int N_t, int K_t, int mode, int d, int d
                       int st_n, int st_k, hipStream_t s) {
   hipLaunchKernelGGL(pad_gather_kernel, dim3(EW_GRID((long long)st_n * st_k)), dim3(256), 0, s, src, N_t, K_t, mode, d,
                      dp, w, ldw, wt, ldwt, st_n, st_k);
+  HIPCHK(hipGetLastError());
+  return PEA_OK;
+}
+
+// ---- GEGLU on the INTERLEAVED pre-activation layout hg[r][2i] = h_i, hg[r][2i+1] = gate_i (fused FF-proj epilogue)
+__global__ void geglu_il_kernel(const bf16* __restrict__ hg, const bf16* __restrict__ dy, bf16* __restrict__ out,
+                                long long rows, int inner, int bwd) {
+  const int ck = inner / 4;                       // 4 (h, gate) pairs = one 16-byte chunk of hg
+  EW_LOOP(i, rows * ck) {
+    const long long r = i / ck;
+    const int c = (int)(i - r * ck) * 4;
+    const bf16x8 v = *(const bf16x8*)(hg + r * 2 * inner + 2 * c);
+    if (!bwd) {
+      bf16x4 o;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) o[j] = (bf16)((float)v[2 * j] * gelu_erf((float)v[2 * j + 1]));
+      *(bf16x4*)(out + r * inner + c) = o;
+    } else {
+      const bf16x4 d = *(const bf16x4*)(dy + r * inner + c);
+      bf16x8 o;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float hf = (float)v[2 * j], gf = (float)v[2 * j + 1], df = (float)d[j];
+        o[2 * j] = (bf16)(df * gelu_erf(gf));
+        o[2 * j + 1] = (bf16)(df * hf * gelu_erf_grad(gf));
+      }
+      *(bf16x8*)(out + r * 2 * inner + 2 * c) = o;
+    }
+  }
+}
+int launch_geglu_fwd_il(const bf16* hg, bf16* y, long long rows, int inner, hipStream_t s) {
+  SHAPECHK(inner % 4 == 0, "geglu: inner %% 4");
+  PROF_BEGIN(6, 0.0, 2.0 * 3.0 * rows * inner, s);
+  hipLaunchKernelGGL(geglu_il_kernel, dim3(EW_GRID(rows * (inner / 4))), dim3(256), 0, s, hg, nullptr, y, rows, inner, 0);
+  PROF_END(s);
+  HIPCHK(hipGetLastError());
+  return PEA_OK;
+}
+int launch_geglu_bwd_il(const bf16* hg, const bf16* dy, bf16* dhg, long long rows, int inner, hipStream_t s) {
+  SHAPECHK(inner % 4 == 0, "geglu: inner %% 4");
+  PROF_BEGIN(6, 0.0, 2.0 * 5.0 * rows * inner, s);
+  hipLaunchKernelGGL(geglu_il_kernel, dim3(EW_GRID(rows * (inner / 4))), dim3(256), 0, s, hg, dy, dhg, rows, inner, 1);
+  PROF_END(s);
+  HIPCHK(hipGetLastError());
+  return PEA_OK;
+}
+__global__ void permute_geglu_vec_kernel(const float* __restrict__ src, float* __restrict__ dst, int inner) {
+  EW_LOOP(i, 2LL * inner) dst[i] = (i & 1) ? src[inner + (i >> 1)] : src[i >> 1];
+}
+int launch_permute_geglu_vec(const float* src, float* dst, int inner, hipStream_t s) {
+  hipLaunchKernelGGL(permute_geglu_vec_kernel, dim3(EW_GRID(2LL * inner)), dim3(256), 0, s, src, dst, inner);
   HIPCHK(hipGetLastError());
   return PEA_OK;
 }

@@ -68,6 +68,13 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x16 (&acc)[NI][
 #pragma unroll
           for (int j = 0; j < 4; ++j) v[j] += (float)rv[j];
         }
+        if (p.geglu_y) {            // v = (h_a, gate_a, h_b, gate_b) after bias
+          bf16x2 y;
+          y[0] = (bf16)(v[0] * gelu_erf(v[1]));
+          y[1] = (bf16)(v[2] * gelu_erf(v[3]));
+          *(bf16x2*)(p.geglu_y + (long long)m * p.ldy + (n >> 1)) = y;
+          if (!p.C) continue;
+        }
         if (p.preact) {
           bf16x4 o;
 #pragma unroll
@@ -228,6 +235,13 @@ __device__ __forceinline__ void gemm_epilogue16(const GemmP& p, f32x4 (&acc)[NT]
         const bf16x4 rv = *(const bf16x4*)(p.rowvec + (long long)bidx * p.ldrv + n);
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[j] += (float)rv[j];
+      }
+      if (p.geglu_y) {            // v = (h_a, gate_a, h_b, gate_b) after bias
+        bf16x2 y;
+        y[0] = (bf16)(v[0] * gelu_erf(v[1]));
+        y[1] = (bf16)(v[2] * gelu_erf(v[3]));
+        *(bf16x2*)(p.geglu_y + (long long)m * p.ldy + (n >> 1)) = y;
+        if (!p.C) continue;
       }
       if (p.preact) {
         bf16x4 o;
@@ -964,7 +978,7 @@ int launch_gemm(const GemmP& p_in, hipStream_t stream) {
   }
   GemmP p = p_in;
   p.debug = g_gemm_debug;
-  p.lds_epilogue = (g_gemm_lds_epilogue && p.N % 8 == 0 && !p.preact && p.ldc % 8 == 0 && (!p.res || p.ldres % 8 == 0)) ? 1 : 0;
+  p.lds_epilogue = (g_gemm_lds_epilogue && !p.geglu_y && p.N % 8 == 0 && !p.preact && p.ldc % 8 == 0 && (!p.res || p.ldres % 8 == 0)) ? 1 : 0;
   int v = pick_variant(p);
   if (p.ksplit > 1) {
     SHAPECHK(p.out_f32 && !p.accum_f32 && !p.bias && !p.res && !p.rowvec && !p.preact && p.act == 0 && p.mode == 0,

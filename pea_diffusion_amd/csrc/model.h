@@ -46,7 +46,7 @@ struct WSlot {
   int fused_parent = -1;     // index of the fused matrix this slot is a row block of
   int row_off = 0;
   // head padding (heads whose width d is not a multiple of 64 are stored dp = 64*ceil(d/64) wide, zero filled)
-  int pad_mode = 0, pad_d = 0, pad_dp = 0;   // 1: rows (to_q/k/v), 2: columns (to_out)
+  int pad_mode = 0, pad_d = 0, pad_dp = 0;   // 1: rows (to_q/k/v), 2: columns (to_out), 3: GEGLU (h_i, gate_i) row interleave
   int st_n = 0, st_k = 0;    // stored (padded) dims of a LINEAR weight
 };
 
@@ -98,6 +98,7 @@ struct Unet {
   int t_ehs = -1, t_text = -1, t_tproj = -1, t_out_in = -1, t_kvall = -1;
   int tproj_total = 0, kvall_total = 0, kv_nsplit = 1;
   float* kv_part = nullptr;
+  bf16* geglu_tmp = nullptr;
   // arenas
   char* warena = nullptr; size_t wbytes = 0; bool owns_weights = true;
   char* aarena = nullptr; size_t abytes = 0;

@@ -180,11 +180,16 @@ struct Builder {
       }
       h = linear(a2, bp + ".attn2.to_out.0", C, true, h, padded ? 2 : 0, d, dp);
       int n3 = ln(h, bp + ".norm3");
-      int hg = linear(n3, bp + ".ff.net.0.proj", 8 * C, true);
+      // FF projection with GEGLU fused into the GEMM epilogue: weight rows interleaved (h_i, gate_i) at load time;
+      // `g` = h * gelu(gate); the [rows][8C] pre-activation (op.c) is kept only when a backward pass will need it
       int g = T(t0.rows, 4 * C, t0.B, t0.H, t0.W);
       {
-        Op& o = push(OP_GEGLU);
-        o.a = hg; o.out = g;
+        const int w = lin(bp + ".ff.net.0.proj.weight", 8 * C, C, 3, 0, 0);
+        const int bsl = vec(bp + ".ff.net.0.proj.bias", 8 * C);
+        u.slots[bsl].pad_mode = 3;
+        const int hg = u.needs_grad ? T(t0.rows, 8 * C, t0.B, t0.H, t0.W) : -1;
+        Op& o = push(OP_LINEAR);
+        o.a = n3; o.w = w; o.bias = bsl; o.out = g; o.c = hg; o.p3 = 3;
       }
       h = linear(g, bp + ".ff.net.2", C, true, h);
     }
@@ -350,7 +355,7 @@ int Unet::build() {
   // requires-grad propagation + which weights need a dgrad layout
   for (Op& o : ops) {
     bool rg = false;
-    for (int t : {o.a, o.b, o.c, o.res, o.rv})
+    for (int t : {o.a, o.b, o.kind == OP_LINEAR ? -1 : o.c, o.res, o.rv})
       if (t >= 0 && tn[t].rg) rg = true;
     if (o.out >= 0) tn[o.out].rg = tn[o.out].rg || rg;
     if ((o.kind == OP_LINEAR || o.kind == OP_CONV3) && o.a >= 0 && tn[o.a].rg) {
@@ -429,12 +434,13 @@ int Unet::alloc() {
   for (Op& o : ops)
     if (o.aux_bytes) o.aux = (float*)(aarena + o.aux_off);
   // ---- scratch
-  size_t delta_elems = 0, ups_elems = 0, part_bytes = 0;
+  size_t delta_elems = 0, ups_elems = 0, part_bytes = 0, geglu_elems = 0;
   for (Op& o : ops) {
     if (o.kind == OP_ATTN) {
       delta_elems = std::max(delta_elems, (size_t)B * o.p0 * o.p1);
       part_bytes = std::max(part_bytes, attention_bwd_scratch_bytes(B, o.p0, o.p1, o.p2, o.p3));
     }
+    if (o.kind == OP_LINEAR && o.p3 == 3 && o.c >= 0) geglu_elems = std::max(geglu_elems, (size_t)tn[o.c].rows * tn[o.c].cols);
     if (o.kind == OP_CONV3 && o.p1 && tn[o.a].rg)
       ups_elems = std::max(ups_elems, (size_t)tn[o.out].rows * tn[o.a].cols);
   }
@@ -448,6 +454,7 @@ int Unet::alloc() {
   if (needs_grad) {
     if (delta_elems) HIPCHK(hipMalloc((void**)&delta, delta_elems * 4));
     if (ups_elems) HIPCHK(hipMalloc((void**)&ups_tmp, ups_elems * 2));
+    if (geglu_elems) HIPCHK(hipMalloc((void**)&geglu_tmp, geglu_elems * 2));
     if (part_bytes) HIPCHK(hipMalloc((void**)&attn_part, part_bytes));
     {
       const int ksteps = kvall_total / 64;
@@ -472,6 +479,7 @@ Unet::~Unet() {
   if (cs_scratch) hipFree(cs_scratch);
   if (attn_part) hipFree(attn_part);
   if (kv_part) hipFree(kv_part);
+  if (geglu_tmp) hipFree(geglu_tmp);
 }
 
 int Unet::load_weight(const char* name, const float* src, long long numel, hipStream_t s) {
@@ -484,6 +492,9 @@ int Unet::load_weight(const char* name, const float* src, long long numel, hipSt
   SHAPECHK(numel == w.numel, "unet: weight '%s' has %lld elements, expected %lld", name, numel, w.numel);
   switch (w.kind) {
     case W_VEC:
+      if (w.pad_mode == 3) { RC(launch_permute_geglu_vec(src, w.f32, (int)(numel / 2), s)); break; }
+      HIPCHK(hipMemcpyAsync(w.f32, src, numel * 4, hipMemcpyDeviceToDevice, s));
+      break;
     case W_CONV_IN:
       HIPCHK(hipMemcpyAsync(w.f32, src, numel * 4, hipMemcpyDeviceToDevice, s));
       break;
@@ -595,6 +606,10 @@ int Unet::forward(const float* x, const float* t, const void* ehs, int ehs_dtype
         if (o.fused >= 0) { FusedMat& f = fused[o.fused]; p.W = f.w; p.ldw = f.K; p.bias = f.bias; }
         else { WSlot& w = slots[o.w]; p.W = w.w; p.ldw = w.ldw; p.bias = o.bias >= 0 ? slots[o.bias].f32 : nullptr; }
         p.C = out.d; p.ldc = out.cols;
+        if (o.p3 == 3) {                  // fused GEGLU: N = 8C interleaved, y -> out, pre-activation -> op.c (student only)
+          p.N = 2 * out.cols; p.geglu_y = out.d; p.ldy = out.cols;
+          p.C = o.c >= 0 ? tn[o.c].d : nullptr; p.ldc = 2 * out.cols;
+        }
         if (o.res >= 0) { p.res = tn[o.res].d; p.ldres = tn[o.res].cols; }
         RC(launch_gemm(p, s));
         break;
@@ -690,6 +705,19 @@ int Unet::backward(const float* deps, hipStream_t s) {
           p.ksplit = kv_nsplit; p.split_stride = (long long)out.rows * a.cols;
           RC(launch_gemm(p, s));
           RC(launch_splitk_reduce(kv_part, kv_nsplit, p.split_stride, a.g, a.cols, (int)a.rows, a.cols, a.gw, s));
+          a.gw = true;
+          break;
+        }
+        if (a.rg && o.p3 == 3) {          // fused GEGLU: d(pre-activation) into scratch, then the dgrad GEMM over K = 8C
+          Tn& hg = tn[o.c];
+          RC(launch_geglu_bwd_il(hg.d, out.g, geglu_tmp, out.rows, out.cols, s));
+          WSlot& w = slots[o.w];
+          GemmP p; fill_gemm(p);
+          p.A = geglu_tmp; p.lda = hg.cols; p.M = (int)out.rows; p.K = hg.cols; p.N = a.cols;
+          p.W = w.wt; p.ldw = w.ldwt; p.C = a.g; p.ldc = a.cols;
+          SHAPECHK(p.W != nullptr, "unet: dgrad weights missing for op %d", oi);
+          if (a.gw) { p.res = a.g; p.ldres = a.cols; }
+          RC(launch_gemm(p, s));
           a.gw = true;
           break;
         }

@@ -43,11 +43,27 @@ void pea_set_error(const char* fmt, ...);
     }                                                                                          \
   } while (0)
 
-__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+// erf by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7, i.e. fp32-epsilon level; every consumer rounds to bf16):
+// 1 v_rcp + 1 v_exp + 7 fma/mul instead of libm's two-branch erff -- the GELU sits in GEMM epilogues where the
+// VALU work is not hidden behind HBM
+__device__ __forceinline__ float erf_fast(float x, float* exp_mx2 = nullptr) {
+  const float ax = fabsf(x);
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));
+  float p = fmaf(t, 1.061405429f, -1.453152027f);
+  p = fmaf(t, p, 1.421413741f);
+  p = fmaf(t, p, -0.284496736f);
+  p = fmaf(t, p, 0.254829592f);
+  p *= t;
+  const float e = __builtin_amdgcn_exp2f(-1.4426950408889634f * ax * ax);   // exp(-x^2)
+  if (exp_mx2) *exp_mx2 = e;
+  return copysignf(fmaf(-p, e, 1.0f), x);
+}
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erf_fast(x * 0.70710678118654752f)); }
 __device__ __forceinline__ float gelu_erf_grad(float x) {
-  // d/dx [x * Phi(x)] = Phi(x) + x * phi(x)
-  const float phi = 0.39894228040143268f * __expf(-0.5f * x * x);
-  return 0.5f * (1.0f + erff(x * 0.70710678118654752f)) + x * phi;
+  // d/dx [x * Phi(x)] = Phi(x) + x * phi(x);  phi(x) = exp(-x^2/2)/sqrt(2 pi) shares the exponential with erf(x/sqrt2)
+  float e;
+  const float er = erf_fast(x * 0.70710678118654752f, &e);
+  return 0.5f * (1.0f + er) + x * 0.39894228040143268f * e;
 }
 // v_rcp_f32 (1 ulp) instead of a correctly rounded division (~10 VALU instructions); results are stored as bf16
 __device__ __forceinline__ float sigmoidf_(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }

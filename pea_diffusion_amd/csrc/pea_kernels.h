@@ -28,6 +28,9 @@ struct GemmP {
   const bf16* zeros;               // >= 16 bytes of zeros (out-of-bounds taps)
   int lds_epilogue;                // set by launch_gemm: transpose the tile through LDS for coalesced stores
   int debug;                       // timing experiments only (scripts/gemm_loop_probe.py)
+  // fused GEGLU: the weight rows are interleaved (h_i, gate_i) so a lane's 4 consecutive columns are two pairs;
+  // geglu_y[m][n/2] = h * gelu(gate).  C may be null then (no pre-activation stash: teacher / inference).
+  bf16* geglu_y; int ldy;
   int ksplit; long long split_stride;   // split-K: fp32 partial s is written at C + s*split_stride (then launch_splitk_reduce)
 };
 int launch_splitk_reduce(const float* part, int nsplit, long long stride, bf16* out, int ldo, int M, int N, int accum,
@@ -171,3 +174,6 @@ void prof_end_impl(hipStream_t s);
 int launch_prefetch(const void* p, long long bytes, int* sink, hipStream_t s);
 int launch_pad_gather(const float* src, int N_t, int K_t, int mode, int d, int dp, bf16* w, int ldw, bf16* wt, int ldwt,
                       int st_n, int st_k, hipStream_t s);
+int launch_geglu_bwd_il(const bf16* hg, const bf16* dy, bf16* dhg, long long rows, int inner, hipStream_t s);
+int launch_geglu_fwd_il(const bf16* hg, bf16* y, long long rows, int inner, hipStream_t s);
+int launch_permute_geglu_vec(const float* src, float* dst, int inner, hipStream_t s);
