@@ -22,22 +22,8 @@ __device__ __forceinline__ int swz_off(int row, int chunk) { return row * 128 + 
 
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
-  if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-  else if constexpr (N == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-  else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-  else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-  else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-  else if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-  else if constexpr (N == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-  else if constexpr (N == 9) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
-  else if constexpr (N == 13) asm volatile("s_waitcnt vmcnt(13)" ::: "memory");
-  else if constexpr (N == 18) asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
-  else if constexpr (N == 24) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
-  else if constexpr (N == 26) asm volatile("s_waitcnt vmcnt(26)" ::: "memory");
-  else if constexpr (N == 27) asm volatile("s_waitcnt vmcnt(27)" ::: "memory");
-  else if constexpr (N == 32) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
-  else static_assert(N == 0, "add the vmcnt literal");
+  static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit counter");
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
 // ---- epilogue shared by both kernels.  acc[ni][mi][4g+j] = D[n = 8g + 4h + j][m = lane&31]
@@ -883,6 +869,219 @@ static int launch_lc(const GemmP& p, hipStream_t stream) {
   return PEA_OK;
 }
 
+// ------------------------------------------------------------------------------------------------
+// PERSISTENT loader / consumer kernel (16x16x32 MFMAs).  One block per CU walks its share of the output tiles;
+// the K-steps of consecutive tiles form ONE stream through the LDS ring, so while the consumer waves run the
+// epilogue of tile i the DMA waves already have the first S K-steps of tile i+1 in flight / landed -- the per-tile
+// prologue (address setup + HBM/L2 latency of the first stages) and the block relaunch disappear for every tile
+// but the first.  With K = 640 .. 1280 that fixed cost was 35-55 % of a tile (scripts/gemm_ksweep.py).
+// Tile order: XCD x owns a contiguous range of (grouped) tile ids, its CUs take them round-robin, so the CUs
+// of an XCD work on neighbouring tiles at any time (shared A rows / W columns in that XCD's L2).
+template <int MODE, int BM, int BN, int WM, int WN, int LW, int S>
+__global__ __launch_bounds__((WM * WN + LW) * 64) void gemm_lcp_kernel(const GemmP p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int NWC = WM * WN;
+  constexpr int STAGE = (BM + BN) * 128;
+  constexpr int A_BYTES = BM * 128;
+  constexpr int PA = BM / 8 / LW, PB = BN / 8 / LW;
+  constexpr int PP = PA + PB;
+  static_assert(BM % (8 * LW) == 0 && BN % (8 * LW) == 0, "tile / loader split");
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+  const int nbm = (p.M + BM - 1) / BM, nbn = (p.N + BN - 1) / BN;
+  const int nwg = nbm * nbn;
+  const int nblk = gridDim.x;
+  const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+  const int nbx = (nblk - xcd + 7) >> 3;                        // blocks living on this XCD
+  const int tq = nwg >> 3, tr = nwg & 7;
+  const int cnt_x = tq + (xcd < tr ? 1 : 0);                    // tiles owned by this XCD
+  const int start_x = xcd < tr ? xcd * (tq + 1) : tr * (tq + 1) + (xcd - tr) * tq;
+  const int my_n = idx < cnt_x ? (cnt_x - idx + nbx - 1) / nbx : 0;
+  const int nt = p.K / BK;
+  const int G = my_n * nt;                                      // K-steps of this block, all tiles
+  if (G == 0) return;
+  const int GROUP = 8;
+  const int per_group = GROUP * nbn;
+  auto tile_of = [&](int i, int& bm, int& bn) {
+    const int bid = start_x + idx + i * nbx;
+    const int gid = bid / per_group;
+    const int first_m = gid * GROUP;
+    const int gsize = min(nbm - first_m, GROUP);
+    const int rem = bid - gid * per_group;
+    bm = first_m + rem % gsize;
+    bn = rem / gsize;
+  };
+
+  if (wave >= NWC) {
+    // ============================== loader waves
+    const int lw = wave - NWC;
+    const int lrow = lane >> 3, cpos = lane & 7;
+    const bf16* a_src[PA];
+    int a_iy0[PA], a_ix0[PA];
+    const bf16* w_src[PB];
+    auto setup = [&](int ti) {
+      int bm, bn;
+      tile_of(ti, bm, bn);
+#pragma unroll
+      for (int j = 0; j < PA; ++j) {
+        const int r = (lw * PA + j) * 8 + lrow;
+        const int chunk = cpos ^ ((r >> 1) & 7);
+        int gm = bm * BM + r;
+        gm = gm < p.M ? gm : p.M - 1;
+        if (MODE == 0) {
+          a_src[j] = p.A + (long long)gm * p.lda + chunk * 8;
+          a_iy0[j] = a_ix0[j] = 0;
+        } else {
+          const int hw = p.Ho * p.Wo;
+          const int b = gm / hw;
+          const int rem = gm - b * hw;
+          const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+          a_iy0[j] = oy * p.stride - 1;
+          a_ix0[j] = ox * p.stride - 1;
+          a_src[j] = p.A + (long long)b * p.Hs * p.Ws * p.Cin + chunk * 8;
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < PB; ++j) {
+        const int r = (lw * PB + j) * 8 + lrow;
+        const int chunk = cpos ^ ((r >> 1) & 7);
+        int gn = bn * BN + r;
+        gn = gn < p.N ? gn : p.N - 1;
+        w_src[j] = p.W + (long long)gn * p.ldw + chunk * 8;
+      }
+    };
+    const int Hv = p.Hs << p.shift, Wv = p.Ws << p.shift;
+    auto issue = [&](int st, int k0) {
+      char* base = smem + st * STAGE;
+      int ky = 0, kx = 0, c0 = 0;
+      if (MODE == 1) {
+        const int tap = k0 / p.Cin;
+        c0 = k0 - tap * p.Cin;
+        ky = tap / 3;
+        kx = tap - ky * 3;
+      }
+#pragma unroll
+      for (int j = 0; j < PA; ++j) {
+        const bf16* src;
+        if (MODE == 0) {
+          src = a_src[j] + k0;
+        } else {
+          const int iy = a_iy0[j] + ky, ix = a_ix0[j] + kx;
+          bool ok = ((unsigned)iy < (unsigned)Hv) && ((unsigned)ix < (unsigned)Wv);
+          if (p.parity) ok = ok && (((iy | ix) & 1) == 0);
+          const int sy = iy >> p.shift, sx = ix >> p.shift;
+          src = ok ? a_src[j] + ((long long)sy * p.Ws + sx) * p.Cin + c0 : p.zeros;
+        }
+        __builtin_amdgcn_global_load_lds(PEA_GLB(src), PEA_LDS(base + (lw * PA + j) * 1024), 16, 0, 0);
+      }
+#pragma unroll
+      for (int j = 0; j < PB; ++j)
+        __builtin_amdgcn_global_load_lds(PEA_GLB(w_src[j] + k0), PEA_LDS(base + A_BYTES + (lw * PB + j) * 1024), 16,
+                                         0, 0);
+    };
+    // producer position (tile ordinal, K-step) of the next stage to issue
+    int ptile = 0, pt = 0;
+    setup(0);
+    auto produce = [&](int st) {
+      issue(st, pt * BK);
+      if (++pt == nt) {
+        pt = 0;
+        if (++ptile < my_n) setup(ptile);
+      }
+    };
+#pragma unroll
+    for (int i = 0; i < S; ++i)
+      if (i < G) produce(i);
+    if (G >= S) wait_vmcnt<(S - 1) * PP>();
+    else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();                              // prologue barrier: K-step 0 landed
+    int cur = 0;
+    for (int g = 0; g + 1 < G; ++g) {
+      if (g + S - 1 < G) wait_vmcnt<(S - 2) * PP>();           // K-step g+1 landed; g+2 .. g+S-1 may stay in flight
+      else wait_vmcnt<0>();
+      __builtin_amdgcn_s_barrier();                            // barrier_g: slot of K-step g is free
+      if (g + S < G) produce(cur);
+      cur = cur + 1 == S ? 0 : cur + 1;
+    }
+    return;
+  }
+
+  // ================================ consumer waves
+  constexpr int MT = BM / WM / 16, NT = BN / WN / 16;
+  const int wr = wave / WN, wc = wave % WN;
+  const int r16 = lane & 15, q4 = lane >> 4;
+  const int a_row0 = wr * (BM / WM) + r16, w_row0 = wc * (BN / WN) + r16;
+  bf16x8 af[2][MT], wf[2][NT];
+  auto load_frags = [&](int which, const char* tile, int s2) {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) af[which][mt] = *(const bf16x8*)(tile + swz_off(a_row0 + mt * 16, 4 * s2 + q4));
+#pragma unroll
+    for (int nt_ = 0; nt_ < NT; ++nt_)
+      wf[which][nt_] = *(const bf16x8*)(tile + A_BYTES + swz_off(w_row0 + nt_ * 16, 4 * s2 + q4));
+  };
+  __builtin_amdgcn_s_barrier();                                // prologue barrier
+  load_frags(0, smem, 0);
+  int cur = 0, g = 0;
+  for (int ti = 0; ti < my_n; ++ti) {
+    f32x4 acc[NT][MT];
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+#pragma unroll
+      for (int j = 0; j < MT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < nt; ++t, ++g) {
+      const char* tile = smem + cur * STAGE;
+      const int nxt = cur + 1 == S ? 0 : cur + 1;
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        if (s2 == 1) {
+          if (g + 1 < G) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                      // barrier_g
+            load_frags(0, smem + nxt * STAGE, 0);              // first fragments of K-step g+1 (maybe the next tile's)
+          }
+        } else {
+          load_frags(1, tile, 1);
+        }
+#pragma unroll
+        for (int nt_ = 0; nt_ < NT; ++nt_)
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt)
+            acc[nt_][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[s2][nt_], af[s2][mt], acc[nt_][mt], 0, 0, 0);
+      }
+      cur = nxt;
+    }
+    int bm, bn;
+    tile_of(ti, bm, bn);
+    gemm_epilogue16<MT, NT>(p, acc, bm * BM + wr * (BM / WM), bn * BN + wc * (BN / WN), r16, q4);
+  }
+}
+
+static int g_num_cus = 0;
+template <int MODE, int BM, int BN, int WM, int WN, int LW, int S>
+static int launch_lcp(const GemmP& p, hipStream_t stream) {
+  constexpr int lds = S * (BM + BN) * 128;
+  static_assert(lds <= 160 * 1024, "LDS budget");
+  static bool attr_set = false;
+  if (!attr_set) {
+    HIPCHK(hipFuncSetAttribute((const void*)gemm_lcp_kernel<MODE, BM, BN, WM, WN, LW, S>,
+                               hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    attr_set = true;
+  }
+  if (!g_num_cus) {
+    int dev = 0;
+    HIPCHK(hipGetDevice(&dev));
+    HIPCHK(hipDeviceGetAttribute(&g_num_cus, hipDeviceAttributeMultiprocessorCount, dev));
+  }
+  SHAPECHK(p.ksplit <= 1, "gemm: the persistent kernel has no split-K path");
+  const int tiles = cdiv(p.M, BM) * cdiv(p.N, BN);
+  const int grid = tiles < g_num_cus ? tiles : g_num_cus;
+  hipLaunchKernelGGL((gemm_lcp_kernel<MODE, BM, BN, WM, WN, LW, S>), dim3(grid), dim3((WM * WN + LW) * 64), lds,
+                     stream, p);
+  return PEA_OK;
+}
+
 // ---- variant table (tile shape x wave grid x ring depth); the launcher picks one per problem shape
 int g_gemm_variant = -1;   // >= 0: forced (benchmark / debug)
 extern "C" void pea_debug_set_gemm_variant(int v) { g_gemm_variant = v; }
@@ -929,26 +1128,33 @@ static int launch_variant(const GemmP& p, hipStream_t stream) {
     case 24: rc = launch_lc<MODE, 256, 160, 4, 2, 4, 3, false, true>(p, stream); break; \
     case 25: rc = launch_lc<MODE, 128, 160, 4, 2, 4, 3, false, true>(p, stream); break; \
     case 26: rc = launch_lc<MODE, 128, 160, 4, 2, 4, 4, false, true>(p, stream); break; \
+    case 27: rc = launch_lcp<MODE, 256, 160, 4, 2, 4, 3>(p, stream); break; \
+    case 28: rc = launch_lcp<MODE, 128, 160, 4, 2, 4, 3>(p, stream); break; \
+    case 29: rc = launch_lcp<MODE, 128, 160, 2, 2, 4, 4>(p, stream); break; \
+    case 30: rc = launch_lcp<MODE, 128, 128, 2, 2, 4, 4>(p, stream); break; \
+    case 31: rc = launch_lcp<MODE, 64, 160, 2, 2, 4, 4>(p, stream); break; \
     default: rc = launch_variant<MODE, 128, 128, 2, 2, 2>(p, stream); break; \
   }
 
 static int pick_variant(const GemmP& p) {
   if (g_gemm_variant >= 0) return g_gemm_variant;
-  // measured on the step's shapes with scripts/gemm_bench.py (profiles/r01_gemm_variants.log); all loader/consumer
-  // kernels with 16x16x32 MFMAs unless noted:
-  //   25    = 128x160 tile, 4x2 consumer waves (32x80 each) + 4 DMA waves, 3 stages (two MFMA waves per SIMD)
-  //   22    = 128x160 tile, 2x2 consumer waves (64x80 each) + 4 DMA waves, 4 stages
-  //   24    = 256x160 tile, 4x2 consumer waves (64x80 each) + 4 DMA waves, 3 stages
-  //   23    = 128x128 tile, 2x2 consumer waves + 4 DMA waves, 4 stages
-  //   12    = software-pipelined 256x256, 8 waves, 32x32x16 MFMAs, 2 stages
+  // measured on the step's shapes with scripts/gemm_bench.py / gemm_ksweep.py (profiles/r01_gemm_variants.log); all
+  // loader/consumer kernels with 16x16x32 MFMAs:
+  //   24 / 27 = 256x160 tile, 4x2 consumer waves (64x80 each) + 4 DMA waves, 3 stages   (27: persistent)
+  //   25 / 28 = 128x160 tile, 4x2 consumer waves (32x80 each) + 4 DMA waves, 3 stages   (28: persistent)
+  //   29      = 128x160 tile, 2x2 consumer waves (64x80 each) + 4 DMA waves, 4 stages, persistent
+  //   31      =  64x160 tile, 2x2 consumer waves (32x80 each) + 4 DMA waves, 4 stages, persistent
+  // A launch of at most one tile per CU gains nothing from the persistent form; beyond that it hides every
+  // tile's prologue behind the previous tile's epilogue.
+  const int t128 = cdiv(p.M, 128) * cdiv(p.N, 160), t256 = cdiv(p.M, 256) * cdiv(p.N, 160);
   if (p.mode == 1) {
-    if (p.M >= 16384) return 24;                     // 128^2- and 64^2-level convs (N = 320 / 640)
-    return 22;                                       // 32^2-level convs (M = 4096, N = 1280)
+    if (t256 >= 256) return 27;                      // 128^2- and 64^2-level convs (N = 320 / 640)
+    return 29;                                       // 32^2-level convs (M = 4096, N = 1280)
   }
-  if (p.M < 1024) return 23;                         // embeddings, adapter, stacked K|V projection (tall-skinny)
-  if (p.N <= 1280) return p.M >= 8192 ? 24 : 25;     // 160-wide tiles fill the chip exactly
-  if (p.N >= 8192) return 24;
-  return p.M <= 4096 ? 25 : 24;
+  if (p.M < 1024 || t128 <= 160) return 31;          // embeddings, adapter, stacked K|V projection (tall-skinny)
+  if (t128 <= 256) return 25;                        // exactly one 128x160 tile per CU
+  if (t256 <= 256) return t256 > 192 ? 24 : 28;
+  return p.N >= 5120 ? 27 : 28;
 }
 
 int g_gemm_debug = 0;

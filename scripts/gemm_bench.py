@@ -14,7 +14,9 @@ NAMES = {0: "128x128 w2x2 S2", 1: "128x128 w2x2 S3", 2: "128x128 w2x2 S4", 3: "2
          5: "256x256 w2x4 S2", 6: "128x256 w2x4 S3", 7: "256x128 w2x2 S3", 8: "P128x160 w4x1 S4", 9: "P256x160 w4x1 S3",
          10: "P256x128 w4x2 S3", 11: "P128x128 w2x2 S3", 12: "P256x256 w2x4 S2", 13: "P128x160 w4x1 S3", 14: "LC128x160 c4+l4 S4", 15: "LC256x160 c4+l4 S3",
          16: "LC256x128 c8+l4 S3", 18: "LC128x128 c4+l4 S4", 19: "LC128x160 c4+l4 S3", 21: "LC16 128x160 2x2 S3",
-         22: "LC16 128x160 2x2 S4", 23: "LC16 128x128 2x2 S4", 24: "LC16 256x160 c8(4x2)+l4 S3", 25: "LC16 128x160 c8(4x2)+l4 S3", 26: "LC16 128x160 c8(4x2)+l4 S4"}
+         22: "LC16 128x160 2x2 S4", 23: "LC16 128x128 2x2 S4", 24: "LC16 256x160 c8(4x2)+l4 S3", 25: "LC16 128x160 c8(4x2)+l4 S3", 26: "LC16 128x160 c8(4x2)+l4 S4",
+         27: "persistent LC16 256x160 c8(4x2)+l4 S3", 28: "persistent LC16 128x160 c8(4x2)+l4 S3", 29: "persistent LC16 128x160 c4(2x2)+l4 S4",
+         30: "persistent LC16 128x128 c4(2x2)+l4 S4", 31: "persistent LC16 64x160 c4(2x2)+l4 S4"}
 
 def timeit(fn, iters=20):
     fn(); torch.cuda.synchronize()
