@@ -1,0 +1,18 @@
+#!/bin/bash
+# Round profile collection on the GPU box (run through gpurun from the repo root): bench line with CPU baseline and
+# per-family breakdown, rocprofv3 kernel stats of the same command, two PMC passes (FETCH_SIZE / WRITE_SIZE) and the
+# GEMM variant tables.  Everything lands in gpurun_out/; copy what should be judged into profiles/.
+R=${GRAFT_REPO_ROOT:-/root/repo}
+O=$R/gpurun_out
+mkdir -p $O
+cd /tmp && export TMPDIR=/tmp
+python3 $R/bench.py --breakdown > $O/bench_line.json 2> $O/bench_breakdown.txt
+rocprofv3 --kernel-trace --stats -d /tmp/prof_stats -o r --output-format csv -- python3 $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-roofline > $O/rocprofv3_bench_line.json 2> /dev/null
+find /tmp/prof_stats -name "*kernel_stats.csv" -exec cp {} $O/rocprofv3_kernel_stats.csv \;
+rocprofv3 --pmc FETCH_SIZE --kernel-trace -d /tmp/prof_fetch -o r --output-format csv -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline > /dev/null 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace -d /tmp/prof_write -o r --output-format csv -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline > /dev/null 2>&1
+python3 $R/scripts/pmc_traffic.py /tmp/prof_fetch /tmp/prof_write > $O/pmc_traffic.json 2> $O/pmc_err.txt
+python3 $R/scripts/gemm_bench.py 24,27,25,28,29,23,31 > $O/gemm_variants.log 2>&1
+python3 $R/scripts/gemm_ksweep.py 25,28,24,27,31 >> $O/gemm_variants.log 2>&1
+tail -1 $O/bench_line.json | cut -c1-300
+cat $O/pmc_traffic.json
