@@ -148,6 +148,7 @@ def main():
     ap.add_argument("--force-collective", action="store_true", help="init RCCL and all-reduce even with one rank (path test)")
     ap.add_argument("--dump-prof", default="", help="write every profiled launch (shape-tagged) to this CSV")
     ap.add_argument("--breakdown", action="store_true", help="print the per-kernel-family table to stderr")
+    ap.add_argument("--single-stream", action="store_true", help="analysis only: teacher and student passes on ONE stream")
     args = ap.parse_args()
     if args.cpu_baseline_worker:
         cpu_baseline_worker(args.model, args.cpu_budget)
@@ -208,6 +209,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if args.single_stream:
+        lib().pea_trainer_set_option(trainer._h, b"two_stream", 0)
     for _ in range(args.warmup):
         step()
     barrier()

@@ -98,7 +98,7 @@ int pea_op_groupnorm_bwd(const void* x, const void* dy, const float* gamma, cons
                          void* dx, void* scratch, int B, int HW, int C, int groups, int silu, int accum,
                          void* stream) {
   return launch_groupnorm_bwd((const bf16*)x, (const bf16*)dy, gamma, beta, stats, (bf16*)dx, (double*)scratch, B, HW,
-                              C, groups, silu, accum, (hipStream_t)stream);
+                              C, groups, silu, accum ? (const bf16*)dx : nullptr, (hipStream_t)stream);
 }
 int pea_op_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* stats, int R, int C,
                          float eps, void* stream) {
@@ -106,8 +106,8 @@ int pea_op_layernorm_fwd(const void* x, const float* gamma, const float* beta, v
 }
 int pea_op_layernorm_bwd(const void* x, const void* dy, const float* gamma, const float* stats, void* dx,
                          float* dgamma, float* dbeta, int R, int C, int accum, void* stream) {
-  return launch_layernorm_bwd((const bf16*)x, (const bf16*)dy, gamma, stats, (bf16*)dx, dgamma, dbeta, R, C, accum,
-                              (hipStream_t)stream);
+  return launch_layernorm_bwd((const bf16*)x, (const bf16*)dy, gamma, stats, (bf16*)dx, dgamma, dbeta, R, C,
+                              accum ? (const bf16*)dx : nullptr, (hipStream_t)stream);
 }
 
 int pea_op_attention_fwd(const void* Q, int ldq, const void* K, int ldk, const void* V, int ldv, void* O, int ldo,

@@ -612,8 +612,8 @@ static int launch_pipe(const GemmP& p, hipStream_t stream) {
 //   consumer t: sub-steps 0..2 of tile t, lgkmcnt(0) -> barrier_t -> prefetch (t+1, 0), sub-step 3 of tile t
 // After barrier_t every consumer has issued and retired all reads of tile t's LDS slot, so the ring runs S
 // tiles ahead (all S slots in flight).
-template <int MODE, int BM, int BN, int WM, int WN, int LW, int S, bool PROBE16 = false, bool M16 = false>
-__global__ __launch_bounds__((WM * WN + LW) * 64) void gemm_lc_kernel(const GemmP p) {
+template <int MODE, int BM, int BN, int WM, int WN, int LW, int S, bool PROBE16 = false, bool M16 = false, int MINW = 1>
+__global__ __launch_bounds__((WM * WN + LW) * 64, MINW) void gemm_lc_kernel(const GemmP p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int NWC = WM * WN;
   constexpr int STAGE = (BM + BN) * 128;
@@ -853,18 +853,18 @@ __global__ __launch_bounds__((WM * WN + LW) * 64) void gemm_lc_kernel(const Gemm
     gemm_epilogue<MI, NI>(p, acc, bm * BM + wr * (BM / WM), bn * BN + wc * (BN / WN), frow, fh);
 }
 
-template <int MODE, int BM, int BN, int WM, int WN, int LW, int S, bool PROBE16 = false, bool M16 = false>
+template <int MODE, int BM, int BN, int WM, int WN, int LW, int S, bool PROBE16 = false, bool M16 = false, int MINW = 1>
 static int launch_lc(const GemmP& p, hipStream_t stream) {
   constexpr int lds = S * (BM + BN) * 128;
   static_assert(lds <= 160 * 1024, "LDS budget");
   static bool attr_set = false;
   if (!attr_set) {
-    HIPCHK(hipFuncSetAttribute((const void*)gemm_lc_kernel<MODE, BM, BN, WM, WN, LW, S, PROBE16, M16>,
+    HIPCHK(hipFuncSetAttribute((const void*)gemm_lc_kernel<MODE, BM, BN, WM, WN, LW, S, PROBE16, M16, MINW>,
                                hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     attr_set = true;
   }
   const int grid = cdiv(p.M, BM) * cdiv(p.N, BN);
-  hipLaunchKernelGGL((gemm_lc_kernel<MODE, BM, BN, WM, WN, LW, S, PROBE16, M16>), dim3(grid, p.ksplit > 1 ? p.ksplit : 1),
+  hipLaunchKernelGGL((gemm_lc_kernel<MODE, BM, BN, WM, WN, LW, S, PROBE16, M16, MINW>), dim3(grid, p.ksplit > 1 ? p.ksplit : 1),
                      dim3((WM * WN + LW) * 64), lds, stream, p);
   return PEA_OK;
 }
@@ -1129,6 +1129,7 @@ static int launch_variant(const GemmP& p, hipStream_t stream) {
     case 25: rc = launch_lc<MODE, 128, 160, 4, 2, 4, 3, false, true>(p, stream); break; \
     case 26: rc = launch_lc<MODE, 128, 160, 4, 2, 4, 4, false, true>(p, stream); break; \
     case 27: rc = launch_lcp<MODE, 256, 160, 4, 2, 4, 3>(p, stream); break; \
+    case 32: rc = launch_lc<MODE, 128, 160, 4, 2, 2, 2, false, true, 5>(p, stream); break; /* two workgroups per CU */ \
     case 28: rc = launch_lcp<MODE, 128, 160, 4, 2, 4, 3>(p, stream); break; \
     case 29: rc = launch_lcp<MODE, 128, 160, 2, 2, 4, 4>(p, stream); break; \
     case 30: rc = launch_lcp<MODE, 128, 128, 2, 2, 4, 4>(p, stream); break; \

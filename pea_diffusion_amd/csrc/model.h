@@ -63,6 +63,7 @@ struct Tn {
   bf16* d = nullptr; bf16* g = nullptr;
   bool rg = false;           // requires grad
   bool gw = false;           // gradient already written in the current backward pass
+  const bf16* gpend = nullptr;   // gradient passed on by a residual, not yet added into g (Unet::backward)
   size_t off_d = 0, off_g = 0;
   bool external = false;     // no buffer of its own
 };

@@ -670,12 +670,36 @@ int Unet::forward(const float* x, const float* t, const void* ehs, int ehs_dtype
 
 // ============================================================================ backward
 void Unet::begin_backward() {
-  for (Tn& t : tn) t.gw = false;
+  for (Tn& t : tn) { t.gw = false; t.gpend = nullptr; }
 }
 
 int Unet::backward(const float* deps, hipStream_t s) {
   SHAPECHK(needs_grad, "unet: created without gradient support");
   HIPCHK(hipMemsetAsync(tproj_grad, 0, sizeof(float) * B * tproj_total, s));
+  // A residual connection hands its gradient on unchanged.  Instead of copying / adding it into the skip tensor's
+  // buffer at once, the skip tensor remembers it as a PENDING alias (Tn::gpend) and the next kernel that writes that
+  // tensor's gradient (LayerNorm / GroupNorm backward, dgrad GEMM) takes it as its addend: one launch and one
+  // read+write of the tensor less per residual.  Writers without an addend input materialise the alias first.
+  auto addend = [](Tn& t) -> const bf16* {       // addend for a kernel about to write t.g (consumes a pending alias)
+    if (t.gw) return t.g;
+    const bf16* p = t.gpend;
+    t.gpend = nullptr;
+    return p;
+  };
+  auto materialize = [&](Tn& t) -> int {         // for writers that can only accumulate in place
+    if (!t.gw && t.gpend) {
+      RC(launch_accum(t.gpend, t.g, t.rows * t.cols, 0, s));
+      t.gpend = nullptr;
+      t.gw = true;
+    }
+    return PEA_OK;
+  };
+  auto pass_on = [&](Tn& from, Tn& r) -> int {   // residual: r.g += from.g, deferred when r has no gradient yet
+    if (!r.gw && !r.gpend) { r.gpend = from.g; return PEA_OK; }
+    RC(materialize(r));
+    RC(launch_accum(from.g, r.g, r.rows * r.cols, 1, s));
+    return PEA_OK;
+  };
   for (int oi = (int)ops.size() - 1; oi >= 0; --oi) {
     Op& o = ops[oi];
     if (o.kind == OP_CONV_OUT) {
@@ -693,6 +717,7 @@ int Unet::backward(const float* deps, hipStream_t s) {
       RC(launch_cast_f32_bf16(tproj_grad, out.g, (long long)B * tproj_total, s));
       out.gw = true;
     }
+    RC(materialize(out));
     if (!out.gw) continue;                     // no consumer produced a gradient for this tensor
     switch (o.kind) {
       case OP_LINEAR: {
@@ -704,6 +729,7 @@ int Unet::backward(const float* deps, hipStream_t s) {
           p.W = f.wt; p.ldw = f.N; p.C = kv_part; p.ldc = a.cols; p.out_f32 = 1;
           p.ksplit = kv_nsplit; p.split_stride = (long long)out.rows * a.cols;
           RC(launch_gemm(p, s));
+          RC(materialize(a));
           RC(launch_splitk_reduce(kv_part, kv_nsplit, p.split_stride, a.g, a.cols, (int)a.rows, a.cols, a.gw, s));
           a.gw = true;
           break;
@@ -716,7 +742,7 @@ int Unet::backward(const float* deps, hipStream_t s) {
           p.A = geglu_tmp; p.lda = hg.cols; p.M = (int)out.rows; p.K = hg.cols; p.N = a.cols;
           p.W = w.wt; p.ldw = w.ldwt; p.C = a.g; p.ldc = a.cols;
           SHAPECHK(p.W != nullptr, "unet: dgrad weights missing for op %d", oi);
-          if (a.gw) { p.res = a.g; p.ldres = a.cols; }
+          if (const bf16* ad = addend(a)) { p.res = ad; p.ldres = a.cols; }
           RC(launch_gemm(p, s));
           a.gw = true;
           break;
@@ -728,24 +754,22 @@ int Unet::backward(const float* deps, hipStream_t s) {
           else { WSlot& w = slots[o.w]; p.W = w.wt; p.ldw = w.ldwt; }
           SHAPECHK(p.W != nullptr, "unet: dgrad weights missing for op %d", oi);
           p.C = a.g; p.ldc = a.cols;
-          if (a.gw) { p.res = a.g; p.ldres = a.cols; }
+          if (const bf16* ad = addend(a)) { p.res = ad; p.ldres = a.cols; }
           RC(launch_gemm(p, s));
           a.gw = true;
         }
-        if (o.res >= 0 && tn[o.res].rg) {
-          Tn& r = tn[o.res];
-          RC(launch_accum(out.g, r.g, r.rows * r.cols, r.gw, s));
-          r.gw = true;
-        }
+        if (o.res >= 0 && tn[o.res].rg) RC(pass_on(out, tn[o.res]));
         break;
       }
       case OP_SILU: {
         Tn& a = tn[o.a];
-        if (a.rg) { RC(launch_silu_bwd(a.d, out.g, a.g, a.rows * a.cols, a.gw, s)); a.gw = true; }
+        if (a.rg) { RC(materialize(a)); RC(launch_silu_bwd(a.d, out.g, a.g, a.rows * a.cols, a.gw, s)); a.gw = true; }
         break;
       }
       case OP_CONCAT: {
         Tn &a = tn[o.a], &b = tn[o.b];
+        if (a.rg) RC(materialize(a));
+        if (b.rg) RC(materialize(b));
         RC(launch_split2(out.g, a.cols, b.cols, a.rg ? a.g : nullptr, a.gw, b.rg ? b.g : nullptr, b.gw, a.rows, s));
         if (a.rg) a.gw = true;
         if (b.rg) b.gw = true;
@@ -762,29 +786,26 @@ int Unet::backward(const float* deps, hipStream_t s) {
           if (o.p1) {            // upsample-folded conv: gradient at the upsampled resolution, then 2x2 sum
             p.Ho = out.H; p.Wo = out.W; p.M = (int)out.rows; p.C = ups_tmp; p.ldc = a.cols;
             RC(launch_gemm(p, s));
+            RC(materialize(a));
             RC(launch_sumpool2(ups_tmp, a.g, a.B, a.H, a.W, a.cols, a.gw, s));
           } else {
             if (o.p0 == 2) { p.shift = 1; p.parity = 1; }
             p.Ho = a.H; p.Wo = a.W; p.M = (int)a.rows; p.C = a.g; p.ldc = a.cols;
-            if (a.gw) { p.res = a.g; p.ldres = a.cols; }
+            if (const bf16* ad = addend(a)) { p.res = ad; p.ldres = a.cols; }
             RC(launch_gemm(p, s));
           }
           a.gw = true;
         }
         if (o.rv >= 0 && tn[o.rv].rg)
           RC(launch_colsum_batched(out.g, tproj_grad + o.rv_off, out.B, out.H * out.W, out.cols, tproj_total, cs_scratch, s));
-        if (o.res >= 0 && tn[o.res].rg) {
-          Tn& r = tn[o.res];
-          RC(launch_accum(out.g, r.g, r.rows * r.cols, r.gw, s));
-          r.gw = true;
-        }
+        if (o.res >= 0 && tn[o.res].rg) RC(pass_on(out, tn[o.res]));
         break;
       }
       case OP_GN: {
         Tn& a = tn[o.a];
         if (a.rg) {
           RC(launch_groupnorm_bwd(a.d, out.g, slots[o.w].f32, slots[o.bias].f32, o.aux, a.g, gn_scratch, a.B,
-                                  a.H * a.W, a.cols, cfg.groups, o.p0, a.gw, s));
+                                  a.H * a.W, a.cols, cfg.groups, o.p0, addend(a), s));
           a.gw = true;
         }
         break;
@@ -792,8 +813,8 @@ int Unet::backward(const float* deps, hipStream_t s) {
       case OP_LN: {
         Tn& a = tn[o.a];
         if (a.rg) {
-          RC(launch_layernorm_bwd(a.d, out.g, slots[o.w].f32, o.aux, a.g, nullptr, nullptr, (int)a.rows, a.cols, a.gw,
-                                  s));
+          RC(launch_layernorm_bwd(a.d, out.g, slots[o.w].f32, o.aux, a.g, nullptr, nullptr, (int)a.rows, a.cols,
+                                  addend(a), s));
           a.gw = true;
         }
         break;
@@ -805,7 +826,7 @@ int Unet::backward(const float* deps, hipStream_t s) {
         p.O = out.d; p.ldo = out.cols; p.lse = o.aux; p.B = B; p.H = o.p0; p.Sq = o.p1; p.Skv = o.p2; p.scale = o.f0;
         p.nd = o.p3;
         p.dO = out.g; p.lddo = out.cols; p.delta = delta; p.dkv_part = attn_part;
-        SHAPECHK(!q.gw && (!k.gw || o.b == t_kvall), "unet: attention operand gradient written twice");
+        SHAPECHK(!q.gw && !q.gpend && !k.gpend && (!k.gw || o.b == t_kvall), "unet: attention operand gradient written twice");
         if (q.rg) { p.dQ = q.g + o.acol; p.lddq = q.cols; }
         if (k.rg) { p.dK = k.g + o.bcol; p.lddk = k.cols; p.dV = v.g + o.ccol; p.lddv = v.cols; }
         RC(launch_attention_bwd(p, s));
@@ -826,6 +847,8 @@ int Unet::backward(const float* deps, hipStream_t s) {
         break;
     }
   }
+  for (Tn& t : tn)
+    if (t.rg) RC(materialize(t));              // graph inputs that only ever received a passed-on gradient
   return PEA_OK;
 }
 

@@ -167,7 +167,7 @@ __global__ void gn_apply_kernel(const bf16* __restrict__ x, const float* __restr
 __global__ void gn_bwd_apply_kernel(const bf16* __restrict__ x, const bf16* __restrict__ dy,
                                     const float* __restrict__ gamma, const float* __restrict__ beta,
                                     const float* __restrict__ stats, const float* __restrict__ sums,
-                                    bf16* __restrict__ dx, int HW, int C, int groups, int silu, int accum,
+                                    bf16* dx, int HW, int C, int groups, int silu, const bf16* add,
                                     int pix_per_block) {
   const int nchunk = C / 8;
   const int ppb = blockDim.x / nchunk;
@@ -189,7 +189,7 @@ __global__ void gn_bwd_apply_kernel(const bf16* __restrict__ x, const bf16* __re
     const bf16x8 xv = *(const bf16x8*)(x + off);
     const bf16x8 dv = *(const bf16x8*)(dy + off);
     bf16x8 o;
-    if (accum) o = *(const bf16x8*)(dx + off);
+    if (add) o = *(const bf16x8*)(add + off);          // may be dx itself (in-place accumulate)
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const float xh = ((float)xv[j] - mean[j]) * rstd[j];
@@ -197,7 +197,7 @@ __global__ void gn_bwd_apply_kernel(const bf16* __restrict__ x, const bf16* __re
       if (silu) d *= silu_grad(xh * gm[j] + bt[j]);
       d *= gm[j];
       float r = rstd[j] * (d - S1[j] - xh * S2[j]);
-      if (accum) r += (float)o[j];
+      if (add) r += (float)o[j];
       o[j] = (bf16)r;
     }
     *(bf16x8*)(dx + off) = o;
@@ -247,7 +247,7 @@ int launch_groupnorm_fwd(const bf16* x, const float* gamma, const float* beta, b
 }
 
 int launch_groupnorm_bwd(const bf16* x, const bf16* dy, const float* gamma, const float* beta, const float* stats,
-                         bf16* dx, double* scratch, int B, int HW, int C, int groups, int silu, int accum,
+                         bf16* dx, double* scratch, int B, int HW, int C, int groups, int silu, const bf16* add,
                          hipStream_t s) {
   SHAPECHK(C % 8 == 0 && C % groups == 0 && groups <= GN_MAX_GROUPS, "groupnorm: C=%d groups=%d", C, groups);
   int threads, ppblk, nblk;
@@ -262,7 +262,7 @@ int launch_groupnorm_bwd(const bf16* x, const bf16* dy, const float* gamma, cons
   hipLaunchKernelGGL(gn_finalize_kernel, dim3(B * groups), dim3(64), 0, s, partial, sums, B * groups, groups, nblk,
                      (double)HW * (C / groups), 0.f, 1);
   hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(nblk, B), dim3(threads), 0, s, x, dy, gamma, beta, stats, sums, dx, HW,
-                     C, groups, silu, accum, ppblk);
+                     C, groups, silu, add, ppblk);
   PROF_END(s);
   HIPCHK(hipGetLastError());
   return PEA_OK;
@@ -325,9 +325,9 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const bf16* __restrict__ x,
 template <int NCH>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16* __restrict__ x, const bf16* __restrict__ dy,
                                                      const float* __restrict__ gamma,
-                                                     const float* __restrict__ stats, bf16* __restrict__ dx,
+                                                     const float* __restrict__ stats, bf16* dx,
                                                      float* __restrict__ dgamma, float* __restrict__ dbeta, int R,
-                                                     int C, int accum) {
+                                                     int C, const bf16* add) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= R) return;
@@ -357,13 +357,13 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16* __restrict__ x,
     const int ck = lane + 64 * i;
     if (ck < nchunk) {
       bf16x8 o;
-      if (accum) o = *(const bf16x8*)(dx + (long long)row * C + ck * 8);
+      if (add) o = *(const bf16x8*)(add + (long long)row * C + ck * 8);   // may be dx itself (in-place accumulate)
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const float xh = ((float)xv[i][j] - mean) * rstd;
         const float dyv = (float)dv[i][j];
         float r = rstd * (dyv * gamma[ck * 8 + j] - s1 - xh * s2);
-        if (accum) r += (float)o[j];
+        if (add) r += (float)o[j];
         o[j] = (bf16)r;
       }
       *(bf16x8*)(dx + (long long)row * C + ck * 8) = o;
@@ -402,11 +402,11 @@ __global__ void ln_param_grad_kernel(const bf16* __restrict__ x, const bf16* __r
 }
 
 int launch_layernorm_bwd(const bf16* x, const bf16* dy, const float* gamma, const float* stats, bf16* dx,
-                         float* dgamma, float* dbeta, int R, int C, int accum, hipStream_t s) {
+                         float* dgamma, float* dbeta, int R, int C, const bf16* add, hipStream_t s) {
   SHAPECHK(C % 8 == 0 && C <= 64 * 8 * LN_MAXCH, "layernorm: C=%d unsupported", C);
   PROF_BEGIN(5, 0.0, 6.0 * R * (double)C, s);
   const int nch = cdiv(C / 8, 64);
-#define LN_BWD(N) hipLaunchKernelGGL(ln_bwd_kernel<N>, dim3(cdiv(R, 4)), dim3(256), 0, s, x, dy, gamma, stats, dx, dgamma, dbeta, R, C, accum)
+#define LN_BWD(N) hipLaunchKernelGGL(ln_bwd_kernel<N>, dim3(cdiv(R, 4)), dim3(256), 0, s, x, dy, gamma, stats, dx, dgamma, dbeta, R, C, add)
   if (dx) { if (nch <= 1) LN_BWD(1); else if (nch == 2) LN_BWD(2); else if (nch == 3) LN_BWD(3); else if (nch == 4) LN_BWD(4); else LN_BWD(8); }
 #undef LN_BWD
   if (dgamma) hipLaunchKernelGGL(ln_param_grad_kernel, dim3(cdiv(C, 64)), dim3(64), 0, s, x, dy, stats, dgamma, dbeta, R, C);

@@ -54,13 +54,13 @@ int launch_groupnorm_fwd(const bf16* x, const float* gamma, const float* beta, b
                          double* scratch, int B, int HW, int C, int groups, float eps, int silu, hipStream_t s);
 // dx (+= if accum) for y = [silu](GN(x)); gamma/beta frozen
 int launch_groupnorm_bwd(const bf16* x, const bf16* dy, const float* gamma, const float* beta, const float* stats,
-                         bf16* dx, double* scratch, int B, int HW, int C, int groups, int silu, int accum,
-                         hipStream_t s);
+                         bf16* dx, double* scratch, int B, int HW, int C, int groups, int silu, const bf16* add,
+                         hipStream_t s);   // add: optional addend (may be dx itself)
 // LayerNorm over rows [R][C] (C % 8 == 0, C <= 4096); stats fp32 [R][2] = (mean, rstd)
 int launch_layernorm_fwd(const bf16* x, const float* gamma, const float* beta, bf16* y, float* stats, int R, int C,
                          float eps, hipStream_t s);
 int launch_layernorm_bwd(const bf16* x, const bf16* dy, const float* gamma, const float* stats, bf16* dx,
-                         float* dgamma, float* dbeta, int R, int C, int accum, hipStream_t s);
+                         float* dgamma, float* dbeta, int R, int C, const bf16* add, hipStream_t s);   // add: optional addend (may be dx)
 
 // ---------------------------------------------------------------- attention.hip
 // O[b][q][h*D+d] = softmax(scale * Q K^T) V per (b, head); D = 64*nd (nd = 1, 2, 3); heads whose true width is
