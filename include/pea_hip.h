@@ -105,6 +105,17 @@ int pea_op_add_noise(const float* x0, const float* eps, const long long* t, cons
 int pea_op_cast_f32_bf16(const float* x, void* y, long long n, void* stream);
 int pea_op_cast_bf16_f32(const void* x, float* y, long long n, void* stream);
 
+/* Inference denoise loop glue (tests/test_sdxl_zh.py:376-406).
+ * cfg_combine: eps2 = fp32 [2B][per] (unconditional half first, :394); out[B][per] = u + g*(t-u) (:395), then when
+ *   guidance_rescale > 0 `rescale_noise_cfg` (:44-56, unbiased per-sample std); workspace from *_workspace_bytes(B).
+ * dpm_update: one DPMSolverMultistepScheduler.step (:406; diffusers 0.23 [ext], dpmsolver++ midpoint) with host-side
+ *   coefficients: x0 = (sample - sigma_s*eps)/alpha_s; sample <- c_s*sample + c_0*x0 + c_1*x0_prev; x0_prev <- x0. */
+long long pea_op_cfg_combine_workspace_bytes(int B);
+int pea_op_cfg_combine(const float* eps2, float* out, int B, long long per, float guidance_scale, float guidance_rescale,
+                       void* workspace, void* stream);
+int pea_op_dpm_update(float* sample, const float* eps, float* x0_prev, long long n, float alpha_s, float sigma_s,
+                      float c_s, float c_0, float c_1, void* stream);
+
 /* Fused KD loss of train_sdxl_zh.py:399-441 (SD1.5: train_sd_zh.py:217-276, nan_guard=1).
  * taps_s/taps_t/dtaps: HOST arrays of ntaps device pointers (bf16, elementwise-paired layouts);
  * per: HOST array of per-sample element counts.  eps_*: fp32 [B][per_eps].  zh: int64 [B] device.
@@ -153,8 +164,19 @@ typedef struct pea_unet_config {
  * (train_sdxl_zh.py:138,151).  needs_grad=1 adds the reverse data-gradient tape (student);
  * own_weights=0 creates a context that must borrow weights via pea_unet_share_weights (the
  * reference loads teacher and student from the same checkpoint, train_sdxl_zh.py:138 vs :151).    */
-int pea_unet_create(const pea_unet_config* cfg, int B, int H, int W, int L, int needs_grad, int own_weights,
+/* flags: PEA_UNET_GRAD (backward support) | PEA_UNET_RESIDUAL_INPUTS (ControlNet residual inputs, inference only) */
+#define PEA_UNET_GRAD 1
+#define PEA_UNET_RESIDUAL_INPUTS 2
+int pea_unet_create(const pea_unet_config* cfg, int B, int H, int W, int L, int flags, int own_weights,
                     void** out);
+/* ControlNet extras of the UNet call (tests/test_sdxl_zh_controlnet.py:534-535): `down_block_additional_residuals`
+ * (conv_in output, then every down-block resnet/attention output and downsampler output, in diffusers order) followed
+ * by `mid_block_additional_residual` LAST.  ptrs: HOST array of n device pointers ([B,C,H,W]; NULL entry = zero);
+ * dtype 0 fp32 NCHW, 1 bf16 NCHW, 2 bf16 NHWC; values are multiplied by `scale` (conditioning_scale) on import and
+ * stay in effect for every following pea_unet_forward until set again. */
+int pea_unet_num_residuals(void* unet);
+int pea_unet_residual_info(void* unet, int i, int* C, int* H, int* W);
+int pea_unet_set_residuals(void* unet, int n, const void* const* ptrs, int dtype, float scale, void* stream);
 int pea_unet_destroy(void* unet);
 int pea_unet_num_weights(void* unet);
 /* diffusers state-dict key + torch shape (d0,d1; conv adds [3][3]) of weight i; kind: 0 vector,

@@ -380,7 +380,11 @@ class UNet2DConditionRef(nn.Module):
         return emb
 
     def forward(self, sample, timesteps, encoder_hidden_states, added_cond_kwargs=None,
-                cross_attention_kwargs=None, return_dict=False):
+                cross_attention_kwargs=None, return_dict=False, down_block_additional_residuals=None,
+                mid_block_additional_residual=None):
+        """ControlNet extras (tests/test_sdxl_zh_controlnet.py:534-535), diffusers 0.23 semantics [ext]: each
+        down-path skip tensor gets its residual added AFTER the down path ran (only the copies consumed by the
+        up blocks change), the mid residual is added to the mid-block output."""
         B = sample.shape[0]
         emb = self.embed(timesteps, added_cond_kwargs, B)
         x = self.conv_in(sample)
@@ -388,7 +392,12 @@ class UNet2DConditionRef(nn.Module):
         for blk in self.down_blocks:
             x, outs = blk(x, emb, encoder_hidden_states)
             res += outs
+        if down_block_additional_residuals is not None:
+            assert len(down_block_additional_residuals) == len(res)
+            res = tuple(r + a for r, a in zip(res, down_block_additional_residuals))
         x = self.mid_block(x, emb, encoder_hidden_states)
+        if mid_block_additional_residual is not None:
+            x = x + mid_block_additional_residual
         for blk in self.up_blocks:
             n = len(blk.resnets)
             take, res = res[-n:], res[:-n]

@@ -44,6 +44,7 @@ def parse_header(path: str = HEADER) -> Dict[str, Tuple[object, List[object]]]:
     src = open(path).read()
     src = re.sub(r"/\*.*?\*/", " ", src, flags=re.S)
     src = re.sub(r"//[^\n]*", " ", src)
+    src = re.sub(r"^[ \t]*#[^\n]*", " ", src, flags=re.M)            # preprocessor lines (#define flags, guards)
     src = re.sub(r"typedef\s+struct[^{]*\{.*?\}\s*\w+\s*;", " ", src, flags=re.S)
     protos = {}
     for m in re.finditer(r"([A-Za-z_][\w\s\*]*?)\b(pea_\w+)\s*\(([^;{]*?)\)\s*;", src):

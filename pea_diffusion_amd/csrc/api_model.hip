@@ -21,7 +21,7 @@ static_assert(sizeof(pea_unet_config) == sizeof(PeaUnetCfg), "config struct mism
 
 extern "C" {
 
-int pea_unet_create(const pea_unet_config* cfg, int B, int H, int W, int L, int needs_grad, int own_weights,
+int pea_unet_create(const pea_unet_config* cfg, int B, int H, int W, int L, int flags, int own_weights,
                     void** out) {
   NOTNULL(cfg, "pea_unet_create");
   NOTNULL(out, "pea_unet_create");
@@ -32,7 +32,8 @@ int pea_unet_create(const pea_unet_config* cfg, int B, int H, int W, int L, int 
   }
   Unet* u = new Unet();
   memcpy(&u->cfg, cfg, sizeof(PeaUnetCfg));
-  u->B = B; u->H = H; u->W = W; u->L = L; u->needs_grad = needs_grad != 0; u->owns_weights = own_weights != 0;
+  u->B = B; u->H = H; u->W = W; u->L = L; u->needs_grad = (flags & 1) != 0; u->residual_inputs = (flags & 2) != 0;
+  u->owns_weights = own_weights != 0;
   int rc = u->build();
   if (rc == PEA_OK) rc = u->alloc();
   if (rc != PEA_OK) {
@@ -44,6 +45,43 @@ int pea_unet_create(const pea_unet_config* cfg, int B, int H, int W, int L, int 
 }
 int pea_unet_destroy(void* h) {
   delete (Unet*)h;
+  return PEA_OK;
+}
+int pea_unet_num_residuals(void* h) { return h ? (int)((Unet*)h)->ext_res.size() : 0; }
+int pea_unet_residual_info(void* h, int i, int* C, int* H, int* W) {
+  NOTNULL(h, "pea_unet_residual_info");
+  Unet* u = (Unet*)h;
+  if (i < 0 || i >= (int)u->ext_res.size()) {
+    pea_set_error("pea_unet_residual_info: index %d out of range (%d residual inputs)", i, (int)u->ext_res.size());
+    return PEA_E_INVALID;
+  }
+  const Tn& t = u->tn[u->ext_res[i]];
+  if (C) *C = t.cols;
+  if (H) *H = t.H;
+  if (W) *W = t.W;
+  return PEA_OK;
+}
+int pea_unet_set_residuals(void* h, int n, const void* const* ptrs, int dtype, float scale, void* stream) {
+  NOTNULL(h, "pea_unet_set_residuals");
+  Unet* u = (Unet*)h;
+  if (!u->residual_inputs) {
+    pea_set_error("pea_unet_set_residuals: context created without PEA_UNET_RESIDUAL_INPUTS");
+    return PEA_E_STATE;
+  }
+  if (n != (int)u->ext_res.size() || !ptrs) {
+    pea_set_error("pea_unet_set_residuals: %d pointers given, the graph has %d residual inputs (mid last)", n,
+                  (int)u->ext_res.size());
+    return PEA_E_SHAPE;
+  }
+  for (int i = 0; i < n; ++i) {
+    Tn& t = u->tn[u->ext_res[i]];
+    if (!ptrs[i]) {
+      HIPCHK(hipMemsetAsync(t.d, 0, (size_t)t.rows * t.cols * 2, (hipStream_t)stream));
+      continue;
+    }
+    int rc = launch_residual_import(ptrs[i], dtype, t.d, u->B, t.cols, (long long)t.H * t.W, scale, (hipStream_t)stream);
+    if (rc != PEA_OK) return rc;
+  }
   return PEA_OK;
 }
 int pea_unet_num_weights(void* h) { return h ? (int)((Unet*)h)->slots.size() : 0; }

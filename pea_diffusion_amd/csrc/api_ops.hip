@@ -197,4 +197,17 @@ int pea_op_adamw(float* w, const float* g, float* m, float* v, long long n, floa
   return launch_adamw(w, g, m, v, n, lr, beta1, beta2, eps, weight_decay, step, grad_scale, (hipStream_t)stream);
 }
 
+// ---- inference denoise-loop glue (sampler.hip)
+long long pea_op_cfg_combine_workspace_bytes(int B) { return (long long)cfg_combine_workspace_bytes(B); }
+int pea_op_cfg_combine(const float* eps2, float* out, int B, long long per, float guidance_scale, float guidance_rescale,
+                       void* workspace, void* stream) {
+  if (!eps2 || !out) { pea_set_error("pea_op_cfg_combine: null pointer"); return PEA_E_INVALID; }
+  return launch_cfg_combine(eps2, out, B, per, guidance_scale, guidance_rescale, workspace, (hipStream_t)stream);
+}
+int pea_op_dpm_update(float* sample, const float* eps, float* x0_prev, long long n, float alpha_s, float sigma_s,
+                      float c_s, float c_0, float c_1, void* stream) {
+  if (!sample || !eps || !x0_prev) { pea_set_error("pea_op_dpm_update: null pointer"); return PEA_E_INVALID; }
+  return launch_dpm_update(sample, eps, x0_prev, n, alpha_s, sigma_s, c_s, c_0, c_1, (hipStream_t)stream);
+}
+
 }  // extern "C"

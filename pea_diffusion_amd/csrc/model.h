@@ -69,7 +69,7 @@ struct Tn {
 };
 
 enum OpKind { OP_CONV_IN, OP_CONV3, OP_LINEAR, OP_GN, OP_LN, OP_ATTN, OP_GEGLU, OP_CONCAT, OP_SILU, OP_TEMB,
-              OP_CONV_OUT };
+              OP_CONV_OUT, OP_ADD };
 
 struct Op {
   int kind;
@@ -90,6 +90,8 @@ struct Unet {
   PeaUnetCfg cfg;
   int B, H, W, L;                 // batch, latent H/W, context length
   bool needs_grad;
+  bool residual_inputs = false;      // ControlNet: down_block_additional_residuals / mid_block_additional_residual
+  std::vector<int> ext_res;          // their tensors, diffusers order (conv_in, down blocks..., then mid last)
   std::deque<WSlot> slots;
   std::map<std::string, int> slot_by_name;
   std::deque<FusedMat> fused;

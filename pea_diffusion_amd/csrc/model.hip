@@ -325,10 +325,26 @@ int Unet::build() {
     }
     taps.push_back(x);
   }
+  auto add_external = [&](int t) {              // t + (externally supplied residual, zero until set)
+    const Tn& a = tn[t];
+    const int e = bd.T(a.rows, a.cols, a.B, a.H, a.W);
+    const int y = bd.T(a.rows, a.cols, a.B, a.H, a.W);
+    ext_res.push_back(e);
+    Op& o = bd.push(OP_ADD);
+    o.a = t; o.b = e; o.out = y;
+    return y;
+  };
+  if (residual_inputs) {
+    // diffusers 0.23 [ext]: the ControlNet residuals are added to the skip tensors after the down path ran, i.e.
+    // only the copies the up blocks consume change (tests/test_sdxl_zh_controlnet.py:534)
+    SHAPECHK(!needs_grad, "unet: residual inputs are an inference feature (no backward through them)");
+    for (int& sk : skips) sk = add_external(sk);
+  }
   x = bd.resnet(x, "mid_block.resnets.0", c.block_out[n - 1]);
   x = bd.transformer(x, "mid_block.attentions.0", c.heads[n - 1], c.depth[n - 1]);
   x = bd.resnet(x, "mid_block.resnets.1", c.block_out[n - 1]);
   taps.push_back(x);
+  if (residual_inputs) x = add_external(x);     // mid_block_additional_residual (:535)
   for (int i = 0; i < n; ++i) {
     const std::string p = "up_blocks." + std::to_string(i);
     const int lvl = n - 1 - i;
@@ -433,6 +449,7 @@ int Unet::alloc() {
   }
   for (Op& o : ops)
     if (o.aux_bytes) o.aux = (float*)(aarena + o.aux_off);
+  for (int e : ext_res) HIPCHK(hipMemset(tn[e].d, 0, (size_t)tn[e].rows * tn[e].cols * 2));   // "no residual" = zeros
   // ---- scratch
   size_t delta_elems = 0, ups_elems = 0, part_bytes = 0, geglu_elems = 0;
   for (Op& o : ops) {
@@ -614,6 +631,9 @@ int Unet::forward(const float* x, const float* t, const void* ehs, int ehs_dtype
         RC(launch_gemm(p, s));
         break;
       }
+      case OP_ADD:
+        RC(launch_add(tn[o.a].d, tn[o.b].d, tn[o.out].d, tn[o.out].rows * tn[o.out].cols, s));
+        break;
       case OP_SILU:
         RC(launch_silu_fwd(tn[o.a].d, tn[o.out].d, tn[o.a].rows * tn[o.a].cols, s));
         break;

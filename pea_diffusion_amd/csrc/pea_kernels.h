@@ -177,3 +177,9 @@ int launch_pad_gather(const float* src, int N_t, int K_t, int mode, int d, int d
 int launch_geglu_bwd_il(const bf16* hg, const bf16* dy, bf16* dhg, long long rows, int inner, hipStream_t s);
 int launch_geglu_fwd_il(const bf16* hg, bf16* y, long long rows, int inner, hipStream_t s);
 int launch_permute_geglu_vec(const float* src, float* dst, int inner, hipStream_t s);
+// sampler.hip: inference denoise-loop glue
+size_t cfg_combine_workspace_bytes(int B);
+int launch_cfg_combine(const float* eps2, float* out, int B, long long per, float g, float rescale, void* ws, hipStream_t s);
+int launch_dpm_update(float* sample, const float* eps, float* x0_prev, long long n, float alpha_s, float sigma_s,
+                      float c_s, float c_0, float c_1, hipStream_t s);
+int launch_residual_import(const void* src, int dtype, bf16* dst, int B, int C, long long HW, float scale, hipStream_t s);

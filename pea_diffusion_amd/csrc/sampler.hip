@@ -1,0 +1,126 @@
+// Inference denoise-loop glue of tests/test_sdxl_zh.py:376-406: classifier-free-guidance combine (+ the std rescale of
+// rescale_noise_cfg, :44-56) and the DPM-Solver++ (2M) latent update.  fp32 NCHW latents; HBM-bound elementwise and
+// fixed-order reductions (bit-reproducible).  The schedule's scalar coefficients are computed on the host.
+#include "pea_kernels.h"
+
+#define SM_LOOP(i, n) for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < (n); i += (long long)gridDim.x * blockDim.x)
+static inline int sm_grid(long long n) { long long g = (n + 255) / 256; return (int)(g > 2048 ? 2048 : (g < 1 ? 1 : g)); }
+
+// eps2 = [uncond (B samples) | text (B samples)]; out = u + g * (t - u)
+__global__ void cfg_combine_kernel(const float* __restrict__ eps2, float* __restrict__ out, long long n, float g) {
+  SM_LOOP(i, n) {
+    const float u = eps2[i], t = eps2[n + i];
+    out[i] = u + g * (t - u);
+  }
+}
+
+#define CFG_NBLK 64
+// per (sample, block): sums of t, t^2, c, c^2 in double, fixed order inside the block
+__global__ __launch_bounds__(256) void cfg_stats_kernel(const float* __restrict__ eps2, long long n, long long per,
+                                                        float g, double* __restrict__ part) {
+  const int b = blockIdx.y;
+  const float* u = eps2 + (long long)b * per;
+  const float* t = eps2 + n + (long long)b * per;
+  double s[4] = {0, 0, 0, 0};
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < per; i += (long long)CFG_NBLK * 256) {
+    const float uv = u[i], tv = t[i];
+    const float c = uv + g * (tv - uv);
+    s[0] += tv; s[1] += (double)tv * tv; s[2] += c; s[3] += (double)c * c;
+  }
+  __shared__ double red[4][256];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) red[k][threadIdx.x] = s[k];
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) red[k][threadIdx.x] += red[k][threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x < 4) part[((long long)b * CFG_NBLK + blockIdx.x) * 4 + threadIdx.x] = red[threadIdx.x][0];
+}
+// factor[b] = phi * std_text / std_cfg + (1 - phi)   (torch.std: unbiased)
+__global__ void cfg_factor_kernel(const double* __restrict__ part, float* __restrict__ factor, int B, long long per,
+                                  float phi) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  double s[4] = {0, 0, 0, 0};
+  for (int k = 0; k < CFG_NBLK; ++k)
+    for (int j = 0; j < 4; ++j) s[j] += part[((long long)b * CFG_NBLK + k) * 4 + j];
+  const double nn = (double)per;
+  const double vt = (s[1] - s[0] * s[0] / nn) / (nn - 1.0), vc = (s[3] - s[2] * s[2] / nn) / (nn - 1.0);
+  factor[b] = (float)((double)phi * sqrt(vt / vc) + (1.0 - (double)phi));
+}
+__global__ void cfg_apply_kernel(const float* __restrict__ eps2, float* __restrict__ out, long long n, long long per,
+                                 float g, const float* __restrict__ factor) {
+  SM_LOOP(i, n) {
+    const float u = eps2[i], t = eps2[n + i];
+    out[i] = (u + g * (t - u)) * factor[i / per];
+  }
+}
+
+size_t cfg_combine_workspace_bytes(int B) { return (size_t)B * CFG_NBLK * 4 * sizeof(double) + (size_t)B * sizeof(float); }
+
+int launch_cfg_combine(const float* eps2, float* out, int B, long long per, float g, float rescale, void* ws,
+                       hipStream_t s) {
+  SHAPECHK(B > 0 && per > 1, "cfg_combine: B=%d per=%lld", B, per);
+  const long long n = (long long)B * per;
+  if (rescale <= 0.f) {
+    hipLaunchKernelGGL(cfg_combine_kernel, dim3(sm_grid(n)), dim3(256), 0, s, eps2, out, n, g);
+  } else {
+    SHAPECHK(ws != nullptr, "cfg_combine: guidance_rescale needs the workspace");
+    double* part = (double*)ws;
+    float* factor = (float*)(part + (size_t)B * CFG_NBLK * 4);
+    hipLaunchKernelGGL(cfg_stats_kernel, dim3(CFG_NBLK, B), dim3(256), 0, s, eps2, n, per, g, part);
+    hipLaunchKernelGGL(cfg_factor_kernel, dim3(cdiv(B, 64)), dim3(64), 0, s, part, factor, B, per, rescale);
+    hipLaunchKernelGGL(cfg_apply_kernel, dim3(sm_grid(n)), dim3(256), 0, s, eps2, out, n, per, g, factor);
+  }
+  HIPCHK(hipGetLastError());
+  return PEA_OK;
+}
+
+// x0 = (sample - sigma_s * eps) / alpha_s;  sample <- c_s * sample + c_0 * x0 + c_1 * x0_prev;  x0_prev <- x0
+__global__ void dpm_update_kernel(float* __restrict__ sample, const float* __restrict__ eps, float* __restrict__ x0_prev,
+                                  long long n, float inv_alpha, float sigma, float cs, float c0, float c1) {
+  SM_LOOP(i, n) {
+    const float x = sample[i];
+    const float x0 = (x - sigma * eps[i]) * inv_alpha;
+    float y = cs * x + c0 * x0;
+    if (c1 != 0.f) y += c1 * x0_prev[i];
+    sample[i] = y;
+    x0_prev[i] = x0;
+  }
+}
+int launch_dpm_update(float* sample, const float* eps, float* x0_prev, long long n, float alpha_s, float sigma_s,
+                      float c_s, float c_0, float c_1, hipStream_t s) {
+  SHAPECHK(n > 0 && alpha_s > 0.f, "dpm_update: n=%lld alpha=%g", n, alpha_s);
+  hipLaunchKernelGGL(dpm_update_kernel, dim3(sm_grid(n)), dim3(256), 0, s, sample, eps, x0_prev, n, 1.0f / alpha_s,
+                     sigma_s, c_s, c_0, c_1);
+  HIPCHK(hipGetLastError());
+  return PEA_OK;
+}
+
+// ControlNet residual hand-over: [B][C][HW] (fp32 or bf16) -> [B][HW][C] bf16, scaled
+template <typename T>
+__global__ void nchw_to_nhwc_scaled_kernel(const T* __restrict__ x, bf16* __restrict__ y, int C, long long HW,
+                                           long long n, float scale) {
+  SM_LOOP(i, n) {
+    const int c = (int)(i % C);
+    const long long r = i / C;
+    const long long p = r % HW, b = r / HW;
+    y[i] = (bf16)((float)x[(b * C + c) * HW + p] * scale);
+  }
+}
+__global__ void scale_copy_bf16_kernel(const bf16* __restrict__ x, bf16* __restrict__ y, long long n, float scale) {
+  SM_LOOP(i, n) y[i] = (bf16)((float)x[i] * scale);
+}
+int launch_residual_import(const void* src, int dtype, bf16* dst, int B, int C, long long HW, float scale,
+                           hipStream_t s) {
+  const long long n = (long long)B * C * HW;
+  if (dtype == 0) hipLaunchKernelGGL(nchw_to_nhwc_scaled_kernel<float>, dim3(sm_grid(n)), dim3(256), 0, s, (const float*)src, dst, C, HW, n, scale);
+  else if (dtype == 1) hipLaunchKernelGGL(nchw_to_nhwc_scaled_kernel<bf16>, dim3(sm_grid(n)), dim3(256), 0, s, (const bf16*)src, dst, C, HW, n, scale);
+  else if (dtype == 2) hipLaunchKernelGGL(scale_copy_bf16_kernel, dim3(sm_grid(n)), dim3(256), 0, s, (const bf16*)src, dst, n, scale);
+  else SHAPECHK(false, "residual import: dtype %d (0 fp32 NCHW, 1 bf16 NCHW, 2 bf16 NHWC)", dtype);
+  HIPCHK(hipGetLastError());
+  return PEA_OK;
+}

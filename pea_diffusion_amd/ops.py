@@ -206,3 +206,28 @@ def kd_loss(taps_s: Sequence[torch.Tensor], taps_t: Sequence[torch.Tensor], eps_
 def adamw_(w, g, m, v, lr, step, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0, grad_scale=1.0):
     check(lib().pea_op_adamw(ptr(w), ptr(g), ptr(m), ptr(v), w.numel(), lr, beta1, beta2, eps, weight_decay, step,
                              grad_scale, stream_ptr()))
+
+
+# ---- inference denoise-loop glue (tests/test_sdxl_zh.py:376-406)
+def cfg_combine(noise_pred2, guidance_scale, guidance_rescale=0.0):
+    """`u, t = noise_pred.chunk(2); u + g * (t - u)` (:394-395) and, for guidance_rescale > 0, `rescale_noise_cfg`
+    (:44-56).  noise_pred2: fp32 [2B, ...] on the GPU, unconditional half first."""
+    assert noise_pred2.dtype == torch.float32 and noise_pred2.shape[0] % 2 == 0
+    B = noise_pred2.shape[0] // 2
+    x = noise_pred2.contiguous()
+    out = torch.empty((B,) + tuple(x.shape[1:]), device=x.device, dtype=torch.float32)
+    ws = None
+    if guidance_rescale > 0.0:
+        ws = torch.empty(lib().pea_op_cfg_combine_workspace_bytes(B), device=x.device, dtype=torch.uint8)
+    check(lib().pea_op_cfg_combine(ptr(x), ptr(out), B, out[0].numel(), float(guidance_scale), float(guidance_rescale),
+                                   ptr(ws), stream_ptr()))
+    return out
+
+
+def dpm_update_(sample, eps, x0_prev, alpha_s, sigma_s, c_s, c_0, c_1):
+    """In place: x0 = (sample - sigma_s*eps)/alpha_s; sample <- c_s*sample + c_0*x0 + c_1*x0_prev; x0_prev <- x0."""
+    for t in (sample, eps, x0_prev):
+        assert t.dtype == torch.float32 and t.is_contiguous()
+    check(lib().pea_op_dpm_update(ptr(sample), ptr(eps), ptr(x0_prev), sample.numel(), float(alpha_s), float(sigma_s),
+                                  float(c_s), float(c_0), float(c_1), stream_ptr()))
+    return sample

@@ -43,7 +43,8 @@ class _Config:
 
 class HipUNet:
     def __init__(self, cfg, batch: int, height: Optional[int] = None, width: Optional[int] = None, ctx_len: int = 77,
-                 needs_grad: bool = False, share_weights_from: Optional["HipUNet"] = None):
+                 needs_grad: bool = False, share_weights_from: Optional["HipUNet"] = None,
+                 residual_inputs: bool = False):
         if not torch.cuda.is_available():
             raise PeaError("HipUNet needs a MI355X (no CPU fallback)")
         self.cfg = cfg
@@ -55,7 +56,9 @@ class HipUNet:
         self.device = torch.device("cuda", torch.cuda.current_device())
         self._h = ctypes.c_void_p()
         c = _cfg.to_c(cfg)
-        check(lib().pea_unet_create(ctypes.byref(c), self.B, self.H, self.W, self.L, int(needs_grad),
+        self.residual_inputs = residual_inputs
+        flags = (1 if needs_grad else 0) | (2 if residual_inputs else 0)   # PEA_UNET_GRAD | PEA_UNET_RESIDUAL_INPUTS
+        check(lib().pea_unet_create(ctypes.byref(c), self.B, self.H, self.W, self.L, flags,
                                     int(share_weights_from is None), ctypes.byref(self._h)))
         if share_weights_from is not None:
             check(lib().pea_unet_share_weights(self._h, share_weights_from._h))
@@ -125,7 +128,9 @@ class HipUNet:
     def __call__(self, sample, timestep, encoder_hidden_states, added_cond_kwargs=None, cross_attention_kwargs=None,
                  return_dict=False, down_block_additional_residuals=None, mid_block_additional_residual=None):
         if down_block_additional_residuals is not None or mid_block_additional_residual is not None:
-            raise NotImplementedError("ControlNet residual injection is not implemented in the HIP path yet")
+            self.set_additional_residuals(down_block_additional_residuals, mid_block_additional_residual)
+        elif self.residual_inputs and self._residuals_set:
+            self.set_additional_residuals(None, None)        # a call without the kwargs is a plain UNet call
         B = sample.shape[0]
         if tuple(sample.shape) != (self.B, self.in_channels, self.H, self.W):
             raise PeaError(f"HipUNet built for {(self.B, self.in_channels, self.H, self.W)}, got {tuple(sample.shape)}")
@@ -156,6 +161,45 @@ class HipUNet:
                     fn(blk, (), out)
         out = eps.to(sample.dtype) if sample.dtype in (torch.float16, torch.bfloat16) else eps
         return (out,)
+
+    # ---------------------------------------------------------------- ControlNet residual inputs
+    _residuals_set = False
+
+    def residual_shapes(self):
+        """[(C, H, W)] of `down_block_additional_residuals` followed by `mid_block_additional_residual` (last)."""
+        n = lib().pea_unet_num_residuals(self._h)
+        out = []
+        for i in range(n):
+            c, h, w = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+            check(lib().pea_unet_residual_info(self._h, i, ctypes.byref(c), ctypes.byref(h), ctypes.byref(w)))
+            out.append((c.value, h.value, w.value))
+        return out
+
+    def set_additional_residuals(self, down, mid, scale: float = 1.0):
+        """`down_block_additional_residuals=..., mid_block_additional_residual=...` of the UNet call
+        (tests/test_sdxl_zh_controlnet.py:534-535): NCHW tensors as a torch ControlNet returns them."""
+        if not self.residual_inputs:
+            raise PeaError("HipUNet was created without residual_inputs=True")
+        shapes = self.residual_shapes()
+        items = (list(down) if down is not None else [None] * (len(shapes) - 1)) + [mid]
+        if len(items) != len(shapes):
+            raise PeaError(f"{len(items) - 1} down residuals given, the UNet has {len(shapes) - 1}")
+        keep, ptrs = [], (ctypes.c_void_p * len(items))()
+        dts = {t.dtype for t in items if t is not None}
+        dt = torch.bfloat16 if dts == {torch.bfloat16} else torch.float32
+        for i, (t, (C, H, W)) in enumerate(zip(items, shapes)):
+            if t is None:
+                ptrs[i] = None
+                continue
+            if tuple(t.shape) != (self.B, C, H, W):
+                raise PeaError(f"residual {i}: {tuple(t.shape)} != {(self.B, C, H, W)}")
+            t = t.detach().to(self.device, dt).contiguous()
+            keep.append(t)
+            ptrs[i] = t.data_ptr()
+        check(lib().pea_unet_set_residuals(self._h, len(items), ptrs, 1 if dt == torch.bfloat16 else 0, float(scale),
+                                           stream_ptr()))
+        self._keep_res = keep
+        self._residuals_set = any(t is not None for t in items)
 
     def tap(self, k: int, grad: bool = False) -> torch.Tensor:
         """feature tap k (cast_hook order) as an NCHW fp32 tensor"""

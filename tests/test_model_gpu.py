@@ -256,6 +256,32 @@ def test_training_step_repeatable_and_optimizer(gpu):
     assert float(c["loss"]) != float(a["loss"])   # bf16 working copies were refreshed after the update
 
 
+def test_adamw_and_checkpoint_round_trip(gpu, tmp_path):
+    """fused AdamW over the flat adapter buffer against torch.optim.AdamW (the reference's
+    FusedAdam adam_w_mode, utils/model_utils.py:59-67), and the checkpoint writer of train_sdxl_zh.py:443-448:
+    `proj_{step}/pytorch_model.bin`, torch-loadable, reference state-dict keys, loads into the reference-shaped MLP."""
+    import copy, os
+    from oracle.step_ref import AdapterRef
+    cfg, us, ut, ad_ref, ad_hip, hs, ht, batch, tr = _train_pair(2, 12)
+    tr.training_step(batch, 0, sync=True)
+    w = ad_hip.flat_param.detach().clone().cpu().requires_grad_(True)
+    opt = torch.optim.AdamW([w], lr=1e-3, betas=tr.betas, eps=tr.eps, weight_decay=tr.weight_decay)
+    tr.lr, tr.warmup_steps, tr.lr_end = 1e-3, 0, 1e-3
+    for _ in range(3):
+        w.grad = ad_hip.flat_grad.detach().clone().cpu()
+        opt.step()
+        tr.optimizer_step()
+    assert torch.allclose(ad_hip.flat_param.detach().cpu(), w.detach(), rtol=1e-5, atol=1e-7)
+    d = tr.save_adapter(str(tmp_path))
+    assert os.path.basename(d) == "proj_3"
+    sd = torch.load(os.path.join(d, "pytorch_model.bin"), map_location="cpu")
+    assert list(sd) == list(ad_ref.state_dict())
+    fresh = copy.deepcopy(ad_ref)
+    fresh.load_state_dict(sd, strict=True)
+    for k, v in ad_hip.state_dict().items():
+        assert torch.equal(sd[k], v.detach().cpu()), k
+
+
 def test_asymmetric_teacher_student(gpu):
     """BASELINE config 4 shape case (SSD-1B student + SDXL teacher): student and teacher UNets with different
     transformer depths share tap shapes; the KD step must match the oracle."""
