@@ -178,6 +178,17 @@ int pea_unet_num_residuals(void* unet);
 int pea_unet_residual_info(void* unet, int i, int* C, int* H, int* W);
 int pea_unet_set_residuals(void* unet, int n, const void* const* ptrs, int dtype, float scale, void* stream);
 int pea_unet_destroy(void* unet);
+
+/* VAE encoder (AutoencoderKL.encode, train_sdxl_zh.py:306-309; train_sd_zh.py:188-189) on the same op tape: cfg uses
+ * in_channels (3), out_channels (2 * latent channels = 8), n_levels, block_out, layers_per_block, groups, eps.
+ * The handle works with pea_unet_num_weights / weight_info / load_weight / init_random / memory / destroy (diffusers
+ * keys `encoder.*`, `quant_conv.*`).  pea_vae_encode: pixels fp32 [B,3,H,W] -> moments = quant_conv(encoder(x))
+ * fp32 [B,2L,h,w] (optional) and latents = (mean + exp(0.5*clamp(logvar,-30,20)) * noise) * scaling fp32 [B,L,h,w]
+ * (`.latent_dist.sample() * vae.config.scaling_factor`; noise NULL = `.mode()`). */
+int pea_vae_encoder_create(const pea_unet_config* cfg, int B, int H, int W, void** out);
+int pea_vae_latent_shape(void* vae, int* C, int* H, int* W);
+int pea_vae_encode(void* vae, const float* pixels, const float* noise, float scaling, float* moments, float* latents,
+                   void* stream);
 int pea_unet_num_weights(void* unet);
 /* diffusers state-dict key + torch shape (d0,d1; conv adds [3][3]) of weight i; kind: 0 vector,
  * 1 linear [d0][d1] (1x1 convs included), 2 conv3x3 [d0][d1][3][3], 3 conv_in, 4 conv_out         */

@@ -97,3 +97,40 @@ def to_c(cfg) -> CUNetConfig:
     c.add_time_dim = cfg.addition_time_embed_dim
     c.proj_in_dim = cfg.projection_class_embeddings_input_dim
     return c
+
+
+# ---- VAE encoder (AutoencoderKL.encode, train_sdxl_zh.py:137,306-309)
+@dataclass
+class VAEConfig:
+    in_channels: int = 3
+    latent_channels: int = 4
+    block_out_channels: Tuple[int, ...] = (128, 256, 512, 512)
+    layers_per_block: int = 2
+    norm_num_groups: int = 32
+    norm_eps: float = 1e-6
+    scaling_factor: float = 0.13025
+    sample_size: int = 1024
+    name: str = "sdxl_vae"
+
+
+def sdxl_vae_config() -> VAEConfig:
+    return VAEConfig()
+
+
+def sd15_vae_config() -> VAEConfig:
+    return VAEConfig(scaling_factor=0.18215, sample_size=512, name="sd15_vae")
+
+
+def tiny_vae_config() -> VAEConfig:
+    return VAEConfig(block_out_channels=(64, 128, 128), sample_size=64, name="tiny_vae")
+
+
+def vae_to_c(cfg) -> CUNetConfig:
+    c = CUNetConfig()
+    n = len(cfg.block_out_channels)
+    c.in_channels, c.out_channels, c.n_levels = cfg.in_channels, 2 * cfg.latent_channels, n
+    for i in range(n):
+        c.block_out[i] = cfg.block_out_channels[i]
+    c.layers_per_block = cfg.layers_per_block
+    c.groups, c.eps = cfg.norm_num_groups, cfg.norm_eps
+    return c

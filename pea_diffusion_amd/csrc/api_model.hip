@@ -43,6 +43,50 @@ int pea_unet_create(const pea_unet_config* cfg, int B, int H, int W, int L, int 
   *out = u;
   return PEA_OK;
 }
+int pea_vae_encoder_create(const pea_unet_config* cfg, int B, int H, int W, void** out) {
+  NOTNULL(cfg, "pea_vae_encoder_create");
+  NOTNULL(out, "pea_vae_encoder_create");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
+    pea_set_error("pea_vae_encoder_create: no HIP device (there is no CPU fallback)");
+    return PEA_E_HIP;
+  }
+  Unet* u = new Unet();
+  memcpy(&u->cfg, cfg, sizeof(PeaUnetCfg));
+  u->graph = 1;
+  u->B = B; u->H = H; u->W = W; u->L = 0; u->needs_grad = false; u->owns_weights = true;
+  int rc = u->build();
+  if (rc == PEA_OK) rc = u->alloc();
+  if (rc != PEA_OK) {
+    delete u;
+    return rc;
+  }
+  *out = u;
+  return PEA_OK;
+}
+int pea_vae_latent_shape(void* h, int* C, int* H, int* W) {
+  NOTNULL(h, "pea_vae_latent_shape");
+  Unet* u = (Unet*)h;
+  if (u->graph != 1) { pea_set_error("pea_vae_latent_shape: not a VAE encoder handle"); return PEA_E_INVALID; }
+  const Tn& t = u->tn[u->t_out_in];
+  if (C) *C = u->cfg.out_channels / 2;
+  if (H) *H = t.H;
+  if (W) *W = t.W;
+  return PEA_OK;
+}
+int pea_vae_encode(void* h, const float* pixels, const float* noise, float scaling, float* moments, float* latents,
+                   void* stream) {
+  NOTNULL(h, "pea_vae_encode");
+  NOTNULL(pixels, "pea_vae_encode");
+  Unet* u = (Unet*)h;
+  if (u->graph != 1) { pea_set_error("pea_vae_encode: not a VAE encoder handle"); return PEA_E_INVALID; }
+  hipStream_t s = (hipStream_t)stream;
+  int rc = u->forward(pixels, nullptr, nullptr, 0, nullptr, 0, nullptr, u->vae_h, s);
+  if (rc != PEA_OK) return rc;
+  const Tn& t = u->tn[u->t_out_in];
+  return launch_vae_posterior(u->vae_h, u->slots[u->w_quant].f32, u->slots[u->b_quant].f32, noise, moments, latents, u->B,
+                              u->cfg.out_channels, (long long)t.H * t.W, scaling, s);
+}
 int pea_unet_destroy(void* h) {
   delete (Unet*)h;
   return PEA_OK;

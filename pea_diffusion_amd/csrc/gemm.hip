@@ -323,8 +323,8 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmP p) 
       const int b = gm / hw;
       const int rem = gm - b * hw;
       const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
-      a_iy0[j] = oy * p.stride - 1;
-      a_ix0[j] = ox * p.stride - 1;
+      a_iy0[j] = oy * p.stride - 1 + p.pad_off;
+      a_ix0[j] = ox * p.stride - 1 + p.pad_off;
       a_src[j] = p.A + (long long)b * p.Hs * p.Ws * p.Cin + chunk * 8;
     }
   }
@@ -472,8 +472,8 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_pipe_kernel(const GemmP p) 
       const int b = gm / hw;
       const int rem = gm - b * hw;
       const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
-      a_iy0[j] = oy * p.stride - 1;
-      a_ix0[j] = ox * p.stride - 1;
+      a_iy0[j] = oy * p.stride - 1 + p.pad_off;
+      a_ix0[j] = ox * p.stride - 1 + p.pad_off;
       a_src[j] = p.A + (long long)b * p.Hs * p.Ws * p.Cin + chunk * 8;
     }
   }
@@ -672,8 +672,8 @@ __global__ __launch_bounds__((WM * WN + LW) * 64, MINW) void gemm_lc_kernel(cons
         const int b = gm / hw;
         const int rem = gm - b * hw;
         const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
-        a_iy0[j] = oy * p.stride - 1;
-        a_ix0[j] = ox * p.stride - 1;
+        a_iy0[j] = oy * p.stride - 1 + p.pad_off;
+        a_ix0[j] = ox * p.stride - 1 + p.pad_off;
         a_src[j] = p.A + (long long)b * p.Hs * p.Ws * p.Cin + chunk * 8;
       }
     }
@@ -938,8 +938,8 @@ __global__ __launch_bounds__((WM * WN + LW) * 64) void gemm_lcp_kernel(const Gem
           const int b = gm / hw;
           const int rem = gm - b * hw;
           const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
-          a_iy0[j] = oy * p.stride - 1;
-          a_ix0[j] = ox * p.stride - 1;
+          a_iy0[j] = oy * p.stride - 1 + p.pad_off;
+          a_ix0[j] = ox * p.stride - 1 + p.pad_off;
           a_src[j] = p.A + (long long)b * p.Hs * p.Ws * p.Cin + chunk * 8;
         }
       }
@@ -1147,6 +1147,7 @@ static int pick_variant(const GemmP& p) {
   //   31      =  64x160 tile, 2x2 consumer waves (32x80 each) + 4 DMA waves, 4 stages, persistent
   // A launch of at most one tile per CU gains nothing from the persistent form; beyond that it hides every
   // tile's prologue behind the previous tile's epilogue.
+  if (p.N % 160 != 0 && p.N % 128 == 0 && p.M >= 1024) return 30;   // VAE widths 128/256/512: exact 128-wide tiles
   const int t128 = cdiv(p.M, 128) * cdiv(p.N, 160), t256 = cdiv(p.M, 256) * cdiv(p.N, 160);
   if (p.mode == 1) {
     if (t256 >= 256) return 27;                      // 128^2- and 64^2-level convs (N = 320 / 640)
@@ -1278,7 +1279,7 @@ __global__ __launch_bounds__(256) void conv_out_kernel(const bf16* __restrict__ 
   const long long pix = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (pix >= (long long)B * H * W) return;
   const int xw = (int)(pix % W), yh = (int)((pix / W) % H), b = (int)(pix / ((long long)W * H));
-  float acc[4] = {0.f, 0.f, 0.f, 0.f};   // Cout <= 4
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // Cout <= 8 (UNet eps: 4, VAE moments: 8)
   const int cchunks = Cin / 8;
   for (int i = lane; i < 9 * cchunks; i += 64) {
     const int tap = i / cchunks, c8 = (i - tap * cchunks) * 8;
@@ -1286,15 +1287,20 @@ __global__ __launch_bounds__(256) void conv_out_kernel(const bf16* __restrict__ 
     const int iy = yh + ky - 1, ix = xw + kx - 1;
     if ((unsigned)iy >= (unsigned)H || (unsigned)ix >= (unsigned)W) continue;
     const bf16x8 v = *(const bf16x8*)(x + (((long long)b * H + iy) * W + ix) * Cin + c8);
-    for (int co = 0; co < Cout; ++co) {
-      const float* wp = w + ((long long)co * 9 + tap) * Cin + c8;
-      float a = 0.f;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) a += (float)v[j] * wp[j];
-      acc[co] += a;
+    for (int co = 0; co < 8; ++co) {
+      if (co < Cout) {
+        const float* wp = w + ((long long)co * 9 + tap) * Cin + c8;
+        float a = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) a += (float)v[j] * wp[j];
+        acc[co] += a;
+      }
     }
   }
-  for (int co = 0; co < Cout; ++co) {
+#pragma unroll
+  for (int co = 0; co < 8; ++co) {
+    if (co >= Cout) break;
     const float r = wave_sum(acc[co]);
     if (lane == 0) y[(((long long)b * Cout + co) * H + yh) * W + xw] = r + bias[co];
   }
@@ -1302,7 +1308,7 @@ __global__ __launch_bounds__(256) void conv_out_kernel(const bf16* __restrict__ 
 
 int launch_conv_out(const bf16* x, const float* w, const float* bias, float* y, int B, int Cin, int H, int W,
                     int Cout, hipStream_t s) {
-  SHAPECHK(Cout <= 4 && Cin % 8 == 0, "conv_out: Cout<=4, Cin%%8");
+  SHAPECHK(Cout <= 8 && Cin % 8 == 0, "conv_out: Cout<=8, Cin%%8");
   const long long pix = (long long)B * H * W;
   hipLaunchKernelGGL(conv_out_kernel, dim3((unsigned)cdivl(pix, 4)), dim3(256), 0, s, x, w, bias, y, B, Cin, H, W,
                      Cout);

@@ -69,7 +69,7 @@ struct Tn {
 };
 
 enum OpKind { OP_CONV_IN, OP_CONV3, OP_LINEAR, OP_GN, OP_LN, OP_ATTN, OP_GEGLU, OP_CONCAT, OP_SILU, OP_TEMB,
-              OP_CONV_OUT, OP_ADD };
+              OP_CONV_OUT, OP_ADD, OP_ATTN_MAT };
 
 struct Op {
   int kind;
@@ -90,6 +90,11 @@ struct Unet {
   PeaUnetCfg cfg;
   int B, H, W, L;                 // batch, latent H/W, context length
   bool needs_grad;
+  int graph = 0;                     // 0: UNet2DConditionModel, 1: AutoencoderKL encoder (VAE, inference only)
+  int w_quant = -1, b_quant = -1;    // VAE: quant_conv (1x1) slots
+  bf16* am_scores = nullptr;         // VAE mid attention: materialised [HW][HW] scores of one image, V^T of one image
+  bf16* am_vt = nullptr;
+  float* vae_h = nullptr;            // VAE: encoder output before quant_conv, fp32 [B][C2][h][w]
   bool residual_inputs = false;      // ControlNet: down_block_additional_residuals / mid_block_additional_residual
   std::vector<int> ext_res;          // their tensors, diffusers order (conv_in, down blocks..., then mid last)
   std::deque<WSlot> slots;
@@ -115,6 +120,7 @@ struct Unet {
   float* eps_out = nullptr; const float* deps_in = nullptr;
 
   int build();
+  int build_vae_encoder();
   int alloc();
   int load_weight(const char* name, const float* dev_ptr, long long numel, hipStream_t s);
   int init_random(unsigned long long seed, hipStream_t s);

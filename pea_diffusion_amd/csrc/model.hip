@@ -125,6 +125,31 @@ struct Builder {
     o.a = x; o.w = w; o.bias = b; o.out = out; o.p0 = stride; o.p1 = ups; o.rv = rv; o.rv_off = rv_off; o.res = res;
     return out;
   }
+  // AutoencoderKL pieces (diffusers 0.23 [ext]; call site train_sdxl_zh.py:306-309)
+  int resnet_plain(int x, const std::string& pfx, int cout) {          // ResnetBlock2D with temb_channels=None
+    const int cin = u.tn[x].cols;
+    const float eps = u.cfg.eps;
+    int h = gn(x, pfx + ".norm1", true, eps);
+    h = conv(h, pfx + ".conv1", cout, 1, 0);
+    h = gn(h, pfx + ".norm2", true, eps);
+    int sc = x;
+    if (cin != cout) sc = linear(x, pfx + ".conv_shortcut", cout, true);
+    return conv(h, pfx + ".conv2", cout, 1, 0, -1, 0, sc);
+  }
+  int attention_mat(int x, const std::string& pfx) {                   // Attention(heads=1, residual_connection=True)
+    const Tn t0 = u.tn[x];
+    const int C = t0.cols;
+    int n = gn(x, pfx + ".group_norm", false, u.cfg.eps);
+    int q = linear(n, pfx + ".to_q", C, true);
+    int k = linear(n, pfx + ".to_k", C, true);
+    int v = linear(n, pfx + ".to_v", C, true);
+    const int o = T(t0.rows, C, t0.B, t0.H, t0.W);
+    {
+      Op& op = push(OP_ATTN_MAT);
+      op.a = q; op.b = k; op.c = v; op.out = o; op.f0 = 1.0f / sqrtf((float)C);
+    }
+    return linear(o, pfx + ".to_out.0", C, true, x);
+  }
   int concat(int a, int b) {
     const int out = T(u.tn[a].rows, u.tn[a].cols + u.tn[b].cols, u.tn[a].B, u.tn[a].H, u.tn[a].W);
     Op& o = push(OP_CONCAT);
@@ -240,7 +265,49 @@ std::vector<std::pair<std::string, int>> enumerate_resnets(const PeaUnetCfg& c) 
 }
 }  // namespace
 
+int Unet::build_vae_encoder() {
+  const PeaUnetCfg& c = cfg;
+  SHAPECHK(c.n_levels >= 2 && c.n_levels <= 4, "vae: n_levels=%d", c.n_levels);
+  SHAPECHK(!needs_grad && !residual_inputs, "vae encoder: inference graph only");
+  SHAPECHK(c.out_channels <= 8 && c.out_channels % 2 == 0, "vae: %d moment channels", c.out_channels);
+  const int f = 1 << (c.n_levels - 1);
+  SHAPECHK(H % f == 0 && W % f == 0 && ((H / f) * (W / f)) % 64 == 0, "vae: image %dx%d (latent tokens must be a multiple of 64)", H, W);
+  for (int i = 0; i < c.n_levels; ++i) SHAPECHK(c.block_out[i] % 64 == 0, "vae: block_out_channels[%d]=%d", i, c.block_out[i]);
+  Builder bd(*this);
+  int x = bd.T((long long)B * H * W, c.block_out[0], B, H, W);
+  {
+    Op& o = bd.push(OP_CONV_IN);
+    o.out = x;
+    o.w = bd.slot("encoder.conv_in.weight", W_CONV_IN, c.block_out[0], c.in_channels, 9LL * c.block_out[0] * c.in_channels);
+    o.bias = bd.vec("encoder.conv_in.bias", c.block_out[0]);
+  }
+  const int n = c.n_levels;
+  for (int i = 0; i < n; ++i) {
+    const std::string p = "encoder.down_blocks." + std::to_string(i);
+    for (int j = 0; j < c.layers_per_block; ++j) x = bd.resnet_plain(x, p + ".resnets." + std::to_string(j), c.block_out[i]);
+    if (i != n - 1) {
+      x = bd.conv(x, p + ".downsamplers.0.conv", c.block_out[i], 2, 0);
+      ops.back().p2 = 1;                       // Downsample2D(padding=0): F.pad (0,1,0,1) then a stride-2 conv
+    }
+  }
+  x = bd.resnet_plain(x, "encoder.mid_block.resnets.0", c.block_out[n - 1]);
+  x = bd.attention_mat(x, "encoder.mid_block.attentions.0");
+  x = bd.resnet_plain(x, "encoder.mid_block.resnets.1", c.block_out[n - 1]);
+  x = bd.gn(x, "encoder.conv_norm_out", true, c.eps);
+  t_out_in = x;
+  {
+    Op& o = bd.push(OP_CONV_OUT);
+    o.a = x;
+    o.w = bd.slot("encoder.conv_out.weight", W_CONV_OUT, c.out_channels, c.block_out[n - 1], 9LL * c.out_channels * c.block_out[n - 1]);
+    o.bias = bd.vec("encoder.conv_out.bias", c.out_channels);
+  }
+  w_quant = bd.vec("quant_conv.weight", c.out_channels * c.out_channels);   // [C2][C2][1][1]
+  b_quant = bd.vec("quant_conv.bias", c.out_channels);
+  return PEA_OK;
+}
+
 int Unet::build() {
+  if (graph == 1) return build_vae_encoder();
   const PeaUnetCfg& c = cfg;
   SHAPECHK(c.n_levels >= 2 && c.n_levels <= 4, "unet: n_levels=%d", c.n_levels);
   for (int i = 0; i < c.n_levels; ++i) {
@@ -457,6 +524,11 @@ int Unet::alloc() {
       delta_elems = std::max(delta_elems, (size_t)B * o.p0 * o.p1);
       part_bytes = std::max(part_bytes, attention_bwd_scratch_bytes(B, o.p0, o.p1, o.p2, o.p3));
     }
+    if (o.kind == OP_ATTN_MAT && !am_scores) {
+      const size_t HW = (size_t)tn[o.a].H * tn[o.a].W;
+      HIPCHK(hipMalloc((void**)&am_scores, HW * HW * 2));
+      HIPCHK(hipMalloc((void**)&am_vt, HW * tn[o.a].cols * 2));
+    }
     if (o.kind == OP_LINEAR && o.p3 == 3 && o.c >= 0) geglu_elems = std::max(geglu_elems, (size_t)tn[o.c].rows * tn[o.c].cols);
     if (o.kind == OP_CONV3 && o.p1 && tn[o.a].rg)
       ups_elems = std::max(ups_elems, (size_t)tn[o.out].rows * tn[o.a].cols);
@@ -480,6 +552,10 @@ int Unet::alloc() {
     }
     HIPCHK(hipMalloc((void**)&tproj_grad, sizeof(float) * B * tproj_total));
   }
+  if (graph == 1) {
+    const Tn& t = tn[t_out_in];
+    HIPCHK(hipMalloc((void**)&vae_h, sizeof(float) * (size_t)B * cfg.out_channels * t.H * t.W));
+  }
   RC(pea_zero_page(&zeros));
   return PEA_OK;
 }
@@ -497,6 +573,9 @@ Unet::~Unet() {
   if (attn_part) hipFree(attn_part);
   if (kv_part) hipFree(kv_part);
   if (geglu_tmp) hipFree(geglu_tmp);
+  if (am_scores) hipFree(am_scores);
+  if (am_vt) hipFree(am_vt);
+  if (vae_h) hipFree(vae_h);
 }
 
 int Unet::load_weight(const char* name, const float* src, long long numel, hipStream_t s) {
@@ -591,7 +670,7 @@ int Unet::forward(const float* x, const float* t, const void* ehs, int ehs_dtype
     return PEA_E_STATE;
   }
   x_in = x; t_in = t; tid_in = time_ids; eps_out = eps;
-  {
+  if (graph == 0) {
     Tn& e = tn[t_ehs];
     const long long n = e.rows * e.cols;
     if ((const void*)e.d != ehs) {
@@ -631,6 +710,22 @@ int Unet::forward(const float* x, const float* t, const void* ehs, int ehs_dtype
         RC(launch_gemm(p, s));
         break;
       }
+      case OP_ATTN_MAT: {              // one head over all H*W tokens: S = Q K^T, row softmax, O = P V per image
+        Tn &q = tn[o.a], &k = tn[o.b], &v = tn[o.c], &out = tn[o.out];
+        const int HW = q.H * q.W, C = q.cols;
+        for (int b = 0; b < B; ++b) {
+          const long long off = (long long)b * HW * C;
+          GemmP p; fill_gemm(p);
+          p.A = q.d + off; p.lda = C; p.M = HW; p.K = C; p.W = k.d + off; p.ldw = C; p.N = HW; p.C = am_scores; p.ldc = HW;
+          RC(launch_gemm(p, s));
+          RC(launch_softmax_rows(am_scores, HW, HW, HW, o.f0, s));
+          RC(launch_transpose_bf16(v.d + off, am_vt, HW, C, HW, s));
+          GemmP r; fill_gemm(r);
+          r.A = am_scores; r.lda = HW; r.M = HW; r.K = HW; r.W = am_vt; r.ldw = HW; r.N = C; r.C = out.d + off; r.ldc = C;
+          RC(launch_gemm(r, s));
+        }
+        break;
+      }
       case OP_ADD:
         RC(launch_add(tn[o.a].d, tn[o.b].d, tn[o.out].d, tn[o.out].rows * tn[o.out].cols, s));
         break;
@@ -650,7 +745,7 @@ int Unet::forward(const float* x, const float* t, const void* ehs, int ehs_dtype
         p.mode = 1; p.A = a.d; p.W = slots[o.w].w; p.ldw = slots[o.w].ldw; p.C = out.d; p.ldc = out.cols;
         p.Hs = a.H; p.Ws = a.W; p.Cin = a.cols; p.Ho = out.H; p.Wo = out.W; p.stride = o.p0; p.shift = o.p1 ? 1 : 0;
         p.M = (int)out.rows; p.N = out.cols; p.K = 9 * a.cols; p.bias = slots[o.bias].f32; p.zeros = zeros;
-        p.rows_per_batch = out.H * out.W;
+        p.rows_per_batch = out.H * out.W; p.pad_off = o.p2;
         if (o.rv >= 0) { p.rowvec = tn[o.rv].d + o.rv_off; p.ldrv = tn[o.rv].cols; }
         if (o.res >= 0) { p.res = tn[o.res].d; p.ldres = tn[o.res].cols; }
         RC(launch_gemm(p, s));
@@ -680,7 +775,7 @@ int Unet::forward(const float* x, const float* t, const void* ehs, int ehs_dtype
         RC(launch_geglu_fwd(tn[o.a].d, tn[o.out].d, tn[o.a].rows, tn[o.out].cols, s));
         break;
       case OP_CONV_OUT:
-        RC(launch_conv_out(tn[o.a].d, slots[o.w].f32, slots[o.bias].f32, eps_out, B, tn[o.a].cols, H, W,
+        RC(launch_conv_out(tn[o.a].d, slots[o.w].f32, slots[o.bias].f32, eps_out, B, tn[o.a].cols, tn[o.a].H, tn[o.a].W,
                            cfg.out_channels, s));
         break;
     }

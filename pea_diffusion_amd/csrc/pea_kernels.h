@@ -23,6 +23,7 @@ struct GemmP {
   // conv (mode 1): source NHWC [B][Hs][Ws][Cin]; output pixels [B][Ho][Wo]; M = B*Ho*Wo
   int Hs, Ws, Cin, Ho, Wo;
   int stride;                      // output -> virtual-input coordinate multiplier (1 or 2)
+  int pad_off;                     // 0: padding 1 on every side; 1: the VAE downsampler's (0,1,0,1) padding
   int shift;                       // virtual input = source upsampled by 2^shift (nearest) / zero-stuffed
   int parity;                      // 1: only even virtual coordinates are real (transposed stride-2 conv)
   const bf16* zeros;               // >= 16 bytes of zeros (out-of-bounds taps)
@@ -183,3 +184,6 @@ int launch_cfg_combine(const float* eps2, float* out, int B, long long per, floa
 int launch_dpm_update(float* sample, const float* eps, float* x0_prev, long long n, float alpha_s, float sigma_s,
                       float c_s, float c_0, float c_1, hipStream_t s);
 int launch_residual_import(const void* src, int dtype, bf16* dst, int B, int C, long long HW, float scale, hipStream_t s);
+int launch_softmax_rows(bf16* s, long long rows, int cols, int ld, float scale, hipStream_t st);   // in place
+int launch_vae_posterior(const float* h, const float* wq, const float* bq, const float* noise, float* moments,
+                         float* latents, int B, int C2, long long HW, float scaling, hipStream_t s);

@@ -124,3 +124,83 @@ int launch_residual_import(const void* src, int dtype, bf16* dst, int B, int C, 
   HIPCHK(hipGetLastError());
   return PEA_OK;
 }
+
+// ---- VAE encoder tail (train_sdxl_zh.py:306-309): moments = quant_conv(h) (1x1, C2 = 2*latent channels <= 8);
+// mean, logvar = chunk(moments); logvar clamped to [-30, 20]; latents = (mean + exp(0.5 logvar) * noise) * scaling
+// (diffusers 0.23 DiagonalGaussianDistribution [ext]).  NCHW fp32; one thread per pixel.
+__global__ void vae_posterior_kernel(const float* __restrict__ h, const float* __restrict__ wq,
+                                     const float* __restrict__ bq, const float* __restrict__ noise,
+                                     float* __restrict__ moments, float* __restrict__ latents, int B, int C2,
+                                     long long HW, float scaling) {
+  SM_LOOP(i, (long long)B * HW) {
+    const long long b = i / HW, p = i - b * HW;
+    float in[8], m[8];
+    for (int c = 0; c < C2; ++c) in[c] = h[(b * C2 + c) * HW + p];
+    for (int o = 0; o < C2; ++o) {
+      float a = bq[o];
+      for (int c = 0; c < C2; ++c) a += wq[o * C2 + c] * in[c];
+      m[o] = a;
+      if (moments) moments[(b * C2 + o) * HW + p] = a;
+    }
+    const int L = C2 / 2;
+    if (latents)
+      for (int c = 0; c < L; ++c) {
+        const float lv = fminf(fmaxf(m[L + c], -30.f), 20.f);
+        const float nz = noise ? noise[(b * L + c) * HW + p] : 0.f;
+        latents[(b * L + c) * HW + p] = (m[c] + __expf(0.5f * lv) * nz) * scaling;
+      }
+  }
+}
+int launch_vae_posterior(const float* h, const float* wq, const float* bq, const float* noise, float* moments,
+                         float* latents, int B, int C2, long long HW, float scaling, hipStream_t s) {
+  SHAPECHK(C2 >= 2 && C2 <= 8 && C2 % 2 == 0, "vae posterior: %d moment channels", C2);
+  hipLaunchKernelGGL(vae_posterior_kernel, dim3(sm_grid((long long)B * HW)), dim3(256), 0, s, h, wq, bq, noise, moments,
+                     latents, B, C2, HW, scaling);
+  HIPCHK(hipGetLastError());
+  return PEA_OK;
+}
+
+// ---- row softmax of a materialised score matrix (VAE mid-block attention: ONE head of width 512 over H*W tokens,
+// outside the flash kernel's head widths): s[r][:] = softmax(scale * s[r][:]) in place, bf16 storage, fp32 math.
+// One workgroup per row; the row is read twice (max+sum pass with online rescale, then the write pass).
+__global__ __launch_bounds__(256) void softmax_rows_kernel(bf16* __restrict__ s, int cols, int ld, float scale) {
+  bf16* row = s + (long long)blockIdx.x * ld;
+  const float k = scale * 1.4426950408889634f;
+  float m = -INFINITY, l = 0.f;
+  for (int c = threadIdx.x * 8; c < cols; c += 256 * 8) {
+    const bf16x8 v = *(const bf16x8*)(row + c);
+    float mx = m;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) mx = fmaxf(mx, (float)v[j] * k);
+    float acc = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc += __builtin_amdgcn_exp2f((float)v[j] * k - mx);
+    l = l * __builtin_amdgcn_exp2f(m - mx) + acc;
+    m = mx;
+  }
+  __shared__ float sm[4], sl[4];
+  const float wm = wave_max(m);
+  l *= (m == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(m - wm);
+  const float wl = wave_sum(l);
+  if ((threadIdx.x & 63) == 0) { sm[threadIdx.x >> 6] = wm; sl[threadIdx.x >> 6] = wl; }
+  __syncthreads();
+  const float M = fmaxf(fmaxf(sm[0], sm[1]), fmaxf(sm[2], sm[3]));
+  float Lsum = 0.f;
+#pragma unroll
+  for (int w = 0; w < 4; ++w) Lsum += sl[w] * __builtin_amdgcn_exp2f(sm[w] - M);
+  const float inv = 1.0f / Lsum;
+  for (int c = threadIdx.x * 8; c < cols; c += 256 * 8) {
+    bf16x8 v = *(const bf16x8*)(row + c);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = (bf16)(__builtin_amdgcn_exp2f((float)v[j] * k - M) * inv);
+    *(bf16x8*)(row + c) = v;
+  }
+}
+int launch_softmax_rows(bf16* s, long long rows, int cols, int ld, float scale, hipStream_t st) {
+  SHAPECHK(cols % 8 == 0 && ld % 8 == 0 && rows > 0, "softmax_rows: cols=%d ld=%d", cols, ld);
+  PROF_BEGIN(6, 0.0, 6.0 * rows * (double)cols, st);
+  hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)rows), dim3(256), 0, st, s, cols, ld, scale);
+  PROF_END(st);
+  HIPCHK(hipGetLastError());
+  return PEA_OK;
+}

@@ -1,0 +1,80 @@
+"""-m gpu: the VAE encoder on the HIP tape (C ABI pea_vae_*) against oracle/vae_ref.py on the same bf16-rounded weights
+and seeded pixels; tolerance as for the UNet forward (relative L2 <= 2e-2 through ~40 chained bf16 ops)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+from test_model_gpu import gpu, rel_l2, round_weights_bf16_  # noqa: E402,F401
+
+
+def _pair(cfg_name, B, H, W, seed=0):
+    import oracle.vae_ref as ov
+    from pea_diffusion_amd import config as pc
+    from pea_diffusion_amd.vae import HipVAEEncoder
+    torch.manual_seed(seed)
+    ref = ov.VAEEncoderRef(getattr(ov, cfg_name)())
+    round_weights_bf16_(ref)
+    hip = HipVAEEncoder(getattr(pc, cfg_name)(), B, H, W)
+    assert {k: tuple(v.shape) for k, v in ref.state_dict().items()}.keys() == hip.weight_table().keys()
+    missing, unexpected = hip.load_state_dict(ref.state_dict())
+    assert not missing and not unexpected
+    return ref, hip
+
+
+@pytest.mark.parametrize("B,H,W", [(2, 64, 64), (1, 128, 64)])
+def test_vae_encode_tiny_vs_oracle(gpu, B, H, W):
+    ref, hip = _pair("tiny_vae_config", B, H, W)
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(B, 3, H, W, generator=g).clamp(-1, 1)
+    with torch.no_grad():
+        mom = ref.moments(x)
+    d = hip.encode(x.cuda()).latent_dist
+    e = rel_l2(d.moments, mom)
+    print(f"[vae tiny {B}x3x{H}x{W}] moments {tuple(d.moments.shape)} rel_l2={e:.3e}")
+    assert d.moments.shape == mom.shape and e < 2e-2
+    nz = torch.randn(hip.latent_shape, generator=g)
+    want = (mom[:, :4] + torch.exp(0.5 * mom[:, 4:].clamp(-30, 20)) * nz) * ref.config.scaling_factor
+    got = hip.encode_latents(x.cuda(), noise=nz.cuda())
+    assert rel_l2(got, want) < 2e-2
+    # the fused sample equals the unfused pieces of the same run bit for bit in the mean/std arithmetic
+    assert torch.allclose(got, d.sample(noise=nz.cuda()) * ref.config.scaling_factor, rtol=1e-5, atol=1e-6)
+    assert torch.allclose(hip.encode_latents(x.cuda(), sample=False), d.mode() * ref.config.scaling_factor, rtol=1e-6, atol=1e-7)
+
+
+def test_vae_full_checkpoint_keys_and_shape_errors(gpu):
+    ref, hip = _pair("tiny_vae_config", 1, 64, 64)
+    sd = dict(ref.state_dict())
+    sd["decoder.conv_in.weight"] = torch.zeros(1)
+    sd["post_quant_conv.bias"] = torch.zeros(4)
+    assert hip.load_state_dict(sd) == ([], [])
+    with pytest.raises(Exception):
+        hip.encode(torch.zeros(1, 3, 32, 64).cuda())
+
+
+def test_vae_sdxl_size_vs_oracle_256(gpu):
+    """SDXL VAE widths (128/256/512/512, 34.2 M parameters) on a 256x256 image (1024 latent tokens through the
+    materialised single-head attention), against the fp32 oracle."""
+    ref, hip = _pair("sdxl_vae_config", 1, 256, 256)
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(1, 3, 256, 256, generator=g).clamp(-1, 1)
+    with torch.no_grad():
+        mom = ref.moments(x)
+    got = hip.encode(x.cuda()).latent_dist.moments
+    e = rel_l2(got, mom)
+    print(f"[vae sdxl widths 256x256] rel_l2={e:.3e}")
+    assert e < 2e-2
+
+
+def test_vae_full_size_properties(gpu):
+    """1024x1024 (16 384 latent tokens), batch 2: finite, deterministic run to run, batch elements independent."""
+    from pea_diffusion_amd import config as pc
+    from pea_diffusion_amd.vae import HipVAEEncoder
+    hip = HipVAEEncoder(pc.sdxl_vae_config(), 2)
+    hip.init_random(3)
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(2, 3, 1024, 1024, generator=g).clamp(-1, 1).cuda()
+    a = hip.encode(x).latent_dist.moments.clone()
+    b = hip.encode(x).latent_dist.moments
+    assert a.shape == (2, 8, 128, 128) and torch.isfinite(a).all() and torch.equal(a, b)
+    c = hip.encode(torch.stack([x[1], x[0]])).latent_dist.moments
+    assert torch.equal(c[0], a[1]) and torch.equal(c[1], a[0])
