@@ -148,6 +148,9 @@ def main():
     ap.add_argument("--force-collective", action="store_true", help="init RCCL and all-reduce even with one rank (path test)")
     ap.add_argument("--dump-prof", default="", help="write every profiled launch (shape-tagged) to this CSV")
     ap.add_argument("--breakdown", action="store_true", help="print the per-kernel-family table to stderr")
+    ap.add_argument("--with-vae", action="store_true",
+                    help="also run the NEXT batch's VAE encode (train_sdxl_zh.py:306-309, 1024x1024 pixels) on a side "
+                         "HIP stream inside every step; not the default: BASELINE's metric starts from latents (SURVEY 8d)")
     ap.add_argument("--single-stream", action="store_true", help="analysis only: teacher and student passes on ONE stream")
     args = ap.parse_args()
     if args.cpu_baseline_worker:
@@ -198,11 +201,27 @@ def main():
         pdist.broadcast_params_(adapter.flat_param, src=0)      # identical replicas
         adapter.mark_updated()
 
+    vae = None
+    if args.with_vae:
+        from pea_diffusion_amd.vae import HipVAEEncoder
+        vae = HipVAEEncoder(pc.sdxl_vae_config() if args.model == "sdxl" else pc.tiny_vae_config(), B, hw * 8, hw * 8)
+        vae.init_random(seed=11)
+        pixels = torch.randn(B, 3, hw * 8, hw * 8, device=dev).clamp_(-1, 1)
+        side = torch.cuda.Stream(device=dev)
+        next_latents = [None]
+
     def step():
+        if vae is not None:                   # next batch's latents on the side stream, overlapped with this step
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                next_latents[0] = vae.encode_latents(pixels)
         trainer.training_step(batch)          # includes the all-reduce of the flat adapter grad when world > 1
         if args.force_collective and world == 1:
             dist.all_reduce(adapter.flat_grad)
         trainer.optimizer_step()
+        if vae is not None:
+            torch.cuda.current_stream().wait_stream(side)
+            batch["latents"] = next_latents[0]
 
     def barrier():
         if use_dist:
@@ -290,7 +309,9 @@ def main():
                        "global_batch": world * B, "per_gpu_batch": B, "latent": hw, "ctx_len": args.ctx,
                        "adapter": f"MLP({enc_dim},{cfg.pooled_dim},{hidden},{cfg.cross_attention_dim})",
                        "parallelism": f"dp{world}", "weights": "random init (teacher == student checkpoint)",
-                       "loss": round(loss, 6)},
+                       "loss": round(loss, 6),
+                       **({"vae_encode": f"next batch's {hw * 8}x{hw * 8} VAE encode on a side HIP stream inside every step"}
+                          if args.with_vae else {})},
             "tflop_per_image": TFLOP_PER_IMAGE.get(args.model),
             "achieved_tflops_per_gpu": (round(ips / world * TFLOP_PER_IMAGE[args.model], 1)
                                         if TFLOP_PER_IMAGE.get(args.model) else None),

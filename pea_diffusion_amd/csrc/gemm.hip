@@ -1129,11 +1129,11 @@ static int launch_variant(const GemmP& p, hipStream_t stream) {
     case 25: rc = launch_lc<MODE, 128, 160, 4, 2, 4, 3, false, true>(p, stream); break; \
     case 26: rc = launch_lc<MODE, 128, 160, 4, 2, 4, 4, false, true>(p, stream); break; \
     case 27: rc = launch_lcp<MODE, 256, 160, 4, 2, 4, 3>(p, stream); break; \
-    case 32: rc = launch_lc<MODE, 128, 160, 4, 2, 2, 2, false, true, 5>(p, stream); break; /* two workgroups per CU */ \
     case 28: rc = launch_lcp<MODE, 128, 160, 4, 2, 4, 3>(p, stream); break; \
     case 29: rc = launch_lcp<MODE, 128, 160, 2, 2, 4, 4>(p, stream); break; \
     case 30: rc = launch_lcp<MODE, 128, 128, 2, 2, 4, 4>(p, stream); break; \
     case 31: rc = launch_lcp<MODE, 64, 160, 2, 2, 4, 4>(p, stream); break; \
+    case 33: rc = launch_lcp<MODE, 256, 128, 4, 2, 4, 3>(p, stream); break; \
     default: rc = launch_variant<MODE, 128, 128, 2, 2, 2>(p, stream); break; \
   }
 
@@ -1147,7 +1147,8 @@ static int pick_variant(const GemmP& p) {
   //   31      =  64x160 tile, 2x2 consumer waves (32x80 each) + 4 DMA waves, 4 stages, persistent
   // A launch of at most one tile per CU gains nothing from the persistent form; beyond that it hides every
   // tile's prologue behind the previous tile's epilogue.
-  if (p.N % 160 != 0 && p.N % 128 == 0 && p.M >= 1024) return 30;   // VAE widths 128/256/512: exact 128-wide tiles
+  if (p.N % 160 != 0 && p.N % 128 == 0 && p.M >= 1024)                // VAE widths 128/256/512: exact 128-wide tiles
+    return cdiv(p.M, 256) * (p.N / 128) >= 256 ? 33 : 30;
   const int t128 = cdiv(p.M, 128) * cdiv(p.N, 160), t256 = cdiv(p.M, 256) * cdiv(p.N, 160);
   if (p.mode == 1) {
     if (t256 >= 256) return 27;                      // 128^2- and 64^2-level convs (N = 320 / 640)
