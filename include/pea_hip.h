@@ -179,6 +179,24 @@ int pea_unet_residual_info(void* unet, int i, int* C, int* H, int* W);
 int pea_unet_set_residuals(void* unet, int n, const void* const* ptrs, int dtype, float scale, void* stream);
 int pea_unet_destroy(void* unet);
 
+/* ControlNet (`self.controlnet(control_model_input, t, encoder_hidden_states=..., controlnet_cond=image,
+ * conditioning_scale=..., guess_mode=False, added_cond_kwargs=..., return_dict=False)`,
+ * tests/test_sdxl_zh_controlnet.py:510-519; diffusers 0.23 ControlNetModel [ext]) on the same op tape: the UNet's
+ * conditioning, conv_in, down blocks and mid block + `controlnet_cond_embedding.*`, `controlnet_down_blocks.*`,
+ * `controlnet_mid_block.*` (diffusers keys; handle works with the pea_unet_* weight functions and destroy).
+ * set_cond: conditioning image fp32 [B,3,8H,8W]; its embedding is computed here, once per generation (the image does
+ *   not change over the denoise steps), and reused by every forward.
+ * forward: same conditioning arguments as pea_unet_forward; results stay in the context as bf16 NHWC tensors
+ *   (pea_controlnet_output: down residuals in diffusers order, mid LAST) -- hand them to
+ *   pea_unet_set_residuals(unet, n, ptrs, 2, conditioning_scale, stream). */
+int pea_controlnet_create(const pea_unet_config* cfg, int B, int H, int W, int L, void** out);
+int pea_controlnet_set_cond(void* cn, const float* image, void* stream);
+int pea_controlnet_forward(void* cn, const float* x, const float* t, const void* ehs, int ehs_dtype, const void* text,
+                           int text_dtype, const float* time_ids, void* stream);
+int pea_controlnet_num_outputs(void* cn);
+int pea_controlnet_output(void* cn, int i, void** ptr, int* C, int* H, int* W);
+int pea_controlnet_export_nchw(void* cn, int i, float* dst, void* stream);   /* fp32 [B,C,H,W] copy of output i */
+
 /* VAE encoder (AutoencoderKL.encode, train_sdxl_zh.py:306-309; train_sd_zh.py:188-189) on the same op tape: cfg uses
  * in_channels (3), out_channels (2 * latent channels = 8), n_levels, block_out, layers_per_block, groups, eps.
  * The handle works with pea_unet_num_weights / weight_info / load_weight / init_random / memory / destroy (diffusers

@@ -1,0 +1,113 @@
+"""`HipControlNet`: the ControlNet call of the reference's ControlNet inference path --
+`down_block_res_samples, mid_block_res_sample = self.controlnet(control_model_input, t, encoder_hidden_states=...,
+controlnet_cond=image, conditioning_scale=cond_scale, guess_mode=False, added_cond_kwargs=..., return_dict=False)`
+(tests/test_sdxl_zh_controlnet.py:510-519) -- on the HIP op tape (UNet encoder half + conditioning embedding +
+zero-convs).  The conditioning embedding of an image is computed once and reused while the SAME tensor is passed
+(it is constant over a generation's denoise steps); `feed(unet, scale)` hands the residuals to a `HipUNet`
+device-to-device without the NCHW round trip."""
+from __future__ import annotations
+
+import ctypes
+from typing import Dict, Optional
+
+import torch
+
+from . import config as _cfg
+from ._lib import PeaError, check, lib, ptr, stream_ptr
+from .unet import HipUNet, _Config
+
+
+class HipControlNet:
+    def __init__(self, cfg, batch: int, height: Optional[int] = None, width: Optional[int] = None, ctx_len: int = 77):
+        if not torch.cuda.is_available():
+            raise PeaError("HipControlNet needs a MI355X (no CPU fallback)")
+        self.cfg, self.config = cfg, _Config(cfg)
+        self.B, self.H, self.W, self.L = batch, height or cfg.sample_size, width or cfg.sample_size, ctx_len
+        self.in_channels = cfg.in_channels
+        self.dtype = torch.bfloat16
+        self.device = torch.device("cuda", torch.cuda.current_device())
+        self._h = ctypes.c_void_p()
+        c = _cfg.to_c(cfg)
+        check(lib().pea_controlnet_create(ctypes.byref(c), self.B, self.H, self.W, self.L, ctypes.byref(self._h)))
+        self._cond_key = None
+
+    __del__ = HipUNet.__del__
+    weight_table = HipUNet.weight_table
+    load_state_dict = HipUNet.load_state_dict
+    memory = HipUNet.memory
+
+    def init_random(self, seed: int = 0):
+        check(lib().pea_unet_init_random(self._h, seed, stream_ptr()))
+
+    def output_shapes(self):
+        out = []
+        for i in range(lib().pea_controlnet_num_outputs(self._h)):
+            c, h, w = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+            check(lib().pea_controlnet_output(self._h, i, None, ctypes.byref(c), ctypes.byref(h), ctypes.byref(w)))
+            out.append((c.value, h.value, w.value))
+        return out
+
+    def set_cond(self, image: torch.Tensor):
+        """controlnet_cond: [B, 3, 8H, 8W] (the prepared canny image, values in [0, 1])"""
+        if tuple(image.shape) != (self.B, 3, 8 * self.H, 8 * self.W):
+            raise PeaError(f"controlnet_cond {tuple(image.shape)} != {(self.B, 3, 8 * self.H, 8 * self.W)}")
+        key = (image.data_ptr(), image._version, tuple(image.shape), image.dtype)
+        if key == self._cond_key:
+            return
+        img = image.detach().to(self.device, torch.float32).contiguous()
+        check(lib().pea_controlnet_set_cond(self._h, ptr(img), stream_ptr()))
+        torch.cuda.current_stream().synchronize()       # `img` may be a temporary
+        self._cond_key = key
+
+    def run(self, sample, timestep, encoder_hidden_states, controlnet_cond, added_cond_kwargs=None):
+        """forward pass; results stay on the device inside the context (see `feed` / `outputs`)"""
+        self.set_cond(controlnet_cond)
+        B = sample.shape[0]
+        if tuple(sample.shape) != (self.B, self.in_channels, self.H, self.W):
+            raise PeaError(f"HipControlNet built for {(self.B, self.in_channels, self.H, self.W)}, got {tuple(sample.shape)}")
+        x = sample.detach().to(self.device, torch.float32).contiguous()
+        t = timestep if torch.is_tensor(timestep) else torch.tensor([timestep])
+        t = t.to(self.device, torch.float32).reshape(-1).expand(B).contiguous()
+        ehs = encoder_hidden_states.detach().to(self.device)
+        if tuple(ehs.shape) != (self.B, self.L, self.cfg.cross_attention_dim):
+            raise PeaError(f"encoder_hidden_states {tuple(ehs.shape)} != {(self.B, self.L, self.cfg.cross_attention_dim)}")
+        e_dt = 1 if ehs.dtype == torch.bfloat16 else 0
+        ehs = ehs.contiguous() if e_dt else ehs.float().contiguous()
+        text = tid = None
+        t_dt = 0
+        if self.cfg.addition_embed_type == "text_time":
+            text = added_cond_kwargs["text_embeds"].detach().to(self.device)
+            t_dt = 1 if text.dtype == torch.bfloat16 else 0
+            text = text.contiguous() if t_dt else text.float().contiguous()
+            tid = added_cond_kwargs["time_ids"].detach().to(self.device, torch.float32).contiguous()
+        check(lib().pea_controlnet_forward(self._h, ptr(x), ptr(t), ptr(ehs), e_dt, ptr(text), t_dt, ptr(tid),
+                                           stream_ptr()))
+        self._keep = (x, t, ehs, text, tid)
+
+    def outputs(self, conditioning_scale: float = 1.0):
+        """(down_block_res_samples, mid_block_res_sample) as fp32 NCHW torch tensors, as diffusers returns them"""
+        outs = []
+        for i, (c, h, w) in enumerate(self.output_shapes()):
+            o = torch.empty(self.B, c, h, w, device=self.device, dtype=torch.float32)
+            check(lib().pea_controlnet_export_nchw(self._h, i, ptr(o), stream_ptr()))
+            outs.append(o * conditioning_scale if conditioning_scale != 1.0 else o)
+        return outs[:-1], outs[-1]
+
+    def feed(self, unet: HipUNet, conditioning_scale: float = 1.0):
+        """residuals -> `unet`'s residual inputs, device to device (bf16 NHWC, scaled on import); they stay in effect
+        for the following `unet(...)` calls until fed again or `unet.clear_residuals()`"""
+        n = lib().pea_controlnet_num_outputs(self._h)
+        ptrs = (ctypes.c_void_p * n)()
+        for i in range(n):
+            p = ctypes.c_void_p()
+            check(lib().pea_controlnet_output(self._h, i, ctypes.byref(p), None, None, None))
+            ptrs[i] = p.value
+        check(lib().pea_unet_set_residuals(unet._h, n, ptrs, 2, float(conditioning_scale), stream_ptr()))
+        unet._residuals_set = False      # fed residuals persist over kwargs-free calls until `unet.clear_residuals()`
+
+    def __call__(self, sample, timestep, encoder_hidden_states, controlnet_cond, conditioning_scale: float = 1.0,
+                 guess_mode: bool = False, added_cond_kwargs=None, return_dict: bool = False):
+        if guess_mode:
+            raise NotImplementedError("guess_mode (reference default False, tests/test_sdxl_zh_controlnet.py:376)")
+        self.run(sample, timestep, encoder_hidden_states, controlnet_cond, added_cond_kwargs)
+        return self.outputs(float(conditioning_scale))

@@ -43,6 +43,77 @@ int pea_unet_create(const pea_unet_config* cfg, int B, int H, int W, int L, int 
   *out = u;
   return PEA_OK;
 }
+int pea_controlnet_create(const pea_unet_config* cfg, int B, int H, int W, int L, void** out) {
+  NOTNULL(cfg, "pea_controlnet_create");
+  NOTNULL(out, "pea_controlnet_create");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
+    pea_set_error("pea_controlnet_create: no HIP device (there is no CPU fallback)");
+    return PEA_E_HIP;
+  }
+  Unet* u = new Unet();
+  memcpy(&u->cfg, cfg, sizeof(PeaUnetCfg));
+  u->graph = 2;
+  u->B = B; u->H = H; u->W = W; u->L = L; u->needs_grad = false; u->owns_weights = true;
+  int rc = u->build();
+  if (rc == PEA_OK) rc = u->alloc();
+  if (rc != PEA_OK) {
+    delete u;
+    return rc;
+  }
+  *out = u;
+  return PEA_OK;
+}
+#define CN_HANDLE(h, what)                                                        \
+  NOTNULL(h, what);                                                               \
+  Unet* u = (Unet*)h;                                                             \
+  if (u->graph != 2) { pea_set_error("%s: not a ControlNet handle", what); return PEA_E_INVALID; }
+int pea_controlnet_set_cond(void* h, const float* image, void* stream) {
+  CN_HANDLE(h, "pea_controlnet_set_cond");
+  NOTNULL(image, "pea_controlnet_set_cond");
+  std::string miss;
+  if (!u->all_loaded(&miss)) {
+    pea_set_error("controlnet: weight '%s' was never loaded", miss.c_str());
+    return PEA_E_STATE;
+  }
+  u->cond_in = image;
+  u->ce_valid = false;
+  int rc = u->exec_ops(u->ce_begin, u->ce_end, false, (hipStream_t)stream);
+  if (rc != PEA_OK) return rc;
+  u->ce_valid = true;
+  u->cond_in = nullptr;            // the image is consumed here; the embedding stays valid until the next set_cond
+  return PEA_OK;
+}
+int pea_controlnet_forward(void* h, const float* x, const float* t, const void* ehs, int ehs_dtype, const void* text,
+                           int text_dtype, const float* time_ids, void* stream) {
+  CN_HANDLE(h, "pea_controlnet_forward");
+  if (!u->ce_valid) { pea_set_error("pea_controlnet_forward: call pea_controlnet_set_cond first"); return PEA_E_STATE; }
+  return u->forward(x, t, ehs, ehs_dtype, text, text_dtype, time_ids, nullptr, (hipStream_t)stream);
+}
+int pea_controlnet_num_outputs(void* h) { return h ? (int)((Unet*)h)->cn_out.size() : 0; }
+int pea_controlnet_output(void* h, int i, void** ptr, int* C, int* H, int* W) {
+  CN_HANDLE(h, "pea_controlnet_output");
+  if (i < 0 || i >= (int)u->cn_out.size()) {
+    pea_set_error("pea_controlnet_output: index %d out of range (%d outputs)", i, (int)u->cn_out.size());
+    return PEA_E_INVALID;
+  }
+  const Tn& t = u->tn[u->cn_out[i]];
+  if (ptr) *ptr = t.d;
+  if (C) *C = t.cols;
+  if (H) *H = t.H;
+  if (W) *W = t.W;
+  return PEA_OK;
+}
+int pea_controlnet_export_nchw(void* h, int i, float* dst, void* stream) {
+  CN_HANDLE(h, "pea_controlnet_export_nchw");
+  NOTNULL(dst, "pea_controlnet_export_nchw");
+  if (i < 0 || i >= (int)u->cn_out.size()) {
+    pea_set_error("pea_controlnet_export_nchw: index %d out of range", i);
+    return PEA_E_INVALID;
+  }
+  const Tn& t = u->tn[u->cn_out[i]];
+  return launch_nhwc_to_nchw_f32(t.d, dst, u->B, t.H * t.W, t.cols, (hipStream_t)stream);
+}
 int pea_vae_encoder_create(const pea_unet_config* cfg, int B, int H, int W, void** out) {
   NOTNULL(cfg, "pea_vae_encoder_create");
   NOTNULL(out, "pea_vae_encoder_create");

@@ -250,29 +250,31 @@ int launch_nhwc_to_nchw_f32(const bf16* x, float* y, int B, int HW, int C, hipSt
 // w [Co][Ci][3][3] fp32 -> mode 0: y[co][(ky*3+kx)*Ci + ci]; mode 1: y[ci][((2-ky)*3+(2-kx))*Co + co] (bf16)
 // mode 2: y[co][ky][kx][ci] fp32
 __global__ void pack_conv_kernel(const float* __restrict__ w, bf16* __restrict__ yb, float* __restrict__ yf, int Co,
-                                 int Ci, int mode) {
+                                 int Ci, int mode, int Cip) {
   const long long total = (long long)Co * Ci * 9;
   EW_LOOP(i, total) {
     const int kx = (int)(i % 3), ky = (int)((i / 3) % 3);
     const int ci = (int)((i / 9) % Ci), co = (int)(i / (9LL * Ci));
     const float v = w[i];
-    if (mode == 0) yb[(long long)co * 9 * Ci + (ky * 3 + kx) * Ci + ci] = (bf16)v;
+    if (mode == 0) yb[(long long)co * 9 * Cip + (ky * 3 + kx) * Cip + ci] = (bf16)v;
     else if (mode == 1) yb[(long long)ci * 9 * Co + ((2 - ky) * 3 + (2 - kx)) * Co + co] = (bf16)v;
     else yf[(long long)co * 9 * Ci + (ky * 3 + kx) * Ci + ci] = v;
   }
 }
-int launch_pack_conv_fwd(const float* w, bf16* y, int Co, int Ci, hipStream_t s) {
-  hipLaunchKernelGGL(pack_conv_kernel, dim3(EW_GRID(9LL * Co * Ci)), dim3(256), 0, s, w, y, nullptr, Co, Ci, 0);
+int launch_pack_conv_fwd(const float* w, bf16* y, int Co, int Ci, hipStream_t s, int Cip) {
+  if (Cip <= 0) Cip = Ci;
+  if (Cip != Ci) HIPCHK(hipMemsetAsync(y, 0, (size_t)Co * 9 * Cip * 2, s));      // zero-padded input channels
+  hipLaunchKernelGGL(pack_conv_kernel, dim3(EW_GRID(9LL * Co * Ci)), dim3(256), 0, s, w, y, nullptr, Co, Ci, 0, Cip);
   HIPCHK(hipGetLastError());
   return PEA_OK;
 }
 int launch_pack_conv_dgrad(const float* w, bf16* y, int Co, int Ci, hipStream_t s) {
-  hipLaunchKernelGGL(pack_conv_kernel, dim3(EW_GRID(9LL * Co * Ci)), dim3(256), 0, s, w, y, nullptr, Co, Ci, 1);
+  hipLaunchKernelGGL(pack_conv_kernel, dim3(EW_GRID(9LL * Co * Ci)), dim3(256), 0, s, w, y, nullptr, Co, Ci, 1, Ci);
   HIPCHK(hipGetLastError());
   return PEA_OK;
 }
 int launch_pack_conv_out(const float* w, float* y, int Co, int Ci, hipStream_t s) {
-  hipLaunchKernelGGL(pack_conv_kernel, dim3(EW_GRID(9LL * Co * Ci)), dim3(256), 0, s, w, nullptr, y, Co, Ci, 2);
+  hipLaunchKernelGGL(pack_conv_kernel, dim3(EW_GRID(9LL * Co * Ci)), dim3(256), 0, s, w, nullptr, y, Co, Ci, 2, Ci);
   HIPCHK(hipGetLastError());
   return PEA_OK;
 }

@@ -1209,7 +1209,8 @@ int launch_gemm(const GemmP& p_in, hipStream_t stream) {
 // walks pixels; the 36 input taps are read once per pixel (L1-shared by the threads of that pixel).
 __global__ __launch_bounds__(256) void conv_in_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                       const float* __restrict__ bias, bf16* __restrict__ y, int B,
-                                                      int Cin, int H, int W, int Cout, int pix_per_block) {
+                                                      int Cin, int H, int W, int Cout, int pix_per_block, int ldy,
+                                                      int silu) {
   extern __shared__ __attribute__((aligned(16))) char cism[];
   float* wl = (float*)cism;                       // [Cin*9][Cout]
   const int K = Cin * 9;
@@ -1254,20 +1255,21 @@ __global__ __launch_bounds__(256) void conv_in_kernel(const float* __restrict__ 
       }
     bf16x8 o;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) o[j] = (bf16)acc[j];
-    *(bf16x8*)(y + pix * Cout + c0) = o;
+    for (int j = 0; j < 8; ++j) o[j] = (bf16)(silu ? siluf_(acc[j]) : acc[j]);
+    *(bf16x8*)(y + pix * ldy + c0) = o;
   }
 }
 
 int launch_conv_in(const float* x, const float* w, const float* bias, bf16* y, int B, int Cin, int H, int W,
-                   int Cout, hipStream_t s) {
+                   int Cout, hipStream_t s, int ldy, int silu) {
+  if (ldy <= 0) ldy = Cout;
   SHAPECHK(Cout % 8 == 0 && Cout / 8 <= 256 && Cin * 9 * Cout * 4 <= 64 * 1024, "conv_in: Cout=%d Cin=%d", Cout, Cin);
   const int nchunk = Cout / 8;
   const int ppb = 256 / nchunk;
   const int per = ppb * 8;
   const long long npix = (long long)B * H * W;
   hipLaunchKernelGGL(conv_in_kernel, dim3((unsigned)cdivl(npix, per)), dim3(256), (size_t)Cin * 9 * Cout * 4, s, x, w,
-                     bias, y, B, Cin, H, W, Cout, per);
+                     bias, y, B, Cin, H, W, Cout, per, ldy, silu);
   HIPCHK(hipGetLastError());
   return PEA_OK;
 }

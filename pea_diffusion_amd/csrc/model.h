@@ -62,6 +62,7 @@ struct Tn {
   int B = 0, H = 0, W = 0;
   bf16* d = nullptr; bf16* g = nullptr;
   bool rg = false;           // requires grad
+  bool zero_init = false;    // channel-padded tensor: the padding columns are never written and must read as zeros
   bool gw = false;           // gradient already written in the current backward pass
   const bf16* gpend = nullptr;   // gradient passed on by a residual, not yet added into g (Unet::backward)
   size_t off_d = 0, off_g = 0;
@@ -90,7 +91,12 @@ struct Unet {
   PeaUnetCfg cfg;
   int B, H, W, L;                 // batch, latent H/W, context length
   bool needs_grad;
-  int graph = 0;                     // 0: UNet2DConditionModel, 1: AutoencoderKL encoder (VAE, inference only)
+  int graph = 0;                     // 0: UNet2DConditionModel, 1: AutoencoderKL encoder (VAE), 2: ControlNetModel (1, 2: inference only)
+  std::vector<int> cn_out;           // ControlNet: output tensors (down residuals in diffusers order, mid last)
+  int ce_begin = -1, ce_end = -1;    // ControlNet: op range of the conditioning embedding (constant over a generation)
+  bool ce_valid = false;             // ... already computed for the current conditioning image
+  const float* cond_in = nullptr;    // ControlNet: conditioning image fp32 [B][3][8H][8W]
+  int cond_scale_f = 8;
   int w_quant = -1, b_quant = -1;    // VAE: quant_conv (1x1) slots
   bf16* am_scores = nullptr;         // VAE mid attention: materialised [HW][HW] scores of one image, V^T of one image
   bf16* am_vt = nullptr;
@@ -121,6 +127,7 @@ struct Unet {
 
   int build();
   int build_vae_encoder();
+  int exec_ops(size_t begin, size_t end, bool skip_cached, hipStream_t s);
   int alloc();
   int load_weight(const char* name, const float* dev_ptr, long long numel, hipStream_t s);
   int init_random(unsigned long long seed, hipStream_t s);

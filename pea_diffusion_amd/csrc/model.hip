@@ -125,6 +125,20 @@ struct Builder {
     o.a = x; o.w = w; o.bias = b; o.out = out; o.p0 = stride; o.p1 = ups; o.rv = rv; o.rv_off = rv_off; o.res = res;
     return out;
   }
+  // 3x3 conv whose input tensor is stored wider than the layer's real Cin (zero-padded channels, so the implicit GEMM's
+  // K = 9 * stored width stays a multiple of 64) and whose output goes into a tensor `width` >= Cout columns wide
+  int conv_padded(int x, const std::string& pfx, int cin_real, int Cout, int width, int stride, int act, int res = -1) {
+    const Tn t = u.tn[x];
+    const int Ho = stride == 2 ? (t.H + 1) / 2 : t.H, Wo = stride == 2 ? (t.W + 1) / 2 : t.W;
+    const int w = conv3(pfx + ".weight", Cout, cin_real);
+    u.slots[w].pad_dp = t.cols;
+    const int b = vec(pfx + ".bias", Cout);
+    const int out = T((long long)t.B * Ho * Wo, width, t.B, Ho, Wo);
+    u.tn[out].zero_init = width != Cout;
+    Op& o = push(OP_CONV3);
+    o.a = x; o.w = w; o.bias = b; o.out = out; o.p0 = stride; o.p3 = act; o.res = res;
+    return out;
+  }
   // AutoencoderKL pieces (diffusers 0.23 [ext]; call site train_sdxl_zh.py:306-309)
   int resnet_plain(int x, const std::string& pfx, int cout) {          // ResnetBlock2D with temb_channels=None
     const int cin = u.tn[x].cols;
@@ -224,7 +238,7 @@ struct Builder {
 
 // (prefix, C) of every BasicTransformerBlock in creation order (to build the stacked K|V projection)
 struct CrossAttnInfo { std::string pfx; int C, heads; };
-std::vector<CrossAttnInfo> enumerate_cross_attn(const PeaUnetCfg& c) {
+std::vector<CrossAttnInfo> enumerate_cross_attn(const PeaUnetCfg& c, bool include_up = true) {
   std::vector<CrossAttnInfo> r;
   const int n = c.n_levels;
   int cur_heads = 0;
@@ -239,7 +253,7 @@ std::vector<CrossAttnInfo> enumerate_cross_attn(const PeaUnetCfg& c) {
       }
   cur_heads = c.heads[n - 1];
   add("mid_block.attentions.0", c.block_out[n - 1], c.depth[n - 1]);
-  for (int i = 0; i < n; ++i)
+  for (int i = 0; i < n && include_up; ++i)
     if (c.up_cross[i])
       for (int j = 0; j < c.layers_per_block + 1; ++j) {
         cur_heads = c.heads[n - 1 - i];
@@ -250,7 +264,7 @@ std::vector<CrossAttnInfo> enumerate_cross_attn(const PeaUnetCfg& c) {
 }
 
 // cout of every ResnetBlock2D in creation order (to size the fused time_emb_proj matrix)
-std::vector<std::pair<std::string, int>> enumerate_resnets(const PeaUnetCfg& c) {
+std::vector<std::pair<std::string, int>> enumerate_resnets(const PeaUnetCfg& c, bool include_up = true) {
   std::vector<std::pair<std::string, int>> r;
   const int n = c.n_levels;
   for (int i = 0; i < n; ++i)
@@ -258,7 +272,7 @@ std::vector<std::pair<std::string, int>> enumerate_resnets(const PeaUnetCfg& c) 
       r.push_back({"down_blocks." + std::to_string(i) + ".resnets." + std::to_string(j), c.block_out[i]});
   r.push_back({"mid_block.resnets.0", c.block_out[n - 1]});
   r.push_back({"mid_block.resnets.1", c.block_out[n - 1]});
-  for (int i = 0; i < n; ++i)
+  for (int i = 0; i < n && include_up; ++i)
     for (int j = 0; j < c.layers_per_block + 1; ++j)
       r.push_back({"up_blocks." + std::to_string(i) + ".resnets." + std::to_string(j), c.block_out[n - 1 - i]});
   return r;
@@ -347,7 +361,7 @@ int Unet::build() {
   }
   int semb = bd.silu(emb);
   {   // all ResnetBlock2D.time_emb_proj stacked into one GEMM over silu(emb)
-    auto rs = enumerate_resnets(c);
+    auto rs = enumerate_resnets(c, graph != 2);
     std::vector<std::string> names;
     std::vector<int> ns;
     for (auto& r : rs) { names.push_back(r.first + ".time_emb_proj"); ns.push_back(r.second); }
@@ -356,7 +370,7 @@ int Unet::build() {
     ops.back().p3 = 1;   // its gradient arrives through the fp32 column-sum scratch
   }
   {   // every attn2.to_k / attn2.to_v stacked into one GEMM over encoder_hidden_states
-    auto ca = enumerate_cross_attn(c);
+    auto ca = enumerate_cross_attn(c, graph != 2);
     std::vector<std::string> names;
     std::vector<int> ns, pd, pdp;
     for (auto& r : ca) {
@@ -376,6 +390,32 @@ int Unet::build() {
     o.out = x;
     o.w = bd.slot("conv_in.weight", W_CONV_IN, c.block_out[0], c.in_channels, 9LL * c.block_out[0] * c.in_channels);
     o.bias = bd.vec("conv_in.bias", c.block_out[0]);
+  }
+  if (graph == 2) {
+    // ControlNetConditioningEmbedding (diffusers 0.23 [ext]; call site tests/test_sdxl_zh_controlnet.py:510-519):
+    // conv_in 3->16 + SiLU, then (16->16, 16->32 /2, 32->32, 32->96 /2, 96->96, 96->256 /2) each + SiLU at 8x the latent
+    // resolution, then conv_out 256->block_out[0] added to conv_in(sample).  Widths are stored padded to 64 / 128.
+    SHAPECHK(!needs_grad && !residual_inputs, "controlnet: inference graph only");
+    SHAPECHK(c.n_levels == 3 || c.n_levels == 4, "controlnet: n_levels=%d", c.n_levels);
+    const int f = cond_scale_f;
+    static const int ch[4] = {16, 32, 96, 256}, wd[4] = {64, 64, 128, 256};
+    ce_begin = (int)ops.size();
+    int e = bd.T((long long)B * H * f * W * f, wd[0], B, H * f, W * f);
+    tn[e].zero_init = true;
+    {
+      Op& o = bd.push(OP_CONV_IN);
+      o.out = e; o.src = 1; o.p0 = ch[0]; o.p3 = 2;
+      o.w = bd.slot("controlnet_cond_embedding.conv_in.weight", W_CONV_IN, ch[0], 3, 9LL * ch[0] * 3);
+      o.bias = bd.vec("controlnet_cond_embedding.conv_in.bias", ch[0]);
+    }
+    for (int i = 0; i < 3; ++i) {
+      const std::string p = "controlnet_cond_embedding.blocks.";
+      e = bd.conv_padded(e, p + std::to_string(2 * i), ch[i], ch[i], wd[i], 1, 2);
+      e = bd.conv_padded(e, p + std::to_string(2 * i + 1), ch[i], ch[i + 1], wd[i + 1], 2, 2);
+    }
+    ce_end = (int)ops.size();
+    SHAPECHK(tn[e].H == H && tn[e].W == W, "controlnet: conditioning image must be 8x the latent size");
+    x = bd.conv_padded(e, "controlnet_cond_embedding.conv_out", ch[3], c.block_out[0], c.block_out[0], 1, 0, x);
   }
   std::vector<int> skips{x};
   const int n = c.n_levels;
@@ -412,6 +452,14 @@ int Unet::build() {
   x = bd.resnet(x, "mid_block.resnets.1", c.block_out[n - 1]);
   taps.push_back(x);
   if (residual_inputs) x = add_external(x);     // mid_block_additional_residual (:535)
+  if (graph == 2) {
+    // zero-convs: one 1x1 conv per skip tensor and one for the mid block; their outputs ARE the residuals
+    for (size_t k = 0; k < skips.size(); ++k)
+      cn_out.push_back(bd.linear(skips[k], "controlnet_down_blocks." + std::to_string(k), tn[skips[k]].cols, true));
+    cn_out.push_back(bd.linear(x, "controlnet_mid_block", tn[x].cols, true));
+    SHAPECHK(bd.kv_off == kvall_total, "controlnet: stacked K|V projection layout mismatch (%d vs %d)", bd.kv_off, kvall_total);
+    return PEA_OK;
+  }
   for (int i = 0; i < n; ++i) {
     const std::string p = "up_blocks." + std::to_string(i);
     const int lvl = n - 1 - i;
@@ -464,7 +512,8 @@ int Unet::alloc() {
       if (s.fused_parent >= 0) continue;
       if (s.kind == W_VEC || s.kind == W_CONV_IN || s.kind == W_CONV_OUT) { s.off_f32 = off; off += al256(s.numel * 4); }
       else {
-        const size_t st = s.kind == W_LINEAR ? (size_t)s.st_n * s.st_k : (size_t)s.numel;
+        const size_t st = s.kind == W_LINEAR ? (size_t)s.st_n * s.st_k
+                          : (s.kind == W_CONV3 && s.pad_dp ? (size_t)s.d0 * 9 * s.pad_dp : (size_t)s.numel);
         s.off_w = off; off += al256(st * 2);
         if (s.need_wt) { s.off_wt = off; off += al256(st * 2); }
       }
@@ -489,7 +538,7 @@ int Unet::alloc() {
       if (s.off_f32 != (size_t)-1) s.f32 = (float*)(warena + s.off_f32);
       if (s.off_w != (size_t)-1) {
         s.w = (bf16*)(warena + s.off_w);
-        s.ldw = s.kind == W_CONV3 ? 9 * s.d1 : s.st_k;
+        s.ldw = s.kind == W_CONV3 ? 9 * (s.pad_dp ? s.pad_dp : s.d1) : s.st_k;
       }
       if (s.off_wt != (size_t)-1) {
         s.wt = (bf16*)(warena + s.off_wt);
@@ -517,6 +566,8 @@ int Unet::alloc() {
   for (Op& o : ops)
     if (o.aux_bytes) o.aux = (float*)(aarena + o.aux_off);
   for (int e : ext_res) HIPCHK(hipMemset(tn[e].d, 0, (size_t)tn[e].rows * tn[e].cols * 2));   // "no residual" = zeros
+  for (Tn& t : tn)
+    if (t.zero_init) HIPCHK(hipMemset(t.d, 0, (size_t)t.rows * t.cols * 2));
   // ---- scratch
   size_t delta_elems = 0, ups_elems = 0, part_bytes = 0, geglu_elems = 0;
   for (Op& o : ops) {
@@ -606,7 +657,7 @@ int Unet::load_weight(const char* name, const float* src, long long numel, hipSt
       }
       break;
     case W_CONV3:
-      RC(launch_pack_conv_fwd(src, w.w, w.d0, w.d1, s));
+      RC(launch_pack_conv_fwd(src, w.w, w.d0, w.d1, s, w.pad_dp));
       if (w.wt) RC(launch_pack_conv_dgrad(src, w.wt, w.d0, w.d1, s));
       break;
   }
@@ -670,7 +721,7 @@ int Unet::forward(const float* x, const float* t, const void* ehs, int ehs_dtype
     return PEA_E_STATE;
   }
   x_in = x; t_in = t; tid_in = time_ids; eps_out = eps;
-  if (graph == 0) {
+  if (graph != 1) {
     Tn& e = tn[t_ehs];
     const long long n = e.rows * e.cols;
     if ((const void*)e.d != ehs) {
@@ -687,7 +738,16 @@ int Unet::forward(const float* x, const float* t, const void* ehs, int ehs_dtype
       }
     }
   }
-  for (Op& o : ops) {
+  RC(exec_ops(0, ops.size(), true, s));
+  if (graph == 2) ce_valid = true;
+  return PEA_OK;
+}
+
+// ops [begin, end) of the tape in order; skip_cached: leave out the ControlNet conditioning embedding when it is valid
+int Unet::exec_ops(size_t begin, size_t end, bool skip_cached, hipStream_t s) {
+  for (size_t oi = begin; oi < end; ++oi) {
+    Op& o = ops[oi];
+    if (skip_cached && ce_valid && (int)oi >= ce_begin && (int)oi < ce_end) continue;   // cached conditioning embedding
     switch (o.kind) {
       case OP_TEMB: {
         Tn& out = tn[o.out];
@@ -736,6 +796,12 @@ int Unet::forward(const float* x, const float* t, const void* ehs, int ehs_dtype
         RC(launch_concat2(tn[o.a].d, tn[o.a].cols, tn[o.b].d, tn[o.b].cols, tn[o.out].d, tn[o.a].rows, s));
         break;
       case OP_CONV_IN:
+        if (o.src == 1) {              // ControlNet conditioning image -> first (channel-padded) embedding tensor
+          SHAPECHK(cond_in != nullptr, "controlnet: no conditioning image set");
+          RC(launch_conv_in(cond_in, slots[o.w].f32, slots[o.bias].f32, tn[o.out].d, B, 3, tn[o.out].H, tn[o.out].W,
+                            o.p0, s, tn[o.out].cols, o.p3 == 2));
+          break;
+        }
         RC(launch_conv_in(x_in, slots[o.w].f32, slots[o.bias].f32, tn[o.out].d, B, cfg.in_channels, H, W,
                           tn[o.out].cols, s));
         break;
@@ -744,7 +810,8 @@ int Unet::forward(const float* x, const float* t, const void* ehs, int ehs_dtype
         GemmP p; fill_gemm(p);
         p.mode = 1; p.A = a.d; p.W = slots[o.w].w; p.ldw = slots[o.w].ldw; p.C = out.d; p.ldc = out.cols;
         p.Hs = a.H; p.Ws = a.W; p.Cin = a.cols; p.Ho = out.H; p.Wo = out.W; p.stride = o.p0; p.shift = o.p1 ? 1 : 0;
-        p.M = (int)out.rows; p.N = out.cols; p.K = 9 * a.cols; p.bias = slots[o.bias].f32; p.zeros = zeros;
+        p.M = (int)out.rows; p.N = slots[o.w].d0; p.K = 9 * a.cols; p.bias = slots[o.bias].f32; p.zeros = zeros;
+        p.act = o.p3;
         p.rows_per_batch = out.H * out.W; p.pad_off = o.p2;
         if (o.rv >= 0) { p.rowvec = tn[o.rv].d + o.rv_off; p.ldrv = tn[o.rv].cols; }
         if (o.res >= 0) { p.res = tn[o.res].d; p.ldres = tn[o.res].cols; }

@@ -41,7 +41,7 @@ int launch_gemm(const GemmP& p, hipStream_t stream);
 // direct (non-MFMA) 3x3 convs for the 4-channel ends of the UNet
 // conv_in:  x NCHW fp32 [B][Cin][H][W] -> y NHWC bf16 [B][H][W][Cout];  w [Cout][Cin][3][3] fp32
 int launch_conv_in(const float* x, const float* w, const float* bias, bf16* y, int B, int Cin, int H, int W,
-                   int Cout, hipStream_t s);
+                   int Cout, hipStream_t s, int ldy = 0, int silu = 0);   // ldy: output row stride (0 = Cout)
 // conv_out: x NHWC bf16 [B][H][W][Cin] -> y NCHW fp32 [B][Cout][H][W];  w [Cout][3][3][Cin] fp32
 int launch_conv_out(const bf16* x, const float* w, const float* bias, float* y, int B, int Cin, int H, int W,
                     int Cout, hipStream_t s);
@@ -107,7 +107,7 @@ int launch_transpose_bf16(const bf16* x, bf16* y, int R, int C, int ldy, hipStre
 int launch_transpose_f32_bf16(const float* x, bf16* y, int R, int C, int ldy, hipStream_t s);
 int launch_nhwc_to_nchw_f32(const bf16* x, float* y, int B, int HW, int C, hipStream_t s);
 // conv weight repacks (fp32 torch layout [Co][Ci][3][3]) -> bf16
-int launch_pack_conv_fwd(const float* w, bf16* y, int Co, int Ci, hipStream_t s);          // y[co][(ky,kx,ci)]
+int launch_pack_conv_fwd(const float* w, bf16* y, int Co, int Ci, hipStream_t s, int Cip = 0);   // Cip: stored (zero-padded) Ci          // y[co][(ky,kx,ci)]
 int launch_pack_conv_dgrad(const float* w, bf16* y, int Co, int Ci, hipStream_t s);        // y[ci][(2-ky,2-kx,co)]
 int launch_pack_conv_out(const float* w, float* y, int Co, int Ci, hipStream_t s);         // y[co][ky][kx][ci] fp32
 // sinusoidal timestep embedding (cos|sin), out bf16 [n][dim]; t given as fp32 values

@@ -201,6 +201,9 @@ class HipUNet:
         self._keep_res = keep
         self._residuals_set = any(t is not None for t in items)
 
+    def clear_residuals(self):
+        self.set_additional_residuals(None, None)
+
     def tap(self, k: int, grad: bool = False) -> torch.Tensor:
         """feature tap k (cast_hook order) as an NCHW fp32 tensor"""
         B, H, W, C = ctypes.c_int(), ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
