@@ -98,3 +98,41 @@ def test_controlnet_denoise_loop_vs_oracle(gpu):
     e2 = rel_l2(got2, want)
     print(f"[controlnet denoise loop tiny, fed device-to-device] latents rel_l2={e2:.3e}")
     assert e2 < 3e-2
+
+
+def test_sdxl_controlnet_full_size_steps(gpu):
+    """BASELINE config 5 at full size: SDXL UNet + ControlNet, 1024x1024, one image with CFG (batch 2), 3 DPM-Solver++
+    steps on random-init weights: finite latents, bit-reproducible, and the ControlNet changes the result."""
+    from pea_diffusion_amd import config as pc
+    from pea_diffusion_amd.controlnet import HipControlNet
+    from pea_diffusion_amd.sampler import DPMSolverMultistep, denoise
+    from pea_diffusion_amd.unet import HipUNet
+    cfg = pc.sdxl_config()
+    unet = HipUNet(cfg, 2, 128, 128, 77, residual_inputs=True)
+    unet.init_random(1)
+    cn = HipControlNet(cfg, 2, 128, 128, 77)
+    cn.init_random(2)
+    assert cn.output_shapes() == [(320, 128, 128)] * 3 + [(320, 64, 64)] + [(640, 64, 64)] * 2 + [(640, 32, 32)] + [(1280, 32, 32)] * 3
+    assert cn.output_shapes() == unet.residual_shapes()
+    g = torch.Generator().manual_seed(0)
+    lat = torch.randn(1, 4, 128, 128, generator=g).cuda()
+    ehs = torch.randn(2, 77, 2048, generator=g).cuda().to(torch.bfloat16)
+    added = {"text_embeds": torch.randn(2, 1280, generator=g).cuda().to(torch.bfloat16),
+             "time_ids": torch.tensor([[1024, 1024, 0, 0, 1024, 1024]] * 2).cuda()}
+    img = torch.cat([(torch.rand(1, 3, 1024, 1024, generator=g) > 0.9).float()] * 2).cuda()
+
+    class Pipe:
+        use_cn = True
+        def __call__(self, x, t, encoder_hidden_states=None, added_cond_kwargs=None, return_dict=False):
+            if self.use_cn:
+                cn.run(x, t, encoder_hidden_states, img, added_cond_kwargs)
+                cn.feed(unet, 1.0)
+            return unet(x, t, encoder_hidden_states=encoder_hidden_states, added_cond_kwargs=added_cond_kwargs)
+    p = Pipe()
+    a = denoise(p, DPMSolverMultistep(), lat.clone(), ehs, added, num_inference_steps=3, guidance_scale=5.0)
+    b = denoise(p, DPMSolverMultistep(), lat.clone(), ehs, added, num_inference_steps=3, guidance_scale=5.0)
+    assert a.shape == (1, 4, 128, 128) and torch.isfinite(a).all() and torch.equal(a, b)
+    unet.clear_residuals()
+    p.use_cn = False
+    c = denoise(p, DPMSolverMultistep(), lat.clone(), ehs, added, num_inference_steps=3, guidance_scale=5.0)
+    assert torch.isfinite(c).all() and not torch.equal(a, c)
