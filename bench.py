@@ -148,6 +148,8 @@ def main():
     ap.add_argument("--force-collective", action="store_true", help="init RCCL and all-reduce even with one rank (path test)")
     ap.add_argument("--dump-prof", default="", help="write every profiled launch (shape-tagged) to this CSV")
     ap.add_argument("--breakdown", action="store_true", help="print the per-kernel-family table to stderr")
+    ap.add_argument("--student", default="same", choices=["same", "ssd1b"],
+                    help="BASELINE config 4: a smaller student UNet (SSD-1B-shaped, own weights) under the SDXL teacher")
     ap.add_argument("--with-vae", action="store_true",
                     help="also run the NEXT batch's VAE encode (train_sdxl_zh.py:306-309, 1024x1024 pixels) on a side "
                          "HIP stream inside every step; not the default: BASELINE's metric starts from latents (SURVEY 8d)")
@@ -188,9 +190,15 @@ def main():
     B = args.batch
     enc_dim = 1024 if args.model == "sdxl" else 128
     hidden = args.hidden if args.model == "sdxl" else 192
-    student = HipUNet(cfg, B, hw, hw, args.ctx, needs_grad=True)
-    student.init_random(seed=7)
-    teacher = HipUNet(cfg, B, hw, hw, 77, needs_grad=False, share_weights_from=student)
+    if args.student == "ssd1b" and args.model == "sdxl":
+        student = HipUNet(pc.ssd1b_config(), B, hw, hw, args.ctx, needs_grad=True)
+        student.init_random(seed=7)
+        teacher = HipUNet(cfg, B, hw, hw, 77, needs_grad=False)
+        teacher.init_random(seed=8)
+    else:
+        student = HipUNet(cfg, B, hw, hw, args.ctx, needs_grad=True)
+        student.init_random(seed=7)
+        teacher = HipUNet(cfg, B, hw, hw, 77, needs_grad=False, share_weights_from=student)
     torch.manual_seed(7)
     adapter = PEAAdapter(enc_dim, cfg.pooled_dim, hidden, cfg.cross_attention_dim, False).to(dev)
     trainer = PEATrainer(adapter, student, teacher)
@@ -308,13 +316,15 @@ def main():
                                    f"fwd + student dgrad bwd + adapter fwd/bwd + AdamW), per-GPU batch {B}",
                        "global_batch": world * B, "per_gpu_batch": B, "latent": hw, "ctx_len": args.ctx,
                        "adapter": f"MLP({enc_dim},{cfg.pooled_dim},{hidden},{cfg.cross_attention_dim})",
-                       "parallelism": f"dp{world}", "weights": "random init (teacher == student checkpoint)",
+                       "parallelism": f"dp{world}",
+                       "weights": ("random init (teacher == student checkpoint)" if args.student == "same" else
+                                   "random init, SSD-1B-shaped student (transformer depths 1/2/4) under the SDXL teacher"),
                        "loss": round(loss, 6),
                        **({"vae_encode": f"next batch's {hw * 8}x{hw * 8} VAE encode on a side HIP stream inside every step"}
                           if args.with_vae else {})},
-            "tflop_per_image": TFLOP_PER_IMAGE.get(args.model),
+            "tflop_per_image": TFLOP_PER_IMAGE.get(args.model) if args.student == "same" else None,
             "achieved_tflops_per_gpu": (round(ips / world * TFLOP_PER_IMAGE[args.model], 1)
-                                        if TFLOP_PER_IMAGE.get(args.model) else None),
+                                        if TFLOP_PER_IMAGE.get(args.model) and args.student == "same" else None),
             "hbm_resident_gb": round((mem["weight_bytes"] + 2 * mem["activation_bytes"] + mem["grad_bytes"]) / 2 ** 30, 1),
             "roofline": roof, "cpu_baseline": cpu,
         }
