@@ -14,6 +14,8 @@
 // of one output row -> 8-byte packed bf16 stores and vector bias/residual loads.
 // Workgroup ids are remapped XCD-aware (blocks b, b+8 share an L2) and grouped 8 M-tiles
 // per N-tile so the 64 tiles resident on one XCD share operand panels.
+#include <stdlib.h>
+
 #include "pea_kernels.h"
 
 #define BK 64
@@ -197,56 +199,84 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmP& p, f32x16 (&acc)[
 }
 
 // ---- epilogue for the 16x16x32 accumulator layout: acc[nt][mt][j] = D[n = 4*(lane>>4) + j][m = lane&15]
-template <int MT, int NT>
+template <int MT, int NT, int M0 = 0, int M1 = MT>
 __device__ __forceinline__ void gemm_epilogue16(const GemmP& p, f32x4 (&acc)[NT][MT], int m_base, int n_base, int r16,
                                                 int q4) {
+  // everything of the epilogue except the final store of C; false: nothing to store (GEGLU without the stash)
+  auto value = [&](int mt, int nt, int m, int bidx, float (&v)[4]) -> bool {
+    const int n = n_base + nt * 16 + 4 * q4;
 #pragma unroll
-  for (int mt = 0; mt < MT; ++mt) {
+    for (int j = 0; j < 4; ++j) v[j] = acc[nt][mt][j] * p.alpha;
+    if (p.bias) {
+      const f32x4 b = *(const f32x4*)(p.bias + n);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] += b[j];
+    }
+    if (p.rowvec) {
+      const bf16x4 rv = *(const bf16x4*)(p.rowvec + (long long)bidx * p.ldrv + n);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] += (float)rv[j];
+    }
+    if (p.geglu_y) {            // v = (h_a, gate_a, h_b, gate_b) after bias
+      bf16x2 y;
+      y[0] = (bf16)(v[0] * gelu_erf(v[1]));
+      y[1] = (bf16)(v[2] * gelu_erf(v[3]));
+      *(bf16x2*)(p.geglu_y + (long long)m * p.ldy + (n >> 1)) = y;
+      if (!p.C) return false;
+    }
+    if (p.preact) {
+      bf16x4 o;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) o[j] = (bf16)v[j];
+      *(bf16x4*)(p.preact + (long long)m * p.ldpre + n) = o;
+    }
+    if (p.act == 1) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] = gelu_erf(v[j]);
+    } else if (p.act == 2) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] = siluf_(v[j]);
+    }
+    if (p.res) {
+      const bf16x4 rr = *(const bf16x4*)(p.res + (long long)m * p.ldres + n);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] += (float)rr[j];
+    }
+    return true;
+  };
+  const bool pairs_ok = !p.out_f32 && !(p.geglu_y && !p.C) && (p.ldc % 8 == 0) && (((unsigned long long)p.C & 15) == 0);
+#pragma unroll
+  for (int mt = M0; mt < M1; ++mt) {
     const int m = m_base + mt * 16 + r16;
-    if (m >= p.M) continue;
+    if (m >= p.M) continue;      // depends on r16 only: the four q4 lanes of a row leave together (swap partners)
     const int bidx = p.rowvec ? m / p.rows_per_batch : 0;
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
+      // Two adjacent n-tiles fully inside N: exchange 8-byte quads between the q4 lane rows (v_permlane16_swap) so
+      // every lane stores 16 contiguous bytes and a row's 64 bytes of the pair leave in ONE instruction -- half
+      // the cache lines touched per stored byte (the store tail of a tile is issue-bound, not bandwidth-bound).
+      if ((nt & 1) == 0 && nt + 1 < NT && pairs_ok && n_base + (nt + 2) * 16 <= p.N) {
+        float v0[4], v1[4];
+        value(mt, nt, m, bidx, v0);
+        value(mt, nt + 1, m, bidx, v1);
+        union { bf16x4 h; unsigned u[2]; } a, b;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { a.h[j] = (bf16)v0[j]; b.h[j] = (bf16)v1[j]; }
+        const auto lo = __builtin_amdgcn_permlane16_swap(a.u[0], b.u[0], false, false);
+        const auto hi = __builtin_amdgcn_permlane16_swap(a.u[1], b.u[1], false, false);
+        // row q4 now holds: {lo[0], hi[0]} = quad of lane row (q4 & ~1) and {lo[1], hi[1]} = quad of lane row (q4 | 1),
+        // both of n-tile nt + (q4 & 1)
+        typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+        const u32x4 o = {lo[0], hi[0], lo[1], hi[1]};
+        const int n = n_base + (nt + (q4 & 1)) * 16 + 8 * (q4 >> 1);
+        *(u32x4*)((bf16*)p.C + (long long)m * p.ldc + n) = o;
+        continue;
+      }
+      if ((nt & 1) == 1 && pairs_ok && n_base + (nt + 1) * 16 <= p.N) continue;   // stored with its left neighbour
       const int n = n_base + nt * 16 + 4 * q4;
       if (n >= p.N) continue;
       float v[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) v[j] = acc[nt][mt][j] * p.alpha;
-      if (p.bias) {
-        const f32x4 b = *(const f32x4*)(p.bias + n);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] += b[j];
-      }
-      if (p.rowvec) {
-        const bf16x4 rv = *(const bf16x4*)(p.rowvec + (long long)bidx * p.ldrv + n);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] += (float)rv[j];
-      }
-      if (p.geglu_y) {            // v = (h_a, gate_a, h_b, gate_b) after bias
-        bf16x2 y;
-        y[0] = (bf16)(v[0] * gelu_erf(v[1]));
-        y[1] = (bf16)(v[2] * gelu_erf(v[3]));
-        *(bf16x2*)(p.geglu_y + (long long)m * p.ldy + (n >> 1)) = y;
-        if (!p.C) continue;
-      }
-      if (p.preact) {
-        bf16x4 o;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) o[j] = (bf16)v[j];
-        *(bf16x4*)(p.preact + (long long)m * p.ldpre + n) = o;
-      }
-      if (p.act == 1) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = gelu_erf(v[j]);
-      } else if (p.act == 2) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = siluf_(v[j]);
-      }
-      if (p.res) {
-        const bf16x4 rr = *(const bf16x4*)(p.res + (long long)m * p.ldres + n);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] += (float)rr[j];
-      }
+      if (!value(mt, nt, m, bidx, v)) continue;
       if (p.out_f32) {
         float* cp = (float*)p.C + (long long)m * p.ldc + n;
         f32x4 o;
@@ -264,6 +294,51 @@ __device__ __forceinline__ void gemm_epilogue16(const GemmP& p, f32x4 (&acc)[NT]
 #pragma unroll
         for (int j = 0; j < 4; ++j) o[j] = (bf16)v[j];
         *(bf16x4*)((bf16*)p.C + (long long)m * p.ldc + n) = o;
+      }
+    }
+  }
+}
+
+// lean slice epilogue for the deferred form: alpha, optional bias, bf16 output, every n-tile pair inside N (the launcher
+// guarantees N % 32 == 0, ldc % 8 == 0, C 16-byte aligned); few live values, so it can sit inside the K-loop
+template <int MT, int NT, int M0, int M1>
+__device__ __forceinline__ void gemm_epilogue16_lean(const GemmP& p, f32x4 (&acc)[NT][MT], int m_base, int n_base,
+                                                     int r16, int q4) {
+  typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+#pragma unroll
+  for (int mt = M0; mt < M1; ++mt) {
+    const int m = m_base + mt * 16 + r16;
+    if (m >= p.M) continue;
+    bf16* crow = (bf16*)p.C + (long long)m * p.ldc;
+#pragma unroll
+    for (int nt = 0; nt < NT; nt += 2) {
+      if (nt + 1 < NT) {
+        if (n_base + nt * 16 >= p.N) continue;
+        union { bf16x4 h; unsigned u[2]; } a, b;
+        f32x4 b0 = {0.f, 0.f, 0.f, 0.f}, b1 = {0.f, 0.f, 0.f, 0.f};
+        if (p.bias) {
+          b0 = *(const f32x4*)(p.bias + n_base + nt * 16 + 4 * q4);
+          b1 = *(const f32x4*)(p.bias + n_base + (nt + 1) * 16 + 4 * q4);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          a.h[j] = (bf16)(acc[nt][mt][j] * p.alpha + b0[j]);
+          b.h[j] = (bf16)(acc[nt + 1][mt][j] * p.alpha + b1[j]);
+        }
+        const auto lo = __builtin_amdgcn_permlane16_swap(a.u[0], b.u[0], false, false);
+        const auto hi = __builtin_amdgcn_permlane16_swap(a.u[1], b.u[1], false, false);
+        const u32x4 o = {lo[0], hi[0], lo[1], hi[1]};
+        if (p.debug & 64) { if (o[0] == 0x12345678u) *(u32x4*)crow = o; }   // timing experiment: no store traffic
+        else *(u32x4*)(crow + n_base + (nt + (q4 & 1)) * 16 + 8 * (q4 >> 1)) = o;
+      } else {
+        const int n = n_base + nt * 16 + 4 * q4;
+        if (n >= p.N) continue;
+        f32x4 b0 = {0.f, 0.f, 0.f, 0.f};
+        if (p.bias) b0 = *(const f32x4*)(p.bias + n);
+        bf16x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = (bf16)(acc[nt][mt][j] * p.alpha + b0[j]);
+        *(bf16x4*)(crow + n) = o;
       }
     }
   }
@@ -877,8 +952,19 @@ static int launch_lc(const GemmP& p, hipStream_t stream) {
 // but the first.  With K = 640 .. 1280 that fixed cost was 35-55 % of a tile (scripts/gemm_ksweep.py).
 // Tile order: XCD x owns a contiguous range of (grouped) tile ids, its CUs take them round-robin, so the CUs
 // of an XCD work on neighbouring tiles at any time (shared A rows / W columns in that XCD's L2).
-template <int MODE, int BM, int BN, int WM, int WN, int LW, int S>
-__global__ __launch_bounds__((WM * WN + LW) * 64) void gemm_lcp_kernel(const GemmP p) {
+// SW > 0: STAGED EPILOGUE.  The MFMA waves only convert a finished tile to bf16 (alpha / bias / row vector /
+// activation / GEGLU applied) and drop it into an LDS staging image; SW extra "store waves" move it to HBM in
+// 16-byte row-contiguous pieces, a slice after every K-step barrier of the NEXT tile.  Without this every CU
+// bursts its tile at the same moment and the MFMA waves sit in the store-issue queue: 27-36 % of a K = 640..1280
+// launch (scripts/gemm_epi_probe.py).  Only for bf16 outputs without residual / pre-activation stash.
+// DF = 1: DEFERRED EPILOGUE.  A finished tile's accumulators are parked in a second register set and written out
+// in 16-row slices at the head of the next tile's K-steps; the two MFMA waves that share a SIMD take turns (even /
+// odd K-steps), so while one converts and stores a slice the other keeps the matrix pipe busy -- the tile
+// transition, 27-36 % of a K = 640..1280 launch when every wave stops for its epilogue at once
+// (scripts/gemm_epi_probe.py), disappears behind the main loop.
+template <int MODE, int BM, int BN, int WM, int WN, int LW, int S, int SW = 0, int DF = 0>
+__global__ __launch_bounds__((WM * WN + LW + SW) * 64) void gemm_lcp_kernel(const GemmP p) {
+  constexpr int PITCH = BN * 2 + 16;                            // staging row pitch: conflict-free 8-byte writes
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int NWC = WM * WN;
   constexpr int STAGE = (BM + BN) * 128;
@@ -914,6 +1000,44 @@ __global__ __launch_bounds__((WM * WN + LW) * 64) void gemm_lcp_kernel(const Gem
     bn = rem / gsize;
   };
 
+  char* const stg = smem + S * STAGE;                          // [BM][PITCH] bf16 staging image (SW > 0)
+  if (SW > 0 && wave >= NWC + LW) {
+    // ============================== store waves
+    const int sw = wave - NWC - LW;
+    const bool gg = p.geglu_y != nullptr;
+    const int cpr = (gg ? BN / 2 : BN) / 8;                     // 16-byte chunks per staged row
+    const int NP = (BM * cpr + SW * 64 - 1) / (SW * 64);        // passes of SW*64 chunks per tile
+    bf16* const dst = gg ? p.geglu_y : (bf16*)p.C;
+    const int ldd = gg ? p.ldy : p.ldc;
+    const int Nout = gg ? p.N / 2 : p.N;
+    typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+    auto drain = [&](int ti, int pb, int pe) {
+      int bm, bn;
+      tile_of(ti, bm, bn);
+      const int n0 = bn * (gg ? BN / 2 : BN);
+      for (int ps = pb; ps < pe; ++ps) {
+        const int c = (ps * SW + sw) * 64 + lane;
+        const int row = c / cpr, col = c - row * cpr;
+        const int gm = bm * BM + row, gn = n0 + col * 8;
+        if (row < BM && gm < p.M && gn < Nout && !(p.debug & 32)) {
+          const u32x4 v = *(const u32x4*)(stg + row * PITCH + col * 16);
+          *(u32x4*)(dst + (long long)gm * ldd + gn) = v;
+        }
+      }
+    };
+    __builtin_amdgcn_s_barrier();                              // prologue barrier
+    int ti = 0, t = 0;
+    for (int g = 0; g + 1 < G; ++g) {
+      __builtin_amdgcn_s_barrier();                            // barrier_g
+      // tile ti-1 was staged before the barrier of this tile's first K-step; spread its NP passes over K-steps
+      // 0 .. nt-2 (after the last one the MFMA waves overwrite the image)
+      if (ti > 0 && t < nt - 1) drain(ti - 1, t * NP / (nt - 1), (t + 1) * NP / (nt - 1));
+      if (++t == nt) { t = 0; ++ti; }
+    }
+    __builtin_amdgcn_s_barrier();                              // final barrier: the last tile is staged
+    drain(my_n - 1, 0, NP);
+    return;
+  }
   if (wave >= NWC) {
     // ============================== loader waves
     const int lw = wave - NWC;
@@ -1005,6 +1129,7 @@ __global__ __launch_bounds__((WM * WN + LW) * 64) void gemm_lcp_kernel(const Gem
       if (g + S < G) produce(cur);
       cur = cur + 1 == S ? 0 : cur + 1;
     }
+    if (SW > 0) __builtin_amdgcn_s_barrier();                  // final barrier (store waves drain the last tile after it)
     return;
   }
 
@@ -1024,6 +1149,20 @@ __global__ __launch_bounds__((WM * WN + LW) * 64) void gemm_lcp_kernel(const Gem
   __builtin_amdgcn_s_barrier();                                // prologue barrier
   load_frags(0, smem, 0);
   int cur = 0, g = 0;
+  f32x4 accp[DF ? NT : 1][DF ? MT : 1];                        // DF: the previous tile, waiting to be written out
+  int pm = 0, pn = 0, pdone = MT;                              // its origin; slices already written (MT = none pending)
+  const int par = (wave >> 2) & 1;                             // waves w and w+4 share a SIMD
+  auto slice = [&](int sidx) {
+    if constexpr (DF) {
+      static_assert(!DF || MT <= 4, "deferred epilogue: at most 4 slices");
+      switch (sidx) {
+        case 0: gemm_epilogue16_lean<MT, NT, 0, 1>(p, accp, pm, pn, r16, q4); break;
+        case 1: if constexpr (MT > 1) gemm_epilogue16_lean<MT, NT, 1, (MT > 1 ? 2 : MT)>(p, accp, pm, pn, r16, q4); break;
+        case 2: if constexpr (MT > 2) gemm_epilogue16_lean<MT, NT, 2, (MT > 2 ? 3 : MT)>(p, accp, pm, pn, r16, q4); break;
+        default: if constexpr (MT > 3) gemm_epilogue16_lean<MT, NT, 3, (MT > 3 ? 4 : MT)>(p, accp, pm, pn, r16, q4); break;
+      }
+    }
+  };
   for (int ti = 0; ti < my_n; ++ti) {
     f32x4 acc[NT][MT];
 #pragma unroll
@@ -1033,6 +1172,9 @@ __global__ __launch_bounds__((WM * WN + LW) * 64) void gemm_lcp_kernel(const Gem
     for (int t = 0; t < nt; ++t, ++g) {
       const char* tile = smem + cur * STAGE;
       const int nxt = cur + 1 == S ? 0 : cur + 1;
+      if constexpr (DF) {
+        if (pdone < MT && (t & 1) == par) { slice(pdone); ++pdone; }
+      }
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
         if (s2 == 1) {
@@ -1054,18 +1196,79 @@ __global__ __launch_bounds__((WM * WN + LW) * 64) void gemm_lcp_kernel(const Gem
     }
     int bm, bn;
     tile_of(ti, bm, bn);
-    gemm_epilogue16<MT, NT>(p, acc, bm * BM + wr * (BM / WM), bn * BN + wc * (BN / WN), r16, q4);
+    if constexpr (SW > 0) {
+      // staged epilogue: values -> bf16 -> LDS image (row = tile row, column = tile column), no global stores here
+      const int m_base = bm * BM + wr * (BM / WM), n_base = bn * BN + wc * (BN / WN);
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        const int row = wr * (BM / WM) + mt * 16 + r16;
+        const int bidx = p.rowvec ? min(m_base + mt * 16 + r16, p.M - 1) / p.rows_per_batch : 0;
+#pragma unroll
+        for (int nt_ = 0; nt_ < NT; ++nt_) {
+          const int col = wc * (BN / WN) + nt_ * 16 + 4 * q4;
+          const int n = min(n_base + nt_ * 16 + 4 * q4, p.N - 4);      // clamp: out-of-range columns are never stored
+          float v[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] = acc[nt_][mt][j] * p.alpha;
+          if (p.bias) {
+            const f32x4 bb = *(const f32x4*)(p.bias + n);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] += bb[j];
+          }
+          if (p.rowvec) {
+            const bf16x4 rv = *(const bf16x4*)(p.rowvec + (long long)bidx * p.ldrv + n);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] += (float)rv[j];
+          }
+          if (p.geglu_y) {
+            bf16x2 y;
+            y[0] = (bf16)(v[0] * gelu_erf(v[1]));
+            y[1] = (bf16)(v[2] * gelu_erf(v[3]));
+            *(bf16x2*)(stg + row * PITCH + col) = y;               // column col/2, 2 bytes each
+            continue;
+          }
+          if (p.act == 1) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = gelu_erf(v[j]);
+          } else if (p.act == 2) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = siluf_(v[j]);
+          }
+          bf16x4 o;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) o[j] = (bf16)v[j];
+          *(bf16x4*)(stg + row * PITCH + col * 2) = o;
+        }
+      }
+    } else if constexpr (DF) {
+      while (pdone < MT) { slice(pdone); ++pdone; }            // short K: the parked tile must leave before it is replaced
+#pragma unroll
+      for (int i = 0; i < NT; ++i)
+#pragma unroll
+        for (int j = 0; j < MT; ++j) accp[i][j] = acc[i][j];
+      pm = bm * BM + wr * (BM / WM); pn = bn * BN + wc * (BN / WN); pdone = 0;
+    } else {
+      if (!(p.debug & 16)) gemm_epilogue16<MT, NT>(p, acc, bm * BM + wr * (BM / WM), bn * BN + wc * (BN / WN), r16, q4);
+      else if (acc[0][0][0] == 12345.678f) *(float*)p.C = 1.f;   // timing experiment: keep the accumulators alive
+    }
+  }
+  if constexpr (DF) {
+    while (pdone < MT) { slice(pdone); ++pdone; }
+  }
+  if constexpr (SW > 0) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                              // final barrier
   }
 }
 
 static int g_num_cus = 0;
-template <int MODE, int BM, int BN, int WM, int WN, int LW, int S>
+template <int MODE, int BM, int BN, int WM, int WN, int LW, int S, int SW = 0, int DF = 0>
 static int launch_lcp(const GemmP& p, hipStream_t stream) {
-  constexpr int lds = S * (BM + BN) * 128;
+  constexpr int lds = S * (BM + BN) * 128 + (SW ? BM * (BN * 2 + 16) : 0);
   static_assert(lds <= 160 * 1024, "LDS budget");
   static bool attr_set = false;
   if (!attr_set) {
-    HIPCHK(hipFuncSetAttribute((const void*)gemm_lcp_kernel<MODE, BM, BN, WM, WN, LW, S>,
+    HIPCHK(hipFuncSetAttribute((const void*)gemm_lcp_kernel<MODE, BM, BN, WM, WN, LW, S, SW, DF>,
                                hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     attr_set = true;
   }
@@ -1077,7 +1280,7 @@ static int launch_lcp(const GemmP& p, hipStream_t stream) {
   SHAPECHK(p.ksplit <= 1, "gemm: the persistent kernel has no split-K path");
   const int tiles = cdiv(p.M, BM) * cdiv(p.N, BN);
   const int grid = tiles < g_num_cus ? tiles : g_num_cus;
-  hipLaunchKernelGGL((gemm_lcp_kernel<MODE, BM, BN, WM, WN, LW, S>), dim3(grid), dim3((WM * WN + LW) * 64), lds,
+  hipLaunchKernelGGL((gemm_lcp_kernel<MODE, BM, BN, WM, WN, LW, S, SW, DF>), dim3(grid), dim3((WM * WN + LW + SW) * 64), lds,
                      stream, p);
   return PEA_OK;
 }
@@ -1134,6 +1337,8 @@ static int launch_variant(const GemmP& p, hipStream_t stream) {
     case 30: rc = launch_lcp<MODE, 128, 128, 2, 2, 4, 4>(p, stream); break; \
     case 31: rc = launch_lcp<MODE, 64, 160, 2, 2, 4, 4>(p, stream); break; \
     case 33: rc = launch_lcp<MODE, 256, 128, 4, 2, 4, 3>(p, stream); break; \
+    case 34: rc = launch_lcp<MODE, 128, 160, 4, 2, 4, 3, 4>(p, stream); break; /* staged epilogue */ \
+    case 35: rc = launch_lcp<MODE, 128, 160, 4, 2, 4, 3, 0, 1>(p, stream); break; /* deferred epilogue */ \
     default: rc = launch_variant<MODE, 128, 128, 2, 2, 2>(p, stream); break; \
   }
 
@@ -1155,9 +1360,16 @@ static int pick_variant(const GemmP& p) {
     return 29;                                       // 32^2-level convs (M = 4096, N = 1280)
   }
   if (p.M < 1024 || t128 <= 160) return 31;          // embeddings, adapter, stacked K|V projection (tall-skinny)
-  if (t128 <= 256) return 25;                        // exactly one 128x160 tile per CU
-  if (t256 <= 256) return t256 > 192 ? 24 : 28;
-  return p.N >= 5120 ? 27 : 28;
+  // 35 = 28 with the deferred (lean: alpha / bias / bf16) epilogue: the finished tile leaves in 16-row slices during
+  // the next tile's K-steps, the two MFMA waves of a SIMD taking turns
+  // measured (in-run A/B, profiles/r01_gemm_variants.log): +4..11 % in the hot microbenchmark, nothing in situ -> off
+  // unless PEA_GEMM_DEFER is set
+  static const bool defer = getenv("PEA_GEMM_DEFER") != nullptr;
+  const bool lean = defer && !p.out_f32 && !p.res && !p.rowvec && !p.act && !p.geglu_y && !p.preact && p.ksplit <= 1 &&
+                    p.ldc % 8 == 0 && (((unsigned long long)p.C & 15) == 0);
+  if (t128 <= 256) return lean ? 35 : 25;            // exactly one 128x160 tile per CU
+  if (t256 <= 256) return t256 > 192 ? 24 : (lean ? 35 : 28);
+  return p.N >= 5120 ? 27 : (lean ? 35 : 28);
 }
 
 int g_gemm_debug = 0;
