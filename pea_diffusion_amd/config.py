@@ -134,3 +134,21 @@ def vae_to_c(cfg) -> CUNetConfig:
     c.layers_per_block = cfg.layers_per_block
     c.groups, c.eps = cfg.norm_num_groups, cfg.norm_eps
     return c
+
+
+def vae_encoder_flops(cfg: VAEConfig, H: int, W: int) -> float:
+    """analytic FLOPs of one encode per image (2 x MACs of the convs, linears and the mid-block attention)"""
+    fl, c, h, w = 0.0, cfg.block_out_channels[0], H, W
+    fl += 2.0 * h * w * c * 9 * cfg.in_channels
+    for i, co in enumerate(cfg.block_out_channels):
+        for j in range(cfg.layers_per_block):
+            ci = c if j == 0 else co
+            fl += 2.0 * h * w * 9 * (ci * co + co * co) + (2.0 * h * w * ci * co if ci != co else 0.0)
+        c = co
+        if i != len(cfg.block_out_channels) - 1:
+            h, w = h // 2, w // 2
+            fl += 2.0 * h * w * 9 * c * c
+    fl += 2 * (2.0 * h * w * 9 * 2 * c * c)
+    fl += 4 * 2.0 * h * w * c * c + 2 * 2.0 * (h * w) ** 2 * c
+    fl += 2.0 * h * w * 9 * c * 2 * cfg.latent_channels
+    return fl

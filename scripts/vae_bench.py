@@ -5,7 +5,6 @@ import torch
 from pea_diffusion_amd import config as pc
 from pea_diffusion_amd._lib import lib
 from pea_diffusion_amd.vae import HipVAEEncoder
-from oracle.vae_ref import vae_encoder_flops, sdxl_vae_config
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 4
 hw = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
 vae = HipVAEEncoder(pc.sdxl_vae_config(), B, hw, hw)
@@ -19,7 +18,7 @@ n = 5
 for _ in range(n): vae.encode_latents(x)
 e.record(); torch.cuda.synchronize()
 ms = s.elapsed_time(e) / n
-fl = vae_encoder_flops(sdxl_vae_config(), hw, hw) * B
+fl = pc.vae_encoder_flops(pc.sdxl_vae_config(), hw, hw) * B
 print(f"VAE encode B={B} {hw}x{hw}: {ms:.2f} ms/batch  {fl/ms/1e9:.1f} TFLOP/s  ({fl/B/1e12:.3f} TFLOP/img)  memory {vae.memory()}")
 L = lib()
 L.pea_prof_reset(); L.pea_prof_enable(1)
