@@ -20,5 +20,5 @@ for (M, N, K, v) in [(4096, 10240, 1280, 27), (4096, 3840, 1280, 28), (4096, 384
         L.pea_debug_set_gemm_debug(dbg)
         out.append(timeit(lambda: ops.gemm(a, w)))
     L.pea_debug_set_gemm_debug(0)
-    print(f"M{M} N{N} K{K} v{v}: {out[0]:7.1f} us ({2*M*N*K/out[0]/1e6:6.1f} TF)  without epilogue (v35: nontemporal stores) {out[1]:7.1f} us ({2*M*N*K/out[1]/1e6:6.1f} TF)")
+    print(f"M{M} N{N} K{K} v{v}: {out[0]:7.1f} us ({2*M*N*K/out[0]/1e6:6.1f} TF)  without epilogue (v35: paired stores suppressed) {out[1]:7.1f} us ({2*M*N*K/out[1]/1e6:6.1f} TF)")
 L.pea_debug_set_gemm_variant(-1)
