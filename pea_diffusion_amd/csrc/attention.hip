@@ -118,7 +118,21 @@ __global__ __launch_bounds__(256, (ND == 1 ? (MODE == 0 ? 4 : 2) : 1)) void attn
         dof[nd][s] = *(const bf16x8*)(dOb + (long long)qrow * p.lddo + nd * 64 + 16 * s + 8 * fh);
     const long long li = ((long long)b * p.H + head) * p.Sq + qrow;
     lse2 = p.lse[li] * LOG2E;
-    dlt = p.delta[li];
+    // delta[q] = sum_d dO[q][d] * O[q][d], computed here from the dO fragments already in registers (one extra read of
+    // the O row) instead of a separate kernel; the dK/dV kernel, launched after this one, reads it from p.delta
+    const bf16* Ob = p.O + (long long)b * p.Sq * p.ldo + head * 64 * ND;
+    float dsum = 0.f;
+#pragma unroll
+    for (int nd = 0; nd < ND; ++nd)
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const bf16x8 o = *(const bf16x8*)(Ob + (long long)qrow * p.ldo + nd * 64 + 16 * s + 8 * fh);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) dsum += (float)dof[nd][s][j] * (float)o[j];
+      }
+    dsum += __shfl_xor(dsum, 32, 64);
+    dlt = dsum;
+    if (qvalid && fh == 0 && chunk == 0) p.delta[li] = dsum;
   }
 
   f32x16 oacc[2 * NO];
@@ -601,7 +615,7 @@ int launch_attention_bwd(const AttnP& p0, hipStream_t s) {
   // algorithmic: 5 products (S, dP, dV, dK, dQ) = 10*B*H*Sq*Skv*D flops (the two-kernel form recomputes S and dP)
   if (g_prof_on) { g_prof_tag[0] = p.B * p.H; g_prof_tag[1] = p.Sq; g_prof_tag[2] = p.Skv; g_prof_tag[3] = p.nd; }
   PROF_BEGIN(3, 10.0 * p.B * p.H * (double)p.Sq * p.Skv * 64 * p.nd, 2.0 * p.B * p.H * 64 * p.nd * (4.0 * p.Sq + 4.0 * p.Skv), s);
-  hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)cdivl(total, 256)), dim3(256), 0, s, p);
+  if (!p.dQ) hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)cdivl(total, 256)), dim3(256), 0, s, p);   // else: the dQ kernel computes it
   rc = p.nd == 1 ? attn_bwd_nd<1>(p, s) : p.nd == 2 ? attn_bwd_nd<2>(p, s) : attn_bwd_nd<3>(p, s);
   PROF_END(s);
   if (rc) return rc;
