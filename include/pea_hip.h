@@ -262,8 +262,12 @@ int pea_train_step(void* tr, const float* latents, const float* noise, const lon
                    const long long* zh_or_not, const float* teacher_ehs, const float* teacher_neg,
                    const float* teacher_pooled, const float* time_ids, float grad_scale, float* grads,
                    int accumulate, float* losses, void* stream);
-/* options: "two_stream" (1 = teacher forward on a side HIP stream, default), "nan_guard" */
+/* options: "two_stream" (1 = teacher forward on a side HIP stream, default), "nan_guard", "merge_passes" (default 1:
+ * when the teacher context shares the student's weights -- the reference default, train_sdxl_zh.py:138,151 -- and the
+ * context lengths agree, both UNet forwards run as ONE pass over 2B samples and the backward differentiates the
+ * first B; otherwise the two-stream path is used) */
 int pea_trainer_set_option(void* tr, const char* name, int value);
+int pea_trainer_get_option(void* trainer, const char* name);   /* also "merge_state": 0 undecided, 1 merged, -1 n/a */
 /* intermediate results of the last step (fp32 NCHW [B][4][H][W]): which 0 = x_t, 1 = eps_student, 2 = eps_teacher */
 int pea_trainer_export(void* tr, int which, float* out, void* stream);
 

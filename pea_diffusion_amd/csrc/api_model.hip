@@ -395,6 +395,7 @@ int pea_trainer_set_option(void* h, const char* name, int value) {
   NOTNULL(h, "pea_trainer_set_option");
   Trainer* t = (Trainer*)h;
   if (!strcmp(name, "two_stream")) t->two_stream = value;
+  else if (!strcmp(name, "merge_passes")) t->merge_passes = value;
   else if (!strcmp(name, "nan_guard")) t->nan_guard = value;
   else {
     pea_set_error("pea_trainer_set_option: unknown option '%s'", name);
@@ -402,11 +403,22 @@ int pea_trainer_set_option(void* h, const char* name, int value) {
   }
   return PEA_OK;
 }
+int pea_trainer_get_option(void* h, const char* name) {
+  if (!h || !name) return PEA_E_INVALID;
+  Trainer* t = (Trainer*)h;
+  if (!strcmp(name, "two_stream")) return t->two_stream;
+  if (!strcmp(name, "merge_passes")) return t->merge_passes;
+  if (!strcmp(name, "merge_state")) return t->merge_state;     /* 0 undecided, 1 merged, -1 not eligible */
+  if (!strcmp(name, "nan_guard")) return t->nan_guard;
+  return PEA_E_INVALID;
+}
 int pea_trainer_export(void* h, int which, float* out, void* stream) {
   NOTNULL(h, "pea_trainer_export");
   Trainer* t = (Trainer*)h;
-  const float* src = which == 0 ? t->xt : which == 1 ? t->eps_s : t->eps_t;
   const size_t n = (size_t)t->student->B * t->student->cfg.in_channels * t->student->H * t->student->W;
+  const bool mg = t->merge_passes && t->merge_state == 1;
+  const float* src = mg ? (which == 0 ? t->xt2 : which == 1 ? t->eps2 : t->eps2 + n)
+                        : (which == 0 ? t->xt : which == 1 ? t->eps_s : t->eps_t);
   HIPCHK(hipMemcpyAsync(out, src, n * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));
   return PEA_OK;
 }

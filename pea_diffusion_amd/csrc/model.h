@@ -91,6 +91,7 @@ struct Unet {
   PeaUnetCfg cfg;
   int B, H, W, L;                 // batch, latent H/W, context length
   bool needs_grad;
+  int bwd_batch = 0;                 // > 0: backward() differentiates only the first bwd_batch samples (merged passes)
   int graph = 0;                     // 0: UNet2DConditionModel, 1: AutoencoderKL encoder (VAE), 2: ControlNetModel (1, 2: inference only)
   std::vector<int> cn_out;           // ControlNet: output tensors (down residuals in diffusers order, mid last)
   int ce_begin = -1, ce_end = -1;    // ControlNet: op range of the conditioning embedding (constant over a generation)
@@ -175,5 +176,14 @@ struct Trainer {
            float* grads, int accumulate, float* losses_out, hipStream_t s);
   float* t_f32 = nullptr;
   int two_stream = 1; hipStream_t side = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  // merged passes: when the teacher IS the student checkpoint (shared weights, reference default) both forwards run
+  // as ONE pass over 2B samples (student rows first) and the backward differentiates the first B only
+  int merge_passes = 1; int merge_state = 0;   // state: 0 undecided, 1 merged, -1 not eligible
+  Unet* merged = nullptr;
+  float *xt2 = nullptr, *eps2 = nullptr, *t2 = nullptr, *tid2 = nullptr;
+  int step_merged(const float* latents, const float* noise, const long long* timesteps, const float* enc,
+                  const float* enc_uncond, const unsigned char* prompt_mask, const long long* zh, const float* teacher_ehs,
+                  const float* teacher_neg, const float* teacher_pooled, const float* time_ids, float grad_scale,
+                  float* grads, int accumulate, float* losses_out, hipStream_t s);
   ~Trainer();
 };

@@ -857,7 +857,12 @@ void Unet::begin_backward() {
 
 int Unet::backward(const float* deps, hipStream_t s) {
   SHAPECHK(needs_grad, "unet: created without gradient support");
-  HIPCHK(hipMemsetAsync(tproj_grad, 0, sizeof(float) * B * tproj_total, s));
+  // bwd_batch < B: the forward ran on B samples (student rows first, teacher rows behind them: merged passes of a
+  // trainer whose teacher IS the student checkpoint) and only the first bwd_batch samples are differentiated.
+  // Every tensor is batch-major, so the restricted pass is the same tape on the leading rows of every tensor.
+  const int Bb = bwd_batch > 0 ? bwd_batch : B;
+  auto rb = [&](const Tn& t) -> long long { return t.rows / B * Bb; };
+  HIPCHK(hipMemsetAsync(tproj_grad, 0, sizeof(float) * Bb * tproj_total, s));
   // A residual connection hands its gradient on unchanged.  Instead of copying / adding it into the skip tensor's
   // buffer at once, the skip tensor remembers it as a PENDING alias (Tn::gpend) and the next kernel that writes that
   // tensor's gradient (LayerNorm / GroupNorm backward, dgrad GEMM) takes it as its addend: one launch and one
@@ -870,7 +875,7 @@ int Unet::backward(const float* deps, hipStream_t s) {
   };
   auto materialize = [&](Tn& t) -> int {         // for writers that can only accumulate in place
     if (!t.gw && t.gpend) {
-      RC(launch_accum(t.gpend, t.g, t.rows * t.cols, 0, s));
+      RC(launch_accum(t.gpend, t.g, rb(t) * t.cols, 0, s));
       t.gpend = nullptr;
       t.gw = true;
     }
@@ -879,7 +884,7 @@ int Unet::backward(const float* deps, hipStream_t s) {
   auto pass_on = [&](Tn& from, Tn& r) -> int {   // residual: r.g += from.g, deferred when r has no gradient yet
     if (!r.gw && !r.gpend) { r.gpend = from.g; return PEA_OK; }
     RC(materialize(r));
-    RC(launch_accum(from.g, r.g, r.rows * r.cols, 1, s));
+    RC(launch_accum(from.g, r.g, rb(r) * r.cols, 1, s));
     return PEA_OK;
   };
   for (int oi = (int)ops.size() - 1; oi >= 0; --oi) {
@@ -888,7 +893,7 @@ int Unet::backward(const float* deps, hipStream_t s) {
       if (!deps) continue;
       Tn& a = tn[o.a];
       SHAPECHK(!a.gw, "unet: conv_out input gradient already written");
-      RC(launch_conv_out_dgrad(deps, slots[o.w].f32, a.g, B, a.cols, H, W, cfg.out_channels, s));
+      RC(launch_conv_out_dgrad(deps, slots[o.w].f32, a.g, Bb, a.cols, H, W, cfg.out_channels, s));
       a.gw = true;
       continue;
     }
@@ -896,7 +901,7 @@ int Unet::backward(const float* deps, hipStream_t s) {
     Tn& out = tn[o.out];
     if (!out.rg) continue;
     if (o.kind == OP_LINEAR && o.p3 == 1) {   // fused time_emb_proj: gradient collected in fp32
-      RC(launch_cast_f32_bf16(tproj_grad, out.g, (long long)B * tproj_total, s));
+      RC(launch_cast_f32_bf16(tproj_grad, out.g, (long long)Bb * tproj_total, s));
       out.gw = true;
     }
     RC(materialize(out));
@@ -907,21 +912,21 @@ int Unet::backward(const float* deps, hipStream_t s) {
         if (a.rg && o.p3 == 2) {          // stacked K|V projection: M = B*L rows, K = sum(2C) -> split-K + ordered reduce
           FusedMat& f = fused[o.fused];
           GemmP p; fill_gemm(p);
-          p.A = out.g; p.lda = out.cols; p.M = (int)out.rows; p.K = out.cols; p.N = a.cols;
+          p.A = out.g; p.lda = out.cols; p.M = (int)rb(out); p.K = out.cols; p.N = a.cols;
           p.W = f.wt; p.ldw = f.N; p.C = kv_part; p.ldc = a.cols; p.out_f32 = 1;
-          p.ksplit = kv_nsplit; p.split_stride = (long long)out.rows * a.cols;
+          p.ksplit = kv_nsplit; p.split_stride = rb(out) * a.cols;
           RC(launch_gemm(p, s));
           RC(materialize(a));
-          RC(launch_splitk_reduce(kv_part, kv_nsplit, p.split_stride, a.g, a.cols, (int)a.rows, a.cols, a.gw, s));
+          RC(launch_splitk_reduce(kv_part, kv_nsplit, p.split_stride, a.g, a.cols, (int)rb(a), a.cols, a.gw, s));
           a.gw = true;
           break;
         }
         if (a.rg && o.p3 == 3) {          // fused GEGLU: d(pre-activation) into scratch, then the dgrad GEMM over K = 8C
           Tn& hg = tn[o.c];
-          RC(launch_geglu_bwd_il(hg.d, out.g, geglu_tmp, out.rows, out.cols, s));
+          RC(launch_geglu_bwd_il(hg.d, out.g, geglu_tmp, rb(out), out.cols, s));
           WSlot& w = slots[o.w];
           GemmP p; fill_gemm(p);
-          p.A = geglu_tmp; p.lda = hg.cols; p.M = (int)out.rows; p.K = hg.cols; p.N = a.cols;
+          p.A = geglu_tmp; p.lda = hg.cols; p.M = (int)rb(out); p.K = hg.cols; p.N = a.cols;
           p.W = w.wt; p.ldw = w.ldwt; p.C = a.g; p.ldc = a.cols;
           SHAPECHK(p.W != nullptr, "unet: dgrad weights missing for op %d", oi);
           if (const bf16* ad = addend(a)) { p.res = ad; p.ldres = a.cols; }
@@ -931,7 +936,7 @@ int Unet::backward(const float* deps, hipStream_t s) {
         }
         if (a.rg) {
           GemmP p; fill_gemm(p);
-          p.A = out.g; p.lda = out.cols; p.M = (int)out.rows; p.K = out.cols; p.N = a.cols;
+          p.A = out.g; p.lda = out.cols; p.M = (int)rb(out); p.K = out.cols; p.N = a.cols;
           if (o.fused >= 0) { FusedMat& f = fused[o.fused]; p.W = f.wt; p.ldw = f.N; }
           else { WSlot& w = slots[o.w]; p.W = w.wt; p.ldw = w.ldwt; }
           SHAPECHK(p.W != nullptr, "unet: dgrad weights missing for op %d", oi);
@@ -945,14 +950,14 @@ int Unet::backward(const float* deps, hipStream_t s) {
       }
       case OP_SILU: {
         Tn& a = tn[o.a];
-        if (a.rg) { RC(materialize(a)); RC(launch_silu_bwd(a.d, out.g, a.g, a.rows * a.cols, a.gw, s)); a.gw = true; }
+        if (a.rg) { RC(materialize(a)); RC(launch_silu_bwd(a.d, out.g, a.g, rb(a) * a.cols, a.gw, s)); a.gw = true; }
         break;
       }
       case OP_CONCAT: {
         Tn &a = tn[o.a], &b = tn[o.b];
         if (a.rg) RC(materialize(a));
         if (b.rg) RC(materialize(b));
-        RC(launch_split2(out.g, a.cols, b.cols, a.rg ? a.g : nullptr, a.gw, b.rg ? b.g : nullptr, b.gw, a.rows, s));
+        RC(launch_split2(out.g, a.cols, b.cols, a.rg ? a.g : nullptr, a.gw, b.rg ? b.g : nullptr, b.gw, rb(a), s));
         if (a.rg) a.gw = true;
         if (b.rg) b.gw = true;
         break;
@@ -966,27 +971,27 @@ int Unet::backward(const float* deps, hipStream_t s) {
           p.mode = 1; p.A = out.g; p.W = w.wt; p.ldw = w.ldwt; p.Hs = out.H; p.Ws = out.W; p.Cin = out.cols;
           p.N = a.cols; p.K = 9 * out.cols; p.zeros = zeros; p.stride = 1;
           if (o.p1) {            // upsample-folded conv: gradient at the upsampled resolution, then 2x2 sum
-            p.Ho = out.H; p.Wo = out.W; p.M = (int)out.rows; p.C = ups_tmp; p.ldc = a.cols;
+            p.Ho = out.H; p.Wo = out.W; p.M = (int)rb(out); p.C = ups_tmp; p.ldc = a.cols;
             RC(launch_gemm(p, s));
             RC(materialize(a));
-            RC(launch_sumpool2(ups_tmp, a.g, a.B, a.H, a.W, a.cols, a.gw, s));
+            RC(launch_sumpool2(ups_tmp, a.g, Bb, a.H, a.W, a.cols, a.gw, s));
           } else {
             if (o.p0 == 2) { p.shift = 1; p.parity = 1; }
-            p.Ho = a.H; p.Wo = a.W; p.M = (int)a.rows; p.C = a.g; p.ldc = a.cols;
+            p.Ho = a.H; p.Wo = a.W; p.M = (int)rb(a); p.C = a.g; p.ldc = a.cols;
             if (const bf16* ad = addend(a)) { p.res = ad; p.ldres = a.cols; }
             RC(launch_gemm(p, s));
           }
           a.gw = true;
         }
         if (o.rv >= 0 && tn[o.rv].rg)
-          RC(launch_colsum_batched(out.g, tproj_grad + o.rv_off, out.B, out.H * out.W, out.cols, tproj_total, cs_scratch, s));
+          RC(launch_colsum_batched(out.g, tproj_grad + o.rv_off, Bb, out.H * out.W, out.cols, tproj_total, cs_scratch, s));
         if (o.res >= 0 && tn[o.res].rg) RC(pass_on(out, tn[o.res]));
         break;
       }
       case OP_GN: {
         Tn& a = tn[o.a];
         if (a.rg) {
-          RC(launch_groupnorm_bwd(a.d, out.g, slots[o.w].f32, slots[o.bias].f32, o.aux, a.g, gn_scratch, a.B,
+          RC(launch_groupnorm_bwd(a.d, out.g, slots[o.w].f32, slots[o.bias].f32, o.aux, a.g, gn_scratch, Bb,
                                   a.H * a.W, a.cols, cfg.groups, o.p0, addend(a), s));
           a.gw = true;
         }
@@ -995,7 +1000,7 @@ int Unet::backward(const float* deps, hipStream_t s) {
       case OP_LN: {
         Tn& a = tn[o.a];
         if (a.rg) {
-          RC(launch_layernorm_bwd(a.d, out.g, slots[o.w].f32, o.aux, a.g, nullptr, nullptr, (int)a.rows, a.cols,
+          RC(launch_layernorm_bwd(a.d, out.g, slots[o.w].f32, o.aux, a.g, nullptr, nullptr, (int)rb(a), a.cols,
                                   addend(a), s));
           a.gw = true;
         }
@@ -1005,7 +1010,7 @@ int Unet::backward(const float* deps, hipStream_t s) {
         Tn &q = tn[o.a], &k = tn[o.b], &v = tn[o.c];
         AttnP p; memset(&p, 0, sizeof(p));
         p.Q = q.d + o.acol; p.ldq = q.cols; p.K = k.d + o.bcol; p.ldk = k.cols; p.V = v.d + o.ccol; p.ldv = v.cols;
-        p.O = out.d; p.ldo = out.cols; p.lse = o.aux; p.B = B; p.H = o.p0; p.Sq = o.p1; p.Skv = o.p2; p.scale = o.f0;
+        p.O = out.d; p.ldo = out.cols; p.lse = o.aux; p.B = Bb; p.H = o.p0; p.Sq = o.p1; p.Skv = o.p2; p.scale = o.f0;
         p.nd = o.p3;
         p.dO = out.g; p.lddo = out.cols; p.delta = delta; p.dkv_part = attn_part;
         SHAPECHK(!q.gw && !q.gpend && !k.gpend && (!k.gw || o.b == t_kvall), "unet: attention operand gradient written twice");
@@ -1020,7 +1025,7 @@ int Unet::backward(const float* deps, hipStream_t s) {
         Tn& a = tn[o.a];
         if (a.rg) {
           SHAPECHK(!a.gw, "unet: geglu input gradient written twice");
-          RC(launch_geglu_bwd(a.d, out.g, a.g, a.rows, out.cols, s));
+          RC(launch_geglu_bwd(a.d, out.g, a.g, rb(a), out.cols, s));
           a.gw = true;
         }
         break;
@@ -1162,12 +1167,14 @@ int Adapter::backward(float* g, int accumulate, hipStream_t s) {
 Trainer::~Trainer() {
   if (side) { (void)hipStreamDestroy(side); (void)hipEventDestroy(ev_fork); (void)hipEventDestroy(ev_join); }
   for (void* p : {(void*)xt, (void*)eps_s, (void*)eps_t, (void*)deps, (void*)ac, (void*)t_ehs_sel, (void*)dehs_full, (void*)t_f32,
-                  (void*)losses, (void*)kd_ws, (void*)tehs_c, (void*)tehs_n})
+                  (void*)losses, (void*)kd_ws, (void*)tehs_c, (void*)tehs_n, (void*)xt2, (void*)eps2, (void*)t2, (void*)tid2})
     if (p) hipFree(p);
+  delete merged;
 }
 
 int Trainer::prepare() {
   if (const char* e = getenv("PEA_TWO_STREAM")) two_stream = atoi(e);
+  if (const char* e = getenv("PEA_MERGE_PASSES")) merge_passes = atoi(e);
   Unet& S = *student;
   Unet& Tt = *teacher;
   SHAPECHK(S.needs_grad, "trainer: student context needs gradient support");
@@ -1224,6 +1231,35 @@ int Trainer::step(const float* latents, const float* noise, const long long* tim
   const int B = S.B;
   SHAPECHK(A.B2 == 2 * B && A.L == S.L, "trainer: adapter is prepared for %d x %d rows, the step needs %d x %d", A.B2, A.L,
            2 * B, S.L);
+  if (merge_passes && merge_state == 0) {
+    // eligible: the teacher context shares the student's weight arena (same checkpoint, train_sdxl_zh.py:138,151 load
+    // the same model_path) and both see the same context length
+    // (merge_passes 1: only for per-GPU batches <= 4, where doubling the rows pays more than the two-stream overlap --
+    // measured 32.4 vs 32.1 images/s at B = 4 and 34.7 vs 35.8 at B = 8; 2: always when eligible)
+    bool ok = (merge_passes >= 2 || B <= 4) && !Tt.owns_weights && Tt.slots.size() == S.slots.size() && S.L == Tt.L &&
+              S.graph == 0 && Tt.graph == 0 &&
+              memcmp(&S.cfg, &Tt.cfg, sizeof(PeaUnetCfg)) == 0;
+    for (size_t i = 0; ok && i < S.slots.size(); ++i)
+      ok = S.slots[i].w == Tt.slots[i].w && S.slots[i].f32 == Tt.slots[i].f32;
+    merge_state = ok ? 1 : -1;
+    if (ok) {
+      merged = new Unet();
+      merged->cfg = S.cfg;
+      merged->B = 2 * B; merged->H = S.H; merged->W = S.W; merged->L = S.L;
+      merged->needs_grad = true; merged->owns_weights = false; merged->bwd_batch = B;
+      RC(merged->build());
+      RC(merged->share_weights_from(S));
+      RC(merged->alloc());
+      const size_t n = (size_t)B * S.cfg.in_channels * S.H * S.W;
+      HIPCHK(hipMalloc((void**)&xt2, 2 * n * 4));
+      HIPCHK(hipMalloc((void**)&eps2, 2 * n * 4));
+      HIPCHK(hipMalloc((void**)&t2, 2 * B * 4));
+      HIPCHK(hipMalloc((void**)&tid2, 2 * B * 6 * 4));
+    }
+  }
+  if (merge_passes && merge_state == 1)
+    return step_merged(latents, noise, timesteps, enc, enc_uncond, prompt_mask, zh, teacher_ehs, teacher_neg,
+                       teacher_pooled, time_ids, grad_scale, grads, accumulate, losses_out, s);
   const long long per_img = (long long)S.cfg.in_channels * S.H * S.W;
   if (!t_f32) HIPCHK(hipMalloc((void**)&t_f32, sizeof(float) * B));
   RC(launch_add_noise(latents, noise, timesteps, ac, xt, B, per_img, s));
@@ -1282,6 +1318,77 @@ int Trainer::step(const float* latents, const float* noise, const long long* tim
     HIPCHK(hipMemsetAsync(A.dpool, 0, (size_t)A.B2 * A.out_dim * 2, s));
     if (S.t_text >= 0 && S.tn[S.t_text].gw)
       HIPCHK(hipMemcpyAsync(A.dpool, S.tn[S.t_text].g, (size_t)B * A.out_dim * 2, hipMemcpyDeviceToDevice, s));
+  }
+  RC(A.backward(grads, accumulate, s));
+  return PEA_OK;
+}
+
+
+// The same step with the two UNet forwards merged into one pass over 2B samples (rows [0, B): student conditioning,
+// rows [B, 2B): teacher conditioning, same noisy latents and timesteps), possible when the teacher context shares the
+// student's weights.  Every GEMM / conv / attention launch then works on twice the rows -- at B = 4 that is the
+// difference between one and two 128-row tiles per CU in most launches -- and the backward pass walks the tape on
+// the leading B samples only (Unet::bwd_batch).  The teacher half runs without `no_grad` bookkeeping differences:
+// nothing in the forward depends on whether a gradient will be taken.
+int Trainer::step_merged(const float* latents, const float* noise, const long long* timesteps, const float* enc,
+                         const float* enc_uncond, const unsigned char* prompt_mask, const long long* zh,
+                         const float* teacher_ehs, const float* teacher_neg, const float* teacher_pooled,
+                         const float* time_ids, float grad_scale, float* grads, int accumulate, float* losses_out,
+                         hipStream_t s) {
+  Unet& M = *merged;
+  Adapter& A = *ad;
+  const int B = student->B;
+  const long long per_img = (long long)M.cfg.in_channels * M.H * M.W;
+  RC(launch_add_noise(latents, noise, timesteps, ac, xt2, B, per_img, s));
+  HIPCHK(hipMemcpyAsync(xt2 + B * per_img, xt2, (size_t)B * per_img * 4, hipMemcpyDeviceToDevice, s));
+  RC(launch_cast_i64_f32(timesteps, t2, B, s));
+  HIPCHK(hipMemcpyAsync(t2 + B, t2, (size_t)B * 4, hipMemcpyDeviceToDevice, s));
+  if (time_ids) {
+    HIPCHK(hipMemcpyAsync(tid2, time_ids, (size_t)B * 6 * 4, hipMemcpyDeviceToDevice, s));
+    HIPCHK(hipMemcpyAsync(tid2 + B * 6, time_ids, (size_t)B * 6 * 4, hipMemcpyDeviceToDevice, s));
+  }
+  const long long per_tok = (long long)M.L * M.cfg.cross_dim;
+  Tn& ehs = M.tn[M.t_ehs];
+  // teacher rows: where(prompt_mask, negative, prompt) (:413)
+  RC(launch_cast_f32_bf16(teacher_ehs, tehs_c, B * per_tok, s));
+  RC(launch_cast_f32_bf16(teacher_neg, tehs_n, B * per_tok, s));
+  RC(launch_select_rows(tehs_c, tehs_n, prompt_mask, ehs.d + B * per_tok, B, per_tok, s));
+  // student rows: adapter on (cond | uncond), CFG-dropout select (:383-395)
+  RC(A.forward(enc, enc_uncond, 0, s));
+  const bf16* tokens = A.out1 ? A.tok : A.z2;
+  RC(launch_select_rows(tokens, tokens + B * per_tok, prompt_mask, ehs.d, B, per_tok, s));
+  const void* text = nullptr;
+  if (M.t_text >= 0) {
+    Tn& q = M.tn[M.t_text];
+    HIPCHK(hipMemcpyAsync(q.d, A.pooled, (size_t)B * q.cols * 2, hipMemcpyDeviceToDevice, s));
+    RC(launch_cast_f32_bf16(teacher_pooled, q.d + (long long)B * q.cols, (long long)B * q.cols, s));
+    text = q.d;
+  }
+  RC(M.forward(xt2, t2, ehs.d, 1, text, 1, tid2, eps2, s));
+  KdLossP kp;
+  memset(&kp, 0, sizeof(kp));
+  kp.ntaps = (int)M.taps.size();
+  M.begin_backward();
+  for (int k = 0; k < kp.ntaps; ++k) {
+    Tn& tp = M.tn[M.taps[k]];
+    const long long half = tp.rows / 2 * tp.cols;
+    kp.fs[k] = tp.d; kp.ft[k] = tp.d + half; kp.dfs[k] = tp.g;
+    kp.per[k] = tp.rows / M.B * tp.cols;
+    tp.gw = true;
+  }
+  kp.eps_s = eps2; kp.eps = noise; kp.eps_t = eps2 + B * per_img; kp.deps_s = deps; kp.per_eps = per_img; kp.zh = zh;
+  kp.B = B; kp.feat_weight = feat_weight; kp.nan_guard = nan_guard; kp.grad_scale = grad_scale; kp.losses = losses;
+  kp.partial = (float*)kd_ws;
+  RC(launch_kd_loss(kp, s));
+  if (losses_out) HIPCHK(hipMemcpyAsync(losses_out, losses, 16, hipMemcpyDeviceToDevice, s));
+  RC(M.backward(deps, s));
+  SHAPECHK(ehs.gw, "trainer: no gradient reached encoder_hidden_states");
+  bf16* dtokens = A.out1 ? A.dtok : A.dz2;
+  RC(launch_select_rows_bwd(ehs.g, prompt_mask, dtokens, dtokens + B * per_tok, B, per_tok, s));
+  if (A.out1) {
+    HIPCHK(hipMemsetAsync(A.dpool, 0, (size_t)A.B2 * A.out_dim * 2, s));
+    if (M.t_text >= 0 && M.tn[M.t_text].gw)
+      HIPCHK(hipMemcpyAsync(A.dpool, M.tn[M.t_text].g, (size_t)B * A.out_dim * 2, hipMemcpyDeviceToDevice, s));
   }
   RC(A.backward(grads, accumulate, s));
   return PEA_OK;

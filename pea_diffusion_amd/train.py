@@ -96,6 +96,11 @@ class PEATrainer:
         return out
 
     # ---- data parallel: ONE all-reduce over the flat adapter-grad buffer (24-46 MB), averaged
+    def set_option(self, name: str, value: int):
+        """`two_stream` (teacher pass on a side HIP stream), `merge_passes` (teacher == student checkpoint: both forwards
+        as one pass over 2B samples), `nan_guard`"""
+        check(lib().pea_trainer_set_option(self._h, name.encode(), int(value)))
+
     @property
     def world_size(self) -> int:
         return pdist.world_size()

@@ -282,6 +282,72 @@ def test_adamw_and_checkpoint_round_trip(gpu, tmp_path):
         assert torch.equal(sd[k], v.detach().cpu()), k
 
 
+def test_merged_passes_match_two_streams_and_oracle(gpu):
+    """Reference default: the teacher IS the student checkpoint (train_sdxl_zh.py:138,151 load the same model_path).  The
+    trainer then runs both forwards as ONE pass over 2B samples and differentiates the first B; it must agree with the
+    two-stream path and with the oracle."""
+    import copy
+    from oracle.step_ref import AdapterRef, synthetic_batch, training_step_ref
+    from oracle.unet_ref import UNet2DConditionRef, cast_hook_ref, tiny_config
+    from pea_diffusion_amd import config as pc
+    from pea_diffusion_amd.adapter import PEAAdapter
+    from pea_diffusion_amd.train import PEATrainer
+    from pea_diffusion_amd.unet import HipUNet
+    B, L = 4, 77
+    cfg = tiny_config()
+    torch.manual_seed(0)
+    us = UNet2DConditionRef(cfg)
+    round_weights_bf16_(us)
+    for p in us.parameters():
+        p.requires_grad_(False)
+    ut = copy.deepcopy(us)
+    ad_ref = AdapterRef(128, cfg.pooled_dim, 192, cfg.cross_attention_dim, False)
+    ad_hip = PEAAdapter(128, cfg.pooled_dim, 192, cfg.cross_attention_dim, False)
+    ad_hip.load_state_dict(ad_ref.state_dict())
+    ad_hip = ad_hip.cuda()
+    round_weights_bf16_(ad_ref)
+    hs = HipUNet(pc.tiny_config(), B, 16, 16, L, needs_grad=True)
+    hs.load_state_dict(us.state_dict())
+    ht = HipUNet(pc.tiny_config(), B, 16, 16, L, needs_grad=False, share_weights_from=hs)
+    batch = synthetic_batch(cfg, B, L=L, enc_dim=128, seed=3)
+    tr = PEATrainer(ad_hip, hs, ht)
+    tr.set_option("merge_passes", 0)
+    two = tr.training_step(batch, 0, sync=True)
+    g_two = ad_hip.flat_grad.clone()
+    e_two = (tr.export("x_t").clone(), tr.export("eps_student").clone(), tr.export("eps_teacher").clone())
+    tr.set_option("merge_passes", 1)
+    one = tr.training_step(batch, 0, sync=True)
+    g_one = ad_hip.flat_grad.clone()
+    assert lib_merge_state(tr) == 1, "teacher shares the student's weights: the merged pass must be taken"
+    for k in tr.LOG_KEYS:
+        print(f"[merged passes] {k}: merged={float(one[k]):.6f} two-stream={float(two[k]):.6f}")
+        assert abs(float(one[k]) - float(two[k])) <= 1e-3 * max(abs(float(two[k])), 1e-3), k
+    e = rel_l2(g_one, g_two)
+    print(f"   adapter grad merged vs two-stream rel_l2={e:.3e}")
+    assert e < 5e-3
+    for a, b in zip((tr.export("x_t"), tr.export("eps_student"), tr.export("eps_teacher")), e_two):
+        assert rel_l2(a, b) < 5e-3
+    bq = dict(batch)
+    for k in ("enc", "enc_uncond", "teacher_ehs", "teacher_neg", "teacher_pooled"):
+        bq[k] = batch[k].to(torch.bfloat16).float()
+    out_r = training_step_ref(ad_ref, us, ut, bq, cast_hook_ref)
+    out_r["loss"].backward()
+    for k in tr.LOG_KEYS:
+        # with identical weights the feature / logit losses are differences of nearly equal bf16 tensors: 5 % there
+        tol = 5e-2 if k in ("train_loss_features", "train_loss_logits") else 1e-2
+        assert abs(float(one[k]) - float(out_r[k])) <= tol * max(abs(float(out_r[k])), 1e-3), k
+    for (k, p), (_, q) in zip(ad_hip.named_parameters(), ad_ref.named_parameters()):
+        assert rel_l2(p.grad, q.grad) < 4e-2, k
+    again = tr.training_step(batch, 0, sync=True)          # bit-reproducible in the merged form too
+    assert torch.equal(g_one, ad_hip.flat_grad) and float(again["loss"]) == float(one["loss"])
+
+
+def lib_merge_state(tr):
+    import ctypes
+    from pea_diffusion_amd._lib import lib
+    return lib().pea_trainer_get_option(tr._h, b"merge_state")
+
+
 def test_asymmetric_teacher_student(gpu):
     """BASELINE config 4 shape case (SSD-1B student + SDXL teacher): student and teacher UNets with different
     transformer depths share tap shapes; the KD step must match the oracle."""
