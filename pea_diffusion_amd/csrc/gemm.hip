@@ -61,7 +61,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x16 (&acc)[NI][
           y[0] = (bf16)(v[0] * gelu_erf(v[1]));
           y[1] = (bf16)(v[2] * gelu_erf(v[3]));
           *(bf16x2*)(p.geglu_y + (long long)m * p.ldy + (n >> 1)) = y;
-          if (!p.C) continue;
+          if (!p.C || (p.stash_rows > 0 && m >= p.stash_rows)) continue;
         }
         if (p.preact) {
           bf16x4 o;
@@ -222,7 +222,7 @@ __device__ __forceinline__ void gemm_epilogue16(const GemmP& p, f32x4 (&acc)[NT]
       y[0] = (bf16)(v[0] * gelu_erf(v[1]));
       y[1] = (bf16)(v[2] * gelu_erf(v[3]));
       *(bf16x2*)(p.geglu_y + (long long)m * p.ldy + (n >> 1)) = y;
-      if (!p.C) return false;
+      if (!p.C || (p.stash_rows > 0 && m >= p.stash_rows)) return false;
     }
     if (p.preact) {
       bf16x4 o;
@@ -257,8 +257,9 @@ __device__ __forceinline__ void gemm_epilogue16(const GemmP& p, f32x4 (&acc)[NT]
       // the cache lines touched per stored byte (the store tail of a tile is issue-bound, not bandwidth-bound).
       if ((nt & 1) == 0 && nt + 1 < NT && pairs_ok && n_base + (nt + 2) * 16 <= p.N) {
         float v0[4], v1[4];
-        value(mt, nt, m, bidx, v0);
+        const bool st = value(mt, nt, m, bidx, v0);
         value(mt, nt + 1, m, bidx, v1);
+        if (!st) continue;                    // GEGLU row without a stash (depends on the row only: partners agree)
         union { bf16x4 h; unsigned u[2]; } a, b;
 #pragma unroll
         for (int j = 0; j < 4; ++j) { a.h[j] = (bf16)v0[j]; b.h[j] = (bf16)v1[j]; }

@@ -765,6 +765,7 @@ int Unet::exec_ops(size_t begin, size_t end, bool skip_cached, hipStream_t s) {
         if (o.p3 == 3) {                  // fused GEGLU: N = 8C interleaved, y -> out, pre-activation -> op.c (student only)
           p.N = 2 * out.cols; p.geglu_y = out.d; p.ldy = out.cols;
           p.C = o.c >= 0 ? tn[o.c].d : nullptr; p.ldc = 2 * out.cols;
+          if (bwd_batch > 0) p.stash_rows = (int)(out.rows / B * bwd_batch);   // only the differentiated samples are stashed
         }
         if (o.res >= 0) { p.res = tn[o.res].d; p.ldres = tn[o.res].cols; }
         RC(launch_gemm(p, s));

@@ -32,6 +32,7 @@ struct GemmP {
   // fused GEGLU: the weight rows are interleaved (h_i, gate_i) so a lane's 4 consecutive columns are two pairs;
   // geglu_y[m][n/2] = h * gelu(gate).  C may be null then (no pre-activation stash: teacher / inference).
   bf16* geglu_y; int ldy;
+  int stash_rows;                  // GEGLU with a stash: rows >= stash_rows (> 0) skip the C store (merged passes: teacher rows)
   int ksplit; long long split_stride;   // split-K: fp32 partial s is written at C + s*split_stride (then launch_splitk_reduce)
 };
 int launch_splitk_reduce(const float* part, int nsplit, long long stride, bf16* out, int ldo, int M, int N, int accum,
