@@ -325,7 +325,12 @@ def main():
             "tflop_per_image": TFLOP_PER_IMAGE.get(args.model) if args.student == "same" else None,
             "achieved_tflops_per_gpu": (round(ips / world * TFLOP_PER_IMAGE[args.model], 1)
                                         if TFLOP_PER_IMAGE.get(args.model) and args.student == "same" else None),
-            "hbm_resident_gb": round((mem["weight_bytes"] + 2 * mem["activation_bytes"] + mem["grad_bytes"]) / 2 ** 30, 1),
+            "hbm_resident_gb": round((mem["weight_bytes"] + mem["activation_bytes"] + teacher.memory()["activation_bytes"]
+                                      + mem["grad_bytes"]) / 2 ** 30
+                                     + lib().pea_trainer_get_option(trainer._h, b"merged_mib") / 1024, 1),
+            "passes": ("merged: teacher == student checkpoint, one forward over 2B samples + backward on the first B"
+                       if lib().pea_trainer_get_option(trainer._h, b"merge_state") == 1 else
+                       "teacher forward on a side HIP stream beside the student forward"),
             "roofline": roof, "cpu_baseline": cpu,
         }
         sys.stdout.flush()

@@ -410,6 +410,8 @@ int pea_trainer_get_option(void* h, const char* name) {
   if (!strcmp(name, "merge_passes")) return t->merge_passes;
   if (!strcmp(name, "merge_state")) return t->merge_state;     /* 0 undecided, 1 merged, -1 not eligible */
   if (!strcmp(name, "nan_guard")) return t->nan_guard;
+  if (!strcmp(name, "merged_mib"))                                /* activations + gradients of the merged-pass context */
+    return t->merged ? (int)((t->merged->abytes + t->merged->gbytes) >> 20) : 0;
   return PEA_E_INVALID;
 }
 int pea_trainer_export(void* h, int which, float* out, void* stream) {
