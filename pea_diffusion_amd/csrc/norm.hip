@@ -45,7 +45,8 @@ __global__ void gn_stats_kernel(const bf16* __restrict__ x, const bf16* __restri
     }
     const int p0 = blockIdx.x * pix_per_block;
     const int p1 = min(p0 + pix_per_block, HW);
-    for (int p = p0 + pl; p < p1; p += ppb) {
+  #pragma unroll 4
+  for (int p = p0 + pl; p < p1; p += ppb) {      // 4 pixels in flight per thread (latency-bound otherwise)
       const long long off = ((long long)b * HW + p) * C + c0;
       const bf16x8 xv = *(const bf16x8*)(x + off);
       if (!BWD) {
@@ -150,7 +151,8 @@ __global__ void gn_apply_kernel(const bf16* __restrict__ x, const float* __restr
     sh[j] = beta[c0 + j] - mean * sc[j];
   }
   const int p0 = blockIdx.x * pix_per_block, p1 = min(p0 + pix_per_block, HW);
-  for (int p = p0 + pl; p < p1; p += ppb) {
+#pragma unroll 4
+  for (int p = p0 + pl; p < p1; p += ppb) {      // 4 pixels in flight per thread (latency-bound otherwise)
     const long long off = ((long long)b * HW + p) * C + c0;
     const bf16x8 xv = *(const bf16x8*)(x + off);
     bf16x8 o;
@@ -184,7 +186,8 @@ __global__ void gn_bwd_apply_kernel(const bf16* __restrict__ x, const bf16* __re
     gm[j] = gamma[c0 + j]; bt[j] = beta[c0 + j];
   }
   const int p0 = blockIdx.x * pix_per_block, p1 = min(p0 + pix_per_block, HW);
-  for (int p = p0 + pl; p < p1; p += ppb) {
+#pragma unroll 4
+  for (int p = p0 + pl; p < p1; p += ppb) {      // 4 pixels in flight per thread (latency-bound otherwise)
     const long long off = ((long long)b * HW + p) * C + c0;
     const bf16x8 xv = *(const bf16x8*)(x + off);
     const bf16x8 dv = *(const bf16x8*)(dy + off);
@@ -272,52 +275,70 @@ int launch_groupnorm_bwd(const bf16* x, const bf16* dy, const float* gamma, cons
 // one wave per row, the whole row lives in registers (C <= 4096 -> <= 8 chunks of 8 per lane)
 #define LN_MAXCH 8
 
+// A wave owns LN_NR consecutive rows, all of them loaded before the first reduction: twice the bytes in flight per
+// wave (the kernels are latency-bound: 16 waves x 3 KB per CU did not cover the HBM latency), gamma / beta read
+// once per wave as 16-byte vectors.
+#define LN_NR 2
 template <int NCH>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const bf16* __restrict__ x, const float* __restrict__ gamma,
                                                      const float* __restrict__ beta, bf16* __restrict__ y,
                                                      float* __restrict__ stats, int R, int C, float eps) {
   const int lane = threadIdx.x & 63;
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= R) return;
+  const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * LN_NR;
+  if (row0 >= R) return;
   const int nchunk = C / 8;
-  bf16x8 v[NCH];
-  float s = 0.f;
+  bf16x8 v[LN_NR][NCH];
 #pragma unroll
-  for (int i = 0; i < NCH; ++i) {
-    const int ck = lane + 64 * i;
-    if (ck < nchunk) {
-      v[i] = *(const bf16x8*)(x + (long long)row * C + ck * 8);
+  for (int r = 0; r < LN_NR; ++r) {
+    const int row = min(row0 + r, R - 1);
 #pragma unroll
-      for (int j = 0; j < 8; ++j) s += (float)v[i][j];
+    for (int i = 0; i < NCH; ++i) {
+      const int ck = lane + 64 * i;
+      if (ck < nchunk) v[r][i] = *(const bf16x8*)(x + (long long)row * C + ck * 8);
     }
   }
-  const float mean = wave_sum(s) / (float)C;
-  float q = 0.f;
+  float mean[LN_NR], rstd[LN_NR];
+#pragma unroll
+  for (int r = 0; r < LN_NR; ++r) {
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i)
+      if (lane + 64 * i < nchunk)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s += (float)v[r][i][j];
+    mean[r] = wave_sum(s) / (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i)
+      if (lane + 64 * i < nchunk)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float d = (float)v[r][i][j] - mean[r];
+          q += d * d;
+        }
+    rstd[r] = rsqrtf(wave_sum(q) / (float)C + eps);
+    if (stats && lane == 0 && row0 + r < R) {
+      stats[2 * (long long)(row0 + r)] = mean[r];
+      stats[2 * (long long)(row0 + r) + 1] = rstd[r];
+    }
+  }
 #pragma unroll
   for (int i = 0; i < NCH; ++i) {
     const int ck = lane + 64 * i;
     if (ck < nchunk) {
+      const f32x4 g0 = *(const f32x4*)(gamma + ck * 8), g1 = *(const f32x4*)(gamma + ck * 8 + 4);
+      const f32x4 b0 = *(const f32x4*)(beta + ck * 8), b1 = *(const f32x4*)(beta + ck * 8 + 4);
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const float d = (float)v[i][j] - mean;
-        q += d * d;
+      for (int r = 0; r < LN_NR; ++r) {
+        if (row0 + r >= R) break;
+        bf16x8 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          o[j] = (bf16)(((float)v[r][i][j] - mean[r]) * rstd[r] * g0[j] + b0[j]);
+          o[4 + j] = (bf16)(((float)v[r][i][4 + j] - mean[r]) * rstd[r] * g1[j] + b1[j]);
+        }
+        *(bf16x8*)(y + (long long)(row0 + r) * C + ck * 8) = o;
       }
-    }
-  }
-  const float rstd = rsqrtf(wave_sum(q) / (float)C + eps);
-  if (stats && lane == 0) {
-    stats[2 * (long long)row] = mean;
-    stats[2 * (long long)row + 1] = rstd;
-  }
-#pragma unroll
-  for (int i = 0; i < NCH; ++i) {
-    const int ck = lane + 64 * i;
-    if (ck < nchunk) {
-      bf16x8 o;
-#pragma unroll
-      for (int j = 0; j < 8; ++j)
-        o[j] = (bf16)(((float)v[i][j] - mean) * rstd * gamma[ck * 8 + j] + beta[ck * 8 + j]);
-      *(bf16x8*)(y + (long long)row * C + ck * 8) = o;
     }
   }
 }
@@ -329,44 +350,61 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16* __restrict__ x,
                                                      float* __restrict__ dgamma, float* __restrict__ dbeta, int R,
                                                      int C, const bf16* add) {
   const int lane = threadIdx.x & 63;
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= R) return;
+  const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * LN_NR;
+  if (row0 >= R) return;
   const int nchunk = C / 8;
-  const float mean = stats[2 * (long long)row], rstd = stats[2 * (long long)row + 1];
-  bf16x8 xv[NCH], dv[NCH];
-  float s1 = 0.f, s2 = 0.f;
+  bf16x8 xv[LN_NR][NCH], dv[LN_NR][NCH], av[LN_NR][NCH];
 #pragma unroll
-  for (int i = 0; i < NCH; ++i) {
-    const int ck = lane + 64 * i;
-    if (ck < nchunk) {
-      xv[i] = *(const bf16x8*)(x + (long long)row * C + ck * 8);
-      dv[i] = *(const bf16x8*)(dy + (long long)row * C + ck * 8);
+  for (int r = 0; r < LN_NR; ++r) {
+    const int row = min(row0 + r, R - 1);
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const float xh = ((float)xv[i][j] - mean) * rstd;
-        const float d = (float)dv[i][j] * gamma[ck * 8 + j];
-        s1 += d;
-        s2 += d * xh;
+    for (int i = 0; i < NCH; ++i) {
+      const int ck = lane + 64 * i;
+      if (ck < nchunk) {
+        xv[r][i] = *(const bf16x8*)(x + (long long)row * C + ck * 8);
+        dv[r][i] = *(const bf16x8*)(dy + (long long)row * C + ck * 8);
+        if (add) av[r][i] = *(const bf16x8*)(add + (long long)row * C + ck * 8);   // may be dx itself (in-place accumulate)
       }
     }
   }
-  s1 = wave_sum(s1) / (float)C;
-  s2 = wave_sum(s2) / (float)C;
+  f32x4 g0[NCH], g1[NCH];
 #pragma unroll
   for (int i = 0; i < NCH; ++i) {
     const int ck = lane + 64 * i;
-    if (ck < nchunk) {
-      bf16x8 o;
-      if (add) o = *(const bf16x8*)(add + (long long)row * C + ck * 8);   // may be dx itself (in-place accumulate)
+    if (ck < nchunk) { g0[i] = *(const f32x4*)(gamma + ck * 8); g1[i] = *(const f32x4*)(gamma + ck * 8 + 4); }
+  }
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const float xh = ((float)xv[i][j] - mean) * rstd;
-        const float dyv = (float)dv[i][j];
-        float r = rstd * (dyv * gamma[ck * 8 + j] - s1 - xh * s2);
-        if (add) r += (float)o[j];
-        o[j] = (bf16)r;
+  for (int r = 0; r < LN_NR; ++r) {
+    const int row = min(row0 + r, R - 1);
+    const float mean = stats[2 * (long long)row], rstd = stats[2 * (long long)row + 1];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i)
+      if (lane + 64 * i < nchunk)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float xh = ((float)xv[r][i][j] - mean) * rstd;
+          const float d = (float)dv[r][i][j] * (j < 4 ? g0[i][j] : g1[i][j - 4]);
+          s1 += d;
+          s2 += d * xh;
+        }
+    s1 = wave_sum(s1) / (float)C;
+    s2 = wave_sum(s2) / (float)C;
+    if (row0 + r >= R) break;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int ck = lane + 64 * i;
+      if (ck < nchunk) {
+        bf16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float xh = ((float)xv[r][i][j] - mean) * rstd;
+          float rr = rstd * ((float)dv[r][i][j] * (j < 4 ? g0[i][j] : g1[i][j - 4]) - s1 - xh * s2);
+          if (add) rr += (float)av[r][i][j];
+          o[j] = (bf16)rr;
+        }
+        *(bf16x8*)(dx + (long long)(row0 + r) * C + ck * 8) = o;
       }
-      *(bf16x8*)(dx + (long long)row * C + ck * 8) = o;
     }
   }
 }
@@ -376,7 +414,7 @@ int launch_layernorm_fwd(const bf16* x, const float* gamma, const float* beta, b
   SHAPECHK(C % 8 == 0 && C <= 64 * 8 * LN_MAXCH, "layernorm: C=%d unsupported", C);
   PROF_BEGIN(5, 0.0, 4.0 * R * (double)C, s);
   const int nch = cdiv(C / 8, 64);          // 16-byte chunks per lane: the row lives in registers
-#define LN_FWD(N) hipLaunchKernelGGL(ln_fwd_kernel<N>, dim3(cdiv(R, 4)), dim3(256), 0, s, x, gamma, beta, y, stats, R, C, eps)
+#define LN_FWD(N) hipLaunchKernelGGL(ln_fwd_kernel<N>, dim3(cdiv(R, 4 * LN_NR)), dim3(256), 0, s, x, gamma, beta, y, stats, R, C, eps)
   if (nch <= 1) LN_FWD(1); else if (nch == 2) LN_FWD(2); else if (nch == 3) LN_FWD(3); else if (nch == 4) LN_FWD(4); else LN_FWD(8);
 #undef LN_FWD
   PROF_END(s);
@@ -406,7 +444,7 @@ int launch_layernorm_bwd(const bf16* x, const bf16* dy, const float* gamma, cons
   SHAPECHK(C % 8 == 0 && C <= 64 * 8 * LN_MAXCH, "layernorm: C=%d unsupported", C);
   PROF_BEGIN(5, 0.0, 6.0 * R * (double)C, s);
   const int nch = cdiv(C / 8, 64);
-#define LN_BWD(N) hipLaunchKernelGGL(ln_bwd_kernel<N>, dim3(cdiv(R, 4)), dim3(256), 0, s, x, dy, gamma, stats, dx, dgamma, dbeta, R, C, add)
+#define LN_BWD(N) hipLaunchKernelGGL(ln_bwd_kernel<N>, dim3(cdiv(R, 4 * LN_NR)), dim3(256), 0, s, x, dy, gamma, stats, dx, dgamma, dbeta, R, C, add)
   if (dx) { if (nch <= 1) LN_BWD(1); else if (nch == 2) LN_BWD(2); else if (nch == 3) LN_BWD(3); else if (nch == 4) LN_BWD(4); else LN_BWD(8); }
 #undef LN_BWD
   if (dgamma) hipLaunchKernelGGL(ln_param_grad_kernel, dim3(cdiv(C, 64)), dim3(64), 0, s, x, dy, stats, dgamma, dbeta, R, C);
