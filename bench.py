@@ -280,7 +280,7 @@ def main():
         g_fl = sum(x["flops"] for x in gem)
         g_n = sum(x["launches"] for x in gem)
         ach = g_fl / (g_ms * 1e-3) / 1e12 if g_ms > 0 else 0.0
-        roof = {"bound": "mfma", "kernel": "gemm_bf16_kernel (plain + implicit-GEMM conv3x3)",
+        roof = {"bound": "mfma", "kernel": "gemm_lc_kernel / gemm_lcp_kernel (plain + implicit-GEMM conv3x3)",
                 "achieved": round(ach, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(ach / MFMA_PEAK_TFLOPS, 4), "traffic": pmc_traffic(),
                 "launches_per_step": g_n // nprof, "avg_launch_us": round(g_ms * 1e3 / max(g_n, 1), 2),

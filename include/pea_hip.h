@@ -285,7 +285,6 @@ int pea_prof_report(int fam, double* ms, double* flops, double* bytes, long long
 void pea_debug_set_attn_tr(int v);
 /* benchmark aid: force GEMM tile variant (>= 0) or restore the shape-based choice (-1) */
 void pea_debug_set_gemm_variant(int v);
-void pea_debug_set_gemm_lds_epilogue(int v);
 /* timing-only probes of the loader/consumer GEMM (results are wrong while set): 1 no DMA, 2 no barriers, 4 no ds_reads */
 void pea_debug_set_gemm_debug(int v);
 

@@ -4,16 +4,15 @@
 // train_sdxl_zh.py:397,415 (Linear layers, ResBlock conv3x3, up/down-sample convs) and
 // the adapter Linears of train_sdxl_zh.py:48-55.
 //
-// Structure (round 1): 128x128x64 block tile, 4 waves (2x2), each wave a 64x64 sub-tile as
-// 2x2 v_mfma_f32_32x32x16_bf16; both operands K-contiguous ("NT"), staged global->LDS with
-// global_load_lds_dwordx4 (LDS-DMA, 1 KiB per wave instruction) into a 2-stage ring;
-// the LDS image is linear, the XOR swizzle (chunk ^ ((row>>1)&7)) is applied to the SOURCE
-// address and to the ds_read_b128 address, which makes the 32x32x16 fragment reads of
-// 128-byte rows bank-conflict free.  The MFMA is issued with weights as the A operand
-// and activations as the B operand, so each lane ends with 4 consecutive output columns
-// of one output row -> 8-byte packed bf16 stores and vector bias/residual loads.
-// Workgroup ids are remapped XCD-aware (blocks b, b+8 share an L2) and grouped 8 M-tiles
-// per N-tile so the 64 tiles resident on one XCD share operand panels.
+// Structure: BM x BN x 64 block tiles (128x160, 256x160, 128x128, 256x128, 64x160) of v_mfma_f32_16x16x32_bf16; both
+// operands K-contiguous ("NT"), staged global->LDS with global_load_lds_dwordx4 (LDS-DMA, 1 KiB per wave
+// instruction) by dedicated loader waves into an S-stage ring; the LDS image is linear, the XOR swizzle
+// (chunk ^ ((row>>1)&7)) is applied to the SOURCE address and to the ds_read_b128 address, which makes the fragment
+// reads of 128-byte rows bank-conflict free.  The MFMA is issued with weights as the A operand and activations as
+// the B operand, so each lane ends with 4 consecutive output columns of one output row -> packed bf16 stores and
+// vector bias/residual loads.  gemm_lc_kernel: one tile per workgroup; gemm_lcp_kernel: persistent, one workgroup
+// per CU walking its tiles (XCD-aware order, 8 M-tiles grouped per N-tile so the tiles resident on one XCD share
+// operand panels).  DESIGN.md section 4 has the measured variant table and what was tried and dropped.
 #include <stdlib.h>
 
 #include "pea_kernels.h"
@@ -99,100 +98,6 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x16 (&acc)[NI][
           for (int j = 0; j < 4; ++j) o[j] = (bf16)v[j];
           *(bf16x4*)((bf16*)p.C + (long long)m * p.ldc + n) = o;
         }
-      }
-    }
-  }
-}
-
-// ---- coalesced epilogue: the fp32 accumulator tile (after alpha / bias / row vector / activation) is transposed
-// through LDS (the ring is free after the K loop) so the residual loads and the output stores are row-contiguous,
-// 16 bytes per lane, instead of 8-byte accesses scattered over 32 rows per instruction.  One rounding to bf16.
-// Rows are processed in chunks of CR so that CR x (BN+4) floats fit the ring.  NT = number of consumer threads.
-template <int MI, int NI, int BM, int BN, int WM, int WN>
-__device__ __forceinline__ void gemm_epilogue_lds(const GemmP& p, f32x16 (&acc)[NI][MI], char* smem, int ring_bytes,
-                                                  int bm, int bn, int wr, int wc, int frow, int fh, int ctid) {
-  constexpr int LDT = BN + 4;                       // padded row stride (floats): conflict-free b128 writes
-  constexpr int NT = WM * WN * 64;
-  constexpr int WTM = BM / WM, WTN = BN / WN;
-  float* ct = (float*)smem;
-  int CR = ring_bytes / (LDT * 4);
-  CR = CR >= BM ? BM : (CR / 32) * 32;
-  for (int r0 = 0; r0 < BM; r0 += CR) {
-    __syncthreads();                                // ring (or the previous chunk) no longer read by anyone
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi) {
-      const int lrow = wr * WTM + mi * 32 + frow;   // row inside the block tile
-      if (lrow < r0 || lrow >= r0 + CR) continue;
-      const int m = bm * BM + lrow;
-      const int bidx = (p.rowvec && m < p.M) ? m / p.rows_per_batch : 0;
-#pragma unroll
-      for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const int lcol = wc * WTN + ni * 32 + 8 * g + 4 * fh;
-          const int n = bn * BN + lcol;
-          f32x4 v;
-#pragma unroll
-          for (int j = 0; j < 4; ++j) v[j] = acc[ni][mi][4 * g + j] * p.alpha;
-          if (n < p.N) {
-            if (p.bias) {
-              const f32x4 b = *(const f32x4*)(p.bias + n);
-#pragma unroll
-              for (int j = 0; j < 4; ++j) v[j] += b[j];
-            }
-            if (p.rowvec && m < p.M) {
-              const bf16x4 rv = *(const bf16x4*)(p.rowvec + (long long)bidx * p.ldrv + n);
-#pragma unroll
-              for (int j = 0; j < 4; ++j) v[j] += (float)rv[j];
-            }
-            if (p.act == 1) {
-#pragma unroll
-              for (int j = 0; j < 4; ++j) v[j] = gelu_erf(v[j]);
-            } else if (p.act == 2) {
-#pragma unroll
-              for (int j = 0; j < 4; ++j) v[j] = siluf_(v[j]);
-            }
-          }
-          *(f32x4*)(ct + (lrow - r0) * LDT + lcol) = v;
-        }
-    }
-    __syncthreads();
-    constexpr int CPR = BN / 8;                     // 8-element chunks per row
-    const int rows_here = CR < BM - r0 ? CR : BM - r0;
-    const int nchunks = rows_here * CPR;
-    for (int c = ctid; c < nchunks; c += NT) {
-      const int row = c / CPR, c8 = (c - row * CPR) * 8;
-      const int m = bm * BM + r0 + row, n = bn * BN + c8;
-      if (m >= p.M || n >= p.N) continue;
-      const f32x4 lo = *(const f32x4*)(ct + row * LDT + c8), hi = *(const f32x4*)(ct + row * LDT + c8 + 4);
-      float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-      if (p.res) {
-        const bf16x8 rr = *(const bf16x8*)(p.res + (long long)m * p.ldres + n);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] += (float)rr[j];
-      }
-      if (p.out_f32) {
-        float* cp = (float*)p.C + (long long)m * p.ldc + n;
-        f32x4 o0, o1;
-        if (p.accum_f32) {
-          o0 = *(const f32x4*)cp;
-          o1 = *(const f32x4*)(cp + 4);
-        } else {
-          o0 = (f32x4){0.f, 0.f, 0.f, 0.f};
-          o1 = o0;
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          o0[j] += v[j];
-          o1[j] += v[4 + j];
-        }
-        *(f32x4*)cp = o0;
-        *(f32x4*)(cp + 4) = o1;
-      } else {
-        bf16x8 o;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) o[j] = (bf16)v[j];
-        *(bf16x8*)((bf16*)p.C + (long long)m * p.ldc + n) = o;
       }
     }
   }
@@ -343,340 +248,6 @@ __device__ __forceinline__ void gemm_epilogue16_lean(const GemmP& p, f32x4 (&acc
       }
     }
   }
-}
-
-// Block tile BM x BN x 64, WM x WN waves (each (BM/WM) x (BN/WN), built from 32x32x16 MFMAs), S-stage LDS
-// ring filled by LDS-DMA with a counted vmcnt: tile t+S-1 is issued while tile t is consumed, ONE raw
-// s_barrier per K-step (it orders "tile t landed for every wave" and "everyone finished tile t-1").
-template <int MODE, int BM, int BN, int WM, int WN, int S>
-__global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmP p) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int NW = WM * WN;
-  constexpr int STAGE = (BM + BN) * 128;
-  constexpr int A_BYTES = BM * 128;
-  constexpr int PA = BM / 8 / NW, PB = BN / 8 / NW;     // 1-KiB LDS-DMA pieces per wave per tile
-  constexpr int P = PA + PB;
-  constexpr int MI = BM / WM / 32, NI = BN / WN / 32;
-  static_assert(BM % (8 * NW) == 0 && BN % (8 * NW) == 0, "tile / wave split");
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wr = wave / WN, wc = wave % WN;
-
-  // ---- XCD-aware, grouped tile mapping (bijective for any grid size)
-  const int nbm = (p.M + BM - 1) / BM, nbn = (p.N + BN - 1) / BN;
-  const int nwg = nbm * nbn;
-  int bid = blockIdx.x;
-  {
-    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
-    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-  }
-  const int GROUP = 8;
-  const int per_group = GROUP * nbn;
-  const int gid = bid / per_group;
-  const int first_m = gid * GROUP;
-  const int gsize = min(nbm - first_m, GROUP);
-  const int bm = first_m + (bid % per_group) % gsize;
-  const int bn = (bid % per_group) / gsize;
-
-  // ---- per-thread staging descriptors: PA A rows + PB W rows, one 16-byte chunk each
-  const int lrow = lane >> 3;              // row within an 8-row LDS-DMA piece
-  const int cpos = lane & 7;               // chunk position inside the LDS row
-  const bf16* a_src[PA];
-  int a_iy0[PA], a_ix0[PA];                // conv: virtual-input origin of the 3x3 window
-  const bf16* w_src[PB];
-#pragma unroll
-  for (int j = 0; j < PA; ++j) {
-    const int r = (wave * PA + j) * 8 + lrow;
-    const int chunk = cpos ^ ((r >> 1) & 7);            // source chunk that lands at position cpos
-    int gm = bm * BM + r;
-    gm = gm < p.M ? gm : p.M - 1;
-    if (MODE == 0) {
-      a_src[j] = p.A + (long long)gm * p.lda + chunk * 8;
-      a_iy0[j] = a_ix0[j] = 0;
-    } else {
-      const int hw = p.Ho * p.Wo;
-      const int b = gm / hw;
-      const int rem = gm - b * hw;
-      const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
-      a_iy0[j] = oy * p.stride - 1 + p.pad_off;
-      a_ix0[j] = ox * p.stride - 1 + p.pad_off;
-      a_src[j] = p.A + (long long)b * p.Hs * p.Ws * p.Cin + chunk * 8;
-    }
-  }
-#pragma unroll
-  for (int j = 0; j < PB; ++j) {
-    const int r = (wave * PB + j) * 8 + lrow;
-    const int chunk = cpos ^ ((r >> 1) & 7);
-    int gn = bn * BN + r;
-    gn = gn < p.N ? gn : p.N - 1;
-    w_src[j] = p.W + (long long)gn * p.ldw + chunk * 8;
-  }
-  const int Hv = p.Hs << p.shift, Wv = p.Ws << p.shift;
-
-  auto stage = [&](int st, int k0) {
-    char* base = smem + st * STAGE;
-    int ky = 0, kx = 0, c0 = 0;
-    if (MODE == 1) {
-      const int tap = k0 / p.Cin;
-      c0 = k0 - tap * p.Cin;
-      ky = tap / 3;
-      kx = tap - ky * 3;
-    }
-#pragma unroll
-    for (int j = 0; j < PA; ++j) {
-      const bf16* src;
-      if (MODE == 0) {
-        src = a_src[j] + k0;
-      } else {
-        const int iy = a_iy0[j] + ky, ix = a_ix0[j] + kx;
-        bool ok = ((unsigned)iy < (unsigned)Hv) && ((unsigned)ix < (unsigned)Wv);
-        if (p.parity) ok = ok && (((iy | ix) & 1) == 0);
-        const int sy = iy >> p.shift, sx = ix >> p.shift;
-        src = ok ? a_src[j] + ((long long)sy * p.Ws + sx) * p.Cin + c0 : p.zeros;
-      }
-      __builtin_amdgcn_global_load_lds(PEA_GLB(src), PEA_LDS(base + (wave * PA + j) * 1024), 16, 0, 0);
-    }
-#pragma unroll
-    for (int j = 0; j < PB; ++j)
-      __builtin_amdgcn_global_load_lds(PEA_GLB(w_src[j] + k0), PEA_LDS(base + A_BYTES + (wave * PB + j) * 1024), 16,
-                                       0, 0);
-  };
-
-  f32x16 acc[NI][MI];
-#pragma unroll
-  for (int i = 0; i < NI; ++i)
-#pragma unroll
-    for (int j = 0; j < MI; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-  const int nt = p.K / BK;
-#pragma unroll
-  for (int i = 0; i < S - 1; ++i)
-    if (i < nt) stage(i, i * BK);
-
-  const int frow = lane & 31, fh = lane >> 5;
-  int cur = 0;
-  for (int t = 0; t < nt; ++t) {
-    // tile t must have landed: tiles t+1 .. t+S-2 (P loads each) may stay in flight
-    if (t + S - 2 < nt) wait_vmcnt<(S - 2) * P>();
-    else wait_vmcnt<0>();
-    __builtin_amdgcn_s_barrier();
-    if (t + S - 1 < nt) {
-      int nb = cur + S - 1;
-      nb = nb >= S ? nb - S : nb;
-      stage(nb, (t + S - 1) * BK);
-    }
-    const char* As = smem + cur * STAGE;
-    const char* Ws = As + A_BYTES;
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      bf16x8 af[MI], wf[NI];
-#pragma unroll
-      for (int mi = 0; mi < MI; ++mi) af[mi] = *(const bf16x8*)(As + swz_off(wr * (BM / WM) + mi * 32 + frow, 2 * s + fh));
-#pragma unroll
-      for (int ni = 0; ni < NI; ++ni) wf[ni] = *(const bf16x8*)(Ws + swz_off(wc * (BN / WN) + ni * 32 + frow, 2 * s + fh));
-#pragma unroll
-      for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi)
-          acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ni], af[mi], acc[ni][mi], 0, 0, 0);
-    }
-    cur = cur + 1 == S ? 0 : cur + 1;
-  }
-
-  gemm_epilogue<MI, NI>(p, acc, bm * BM + wr * (BM / WM), bn * BN + wc * (BN / WN), frow, fh);
-}
-
-// ------------------------------------------------------------------------------------------------
-// Software-pipelined kernel.  Same tiling / LDS image as above, but inside a K-step (4 k16 sub-steps):
-//   * fragments are double-buffered in registers: sub-step s issues the ds_reads of sub-step s+1
-//     (or of the next tile's sub-step 0) before its own MFMAs, so LDS latency hides under MFMA time;
-//   * the LDS-DMA pieces of tile t+S-1 are spread over sub-steps 0..2 instead of being issued in one
-//     burst, so their issue slots sit behind already-queued MFMAs of the same wave;
-//   * the single barrier of the K-step sits before sub-step 3's prefetch of the NEXT tile: "tile t+1
-//     landed for every wave" and "every wave has issued all its reads of tile t-1 / t".
-// BN may be 160 (5 x 32): every SDXL width is a multiple of 160, so 128x160 / 256x160 tiles cover the
-// M = 4096 / 8192 GEMMs of the 32^2 level with exactly 256 workgroups (one per CU).
-template <int MODE, int BM, int BN, int WM, int WN, int S>
-__global__ __launch_bounds__(WM * WN * 64) void gemm_pipe_kernel(const GemmP p) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int NW = WM * WN;
-  constexpr int STAGE = (BM + BN) * 128;
-  constexpr int A_BYTES = BM * 128;
-  constexpr int PA = BM / 8 / NW, PB = BN / 8 / NW;
-  constexpr int PP = PA + PB;
-  constexpr int MI = BM / WM / 32, NI = BN / WN / 32;
-  static_assert(BM % (8 * NW) == 0 && BN % (8 * NW) == 0, "tile / wave split");
-  static_assert((BM / WM) % 32 == 0 && (BN / WN) % 32 == 0, "wave tile");
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wr = wave / WN, wc = wave % WN;
-
-  const int nbm = (p.M + BM - 1) / BM, nbn = (p.N + BN - 1) / BN;
-  const int nwg = nbm * nbn;
-  int bid = blockIdx.x;
-  {
-    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
-    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-  }
-  const int GROUP = 8;
-  const int per_group = GROUP * nbn;
-  const int gid = bid / per_group;
-  const int first_m = gid * GROUP;
-  const int gsize = min(nbm - first_m, GROUP);
-  const int bm = first_m + (bid % per_group) % gsize;
-  const int bn = (bid % per_group) / gsize;
-
-  const int lrow = lane >> 3, cpos = lane & 7;
-  const bf16* a_src[PA];
-  int a_iy0[PA], a_ix0[PA];
-  const bf16* w_src[PB];
-#pragma unroll
-  for (int j = 0; j < PA; ++j) {
-    const int r = (wave * PA + j) * 8 + lrow;
-    const int chunk = cpos ^ ((r >> 1) & 7);
-    int gm = bm * BM + r;
-    gm = gm < p.M ? gm : p.M - 1;
-    if (MODE == 0) {
-      a_src[j] = p.A + (long long)gm * p.lda + chunk * 8;
-      a_iy0[j] = a_ix0[j] = 0;
-    } else {
-      const int hw = p.Ho * p.Wo;
-      const int b = gm / hw;
-      const int rem = gm - b * hw;
-      const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
-      a_iy0[j] = oy * p.stride - 1 + p.pad_off;
-      a_ix0[j] = ox * p.stride - 1 + p.pad_off;
-      a_src[j] = p.A + (long long)b * p.Hs * p.Ws * p.Cin + chunk * 8;
-    }
-  }
-#pragma unroll
-  for (int j = 0; j < PB; ++j) {
-    const int r = (wave * PB + j) * 8 + lrow;
-    const int chunk = cpos ^ ((r >> 1) & 7);
-    int gn = bn * BN + r;
-    gn = gn < p.N ? gn : p.N - 1;
-    w_src[j] = p.W + (long long)gn * p.ldw + chunk * 8;
-  }
-  const int Hv = p.Hs << p.shift, Wv = p.Ws << p.shift;
-
-  // issue the LDS-DMA pieces [j0, j1) of the tile whose K offset is k0 into ring slot `st`
-  auto issue = [&](int st, int k0, int j0, int j1) {
-    char* base = smem + st * STAGE;
-    int ky = 0, kx = 0, c0 = 0;
-    if (MODE == 1) {
-      const int tap = k0 / p.Cin;
-      c0 = k0 - tap * p.Cin;
-      ky = tap / 3;
-      kx = tap - ky * 3;
-    }
-#pragma unroll
-    for (int j = 0; j < PP; ++j) {
-      if (j < j0 || j >= j1) continue;
-      if (j < PA) {
-        const bf16* src;
-        if (MODE == 0) {
-          src = a_src[j] + k0;
-        } else {
-          const int iy = a_iy0[j] + ky, ix = a_ix0[j] + kx;
-          bool ok = ((unsigned)iy < (unsigned)Hv) && ((unsigned)ix < (unsigned)Wv);
-          if (p.parity) ok = ok && (((iy | ix) & 1) == 0);
-          const int sy = iy >> p.shift, sx = ix >> p.shift;
-          src = ok ? a_src[j] + ((long long)sy * p.Ws + sx) * p.Cin + c0 : p.zeros;
-        }
-        __builtin_amdgcn_global_load_lds(PEA_GLB(src), PEA_LDS(base + (wave * PA + j) * 1024), 16, 0, 0);
-      } else {
-        const int jb = j - PA;
-        __builtin_amdgcn_global_load_lds(PEA_GLB(w_src[jb] + k0), PEA_LDS(base + A_BYTES + (wave * PB + jb) * 1024),
-                                         16, 0, 0);
-      }
-    }
-  };
-
-  f32x16 acc[NI][MI];
-#pragma unroll
-  for (int i = 0; i < NI; ++i)
-#pragma unroll
-    for (int j = 0; j < MI; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-  const int nt = p.K / BK;
-  const int frow = lane & 31, fh = lane >> 5;
-  const int a_row0 = wr * (BM / WM) + frow, w_row0 = wc * (BN / WN) + frow;
-#pragma unroll
-  for (int i = 0; i < S - 1; ++i)
-    if (i < nt) issue(i, i * BK, 0, PP);
-  if (nt >= S - 1) wait_vmcnt<(S - 2) * PP>();
-  else wait_vmcnt<0>();
-  __builtin_amdgcn_s_barrier();
-
-  bf16x8 af[2][MI], wf[2][NI];
-  auto load_frags = [&](int which, const char* tile, int s) {
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi) af[which][mi] = *(const bf16x8*)(tile + swz_off(a_row0 + mi * 32, 2 * s + fh));
-#pragma unroll
-    for (int ni = 0; ni < NI; ++ni)
-      wf[which][ni] = *(const bf16x8*)(tile + A_BYTES + swz_off(w_row0 + ni * 32, 2 * s + fh));
-  };
-  load_frags(0, smem, 0);
-
-  constexpr int J1 = (PP + 2) / 3, J2 = (2 * PP + 2) / 3;     // piece ranges of the three issue slots
-  int cur = 0;
-  for (int t = 0; t < nt; ++t) {
-    const char* tile = smem + cur * STAGE;
-    int nxt = cur + 1 == S ? 0 : cur + 1;
-    int refill = cur == 0 ? S - 1 : cur - 1;                   // ring slot of tile t-1 == slot of tile t+S-1
-    const bool more = t + S - 1 < nt;
-    const int kf = (t + S - 1) * BK;
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      if (s == 3) {
-        if (t + 1 < nt) {
-          if (more) wait_vmcnt<(S - 2) * PP>();
-          else wait_vmcnt<0>();
-          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-          __builtin_amdgcn_s_barrier();
-          load_frags((s + 1) & 1, smem + nxt * STAGE, 0);
-        }
-      } else {
-        load_frags((s + 1) & 1, tile, s + 1);
-      }
-      if (more) {
-        if (s == 0) issue(refill, kf, 0, J1);
-        else if (s == 1) issue(refill, kf, J1, J2);
-        else if (s == 2) issue(refill, kf, J2, PP);
-      }
-#pragma unroll
-      for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi)
-          acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[s & 1][ni], af[s & 1][mi], acc[ni][mi], 0, 0, 0);
-    }
-    cur = nxt;
-  }
-  if (p.lds_epilogue)
-    gemm_epilogue_lds<MI, NI, BM, BN, WM, WN>(p, acc, smem, S * STAGE, bm, bn, wr, wc, frow, fh, tid);
-  else
-    gemm_epilogue<MI, NI>(p, acc, bm * BM + wr * (BM / WM), bn * BN + wc * (BN / WN), frow, fh);
-}
-
-template <int MODE, int BM, int BN, int WM, int WN, int S>
-static int launch_pipe(const GemmP& p, hipStream_t stream) {
-  constexpr int lds = S * (BM + BN) * 128;
-  static_assert(lds <= 160 * 1024, "LDS budget");
-  static bool attr_set = false;
-  if (!attr_set) {
-    HIPCHK(hipFuncSetAttribute((const void*)gemm_pipe_kernel<MODE, BM, BN, WM, WN, S>,
-                               hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    attr_set = true;
-  }
-  const int grid = cdiv(p.M, BM) * cdiv(p.N, BN);
-  hipLaunchKernelGGL((gemm_pipe_kernel<MODE, BM, BN, WM, WN, S>), dim3(grid), dim3(WM * WN * 64), lds, stream, p);
-  return PEA_OK;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -923,10 +494,7 @@ __global__ __launch_bounds__((WM * WN + LW) * 64, MINW) void gemm_lc_kernel(cons
     gemm_epilogue<MI, NI>(q, acc, bm * BM + wr * (BM / WM), bn * BN + wc * (BN / WN), frow, fh);
     return;
   }
-  if (p.lds_epilogue)
-    gemm_epilogue_lds<MI, NI, BM, BN, WM, WN>(p, acc, smem, S * STAGE, bm, bn, wr, wc, frow, fh, tid);
-  else
-    gemm_epilogue<MI, NI>(p, acc, bm * BM + wr * (BM / WM), bn * BN + wc * (BN / WN), frow, fh);
+  gemm_epilogue<MI, NI>(p, acc, bm * BM + wr * (BM / WM), bn * BN + wc * (BN / WN), frow, fh);
 }
 
 template <int MODE, int BM, int BN, int WM, int WN, int LW, int S, bool PROBE16 = false, bool M16 = false, int MINW = 1>
@@ -1290,48 +858,15 @@ static int launch_lcp(const GemmP& p, hipStream_t stream) {
 int g_gemm_variant = -1;   // >= 0: forced (benchmark / debug)
 extern "C" void pea_debug_set_gemm_variant(int v) { g_gemm_variant = v; }
 
-template <int MODE, int BM, int BN, int WM, int WN, int S>
-static int launch_variant(const GemmP& p, hipStream_t stream) {
-  constexpr int lds = S * (BM + BN) * 128;
-  static bool attr_set = false;
-  if (!attr_set) {
-    HIPCHK(hipFuncSetAttribute((const void*)gemm_bf16_kernel<MODE, BM, BN, WM, WN, S>,
-                               hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    attr_set = true;
-  }
-  const int grid = cdiv(p.M, BM) * cdiv(p.N, BN);
-  hipLaunchKernelGGL((gemm_bf16_kernel<MODE, BM, BN, WM, WN, S>), dim3(grid), dim3(WM * WN * 64), lds, stream, p);
-  return PEA_OK;
-}
-
 #define GEMM_VARIANTS(MODE)                                              \
   switch (v) {                                                           \
-    case 0: rc = launch_variant<MODE, 128, 128, 2, 2, 2>(p, stream); break; \
-    case 1: rc = launch_variant<MODE, 128, 128, 2, 2, 3>(p, stream); break; \
-    case 2: rc = launch_variant<MODE, 128, 128, 2, 2, 4>(p, stream); break; \
-    case 3: rc = launch_variant<MODE, 256, 128, 4, 2, 2>(p, stream); break; \
-    case 4: rc = launch_variant<MODE, 256, 128, 4, 2, 3>(p, stream); break; \
-    case 5: rc = launch_variant<MODE, 256, 256, 2, 4, 2>(p, stream); break; \
-    case 6: rc = launch_variant<MODE, 128, 256, 2, 4, 3>(p, stream); break; \
-    case 7: rc = launch_variant<MODE, 256, 128, 2, 2, 3>(p, stream); break; \
-    case 8: rc = launch_pipe<MODE, 128, 160, 4, 1, 4>(p, stream); break; \
-    case 9: rc = launch_pipe<MODE, 256, 160, 4, 1, 3>(p, stream); break; \
-    case 10: rc = launch_pipe<MODE, 256, 128, 4, 2, 3>(p, stream); break; \
-    case 11: rc = launch_pipe<MODE, 128, 128, 2, 2, 3>(p, stream); break; \
-    case 12: rc = launch_pipe<MODE, 256, 256, 2, 4, 2>(p, stream); break; \
-    case 13: rc = launch_pipe<MODE, 128, 160, 4, 1, 3>(p, stream); break; \
-    case 14: rc = launch_lc<MODE, 128, 160, 4, 1, 4, 4>(p, stream); break; \
-    case 15: rc = launch_lc<MODE, 256, 160, 4, 1, 4, 3>(p, stream); break; \
-    case 16: rc = launch_lc<MODE, 256, 128, 4, 2, 4, 3>(p, stream); break; \
     case 18: rc = launch_lc<MODE, 128, 128, 2, 2, 4, 4>(p, stream); break; \
     case 19: rc = launch_lc<MODE, 128, 160, 4, 1, 4, 3>(p, stream); break; \
     case 20: rc = launch_lc<MODE, 128, 160, 4, 1, 4, 3, true>(p, stream); break; /* timing probe only */ \
-    case 21: rc = launch_lc<MODE, 128, 160, 2, 2, 4, 3, false, true>(p, stream); break; \
     case 22: rc = launch_lc<MODE, 128, 160, 2, 2, 4, 4, false, true>(p, stream); break; \
     case 23: rc = launch_lc<MODE, 128, 128, 2, 2, 4, 4, false, true>(p, stream); break; \
     case 24: rc = launch_lc<MODE, 256, 160, 4, 2, 4, 3, false, true>(p, stream); break; \
     case 25: rc = launch_lc<MODE, 128, 160, 4, 2, 4, 3, false, true>(p, stream); break; \
-    case 26: rc = launch_lc<MODE, 128, 160, 4, 2, 4, 4, false, true>(p, stream); break; \
     case 27: rc = launch_lcp<MODE, 256, 160, 4, 2, 4, 3>(p, stream); break; \
     case 28: rc = launch_lcp<MODE, 128, 160, 4, 2, 4, 3>(p, stream); break; \
     case 29: rc = launch_lcp<MODE, 128, 160, 2, 2, 4, 4>(p, stream); break; \
@@ -1340,7 +875,7 @@ static int launch_variant(const GemmP& p, hipStream_t stream) {
     case 33: rc = launch_lcp<MODE, 256, 128, 4, 2, 4, 3>(p, stream); break; \
     case 34: rc = launch_lcp<MODE, 128, 160, 4, 2, 4, 3, 4>(p, stream); break; /* staged epilogue */ \
     case 35: rc = launch_lcp<MODE, 128, 160, 4, 2, 4, 3, 0, 1>(p, stream); break; /* deferred epilogue */ \
-    default: rc = launch_variant<MODE, 128, 128, 2, 2, 2>(p, stream); break; \
+    default: rc = launch_lc<MODE, 128, 128, 2, 2, 4, 4, false, true>(p, stream); break; \
   }
 
 static int pick_variant(const GemmP& p) {
@@ -1370,13 +905,15 @@ static int pick_variant(const GemmP& p) {
                     p.ldc % 8 == 0 && (((unsigned long long)p.C & 15) == 0);
   if (t128 <= 256) return lean ? 35 : 25;            // exactly one 128x160 tile per CU
   if (t256 <= 256) return t256 > 192 ? 24 : (lean ? 35 : 28);
-  return p.N >= 5120 ? 27 : (lean ? 35 : 28);
+  // more than one 256x160 tile per CU: the large tile wins (less L2 -> LDS traffic per flop) unless its tile count
+  // leaves the last round of CUs mostly idle (e.g. 384 tiles = 1.5 rounds), then the 128x160 form balances better
+  const int rounds = cdiv(t256, 256);
+  if (t256 * 100 >= rounds * 256 * 85) return 27;
+  return lean ? 35 : 28;
 }
 
 int g_gemm_debug = 0;
 extern "C" void pea_debug_set_gemm_debug(int v) { g_gemm_debug = v; }
-int g_gemm_lds_epilogue = 0;   // measured round 1: a net loss in situ (multi-pass on 256-wide tiles); kept for experiments
-extern "C" void pea_debug_set_gemm_lds_epilogue(int v) { g_gemm_lds_epilogue = v; }
 
 int launch_gemm(const GemmP& p_in, hipStream_t stream) {
   const GemmP& p0 = p_in;
@@ -1400,12 +937,10 @@ int launch_gemm(const GemmP& p_in, hipStream_t stream) {
   }
   GemmP p = p_in;
   p.debug = g_gemm_debug;
-  p.lds_epilogue = (g_gemm_lds_epilogue && !p.geglu_y && p.N % 8 == 0 && !p.preact && p.ldc % 8 == 0 && (!p.res || p.ldres % 8 == 0)) ? 1 : 0;
   int v = pick_variant(p);
   if (p.ksplit > 1) {
     SHAPECHK(p.out_f32 && !p.accum_f32 && !p.bias && !p.res && !p.rowvec && !p.preact && p.act == 0 && p.mode == 0,
              "gemm: split-K writes plain fp32 partials");
-    p.lds_epilogue = 0;
     v = 18;                                         // loader/consumer 128x128 (the only kernel with the K-split path)
   }
   int rc = PEA_OK;

@@ -27,7 +27,6 @@ struct GemmP {
   int shift;                       // virtual input = source upsampled by 2^shift (nearest) / zero-stuffed
   int parity;                      // 1: only even virtual coordinates are real (transposed stride-2 conv)
   const bf16* zeros;               // >= 16 bytes of zeros (out-of-bounds taps)
-  int lds_epilogue;                // set by launch_gemm: transpose the tile through LDS for coalesced stores
   int debug;                       // timing experiments only (scripts/gemm_loop_probe.py)
   // fused GEGLU: the weight rows are interleaved (h_i, gate_i) so a lane's 4 consecutive columns are two pairs;
   // geglu_y[m][n/2] = h * gelu(gate).  C may be null then (no pre-activation stash: teacher / inference).

@@ -11,7 +11,7 @@ int g_prof_on = 0;
 static std::vector<ProfRec> g_recs;
 static std::vector<hipEvent_t> g_pool;
 static size_t g_pool_next = 0;
-static const char* kFam[PEA_PROF_FAMILIES] = {"gemm_bf16_kernel<plain>", "gemm_bf16_kernel<conv3x3>", "attn_fwd",
+static const char* kFam[PEA_PROF_FAMILIES] = {"gemm_lc[p]_kernel<plain>", "gemm_lc[p]_kernel<conv3x3>", "attn_fwd",
                                               "attn_bwd", "groupnorm", "layernorm", "elementwise", "kd_loss"};
 
 static hipEvent_t take_event() {

@@ -26,8 +26,12 @@ def timeit(fn, iters=20):
     e.record(); torch.cuda.synchronize()
     return s.elapsed_time(e) / iters * 1e-3
 
+MERGED = len(sys.argv) > 2 and sys.argv[2] == "merged"      # forward shapes of the merged passes (2B = 8 samples)
 shapes = [(8192, 1280, 1280), (8192, 1280, 5120), (8192, 10240, 1280), (4096, 1280, 1280), (4096, 1280, 5120), (4096, 3840, 1280), (4096, 10240, 1280), (16384, 640, 640),
           (16384, 640, 2560), (16384, 1920, 640), (16384, 5120, 640), (308, 2560, 2048), (4096, 1280, 2560), (8192, 8192, 8192)]
+if MERGED:
+    shapes = [(8192, 1280, 1280), (8192, 1280, 5120), (8192, 3840, 1280), (8192, 10240, 1280), (32768, 640, 640), (32768, 640, 2560),
+              (32768, 1920, 640), (32768, 5120, 640), (616, 2560, 2048)]
 print("variants:", {v: NAMES[v] for v in variants})
 for (M, N, K) in shapes:
     a = torch.randn(M, K, device="cuda").to(BF); w = (torch.randn(N, K, device="cuda") * K ** -0.5).to(BF)
@@ -41,7 +45,7 @@ for (M, N, K) in shapes:
         t = timeit(lambda: ops.gemm(a, w))
         line += f" v{v} {2*M*N*K/t/1e12:7.1f}{'' if err < 0.5 else ' ERR%.2g' % err}"
     print(line, flush=True)
-convs = [(4, 128, 320, 320), (4, 128, 960, 320), (4, 64, 640, 640), (4, 64, 1920, 640), (4, 32, 1280, 1280), (4, 32, 2560, 1280)]
+convs = [(8, 128, 320, 320), (8, 128, 960, 320), (8, 64, 640, 640), (8, 64, 1920, 640), (8, 32, 1280, 1280), (8, 32, 2560, 1280)] if MERGED else [(4, 128, 320, 320), (4, 128, 960, 320), (4, 64, 640, 640), (4, 64, 1920, 640), (4, 32, 1280, 1280), (4, 32, 2560, 1280)]
 for (B, H, Ci, Co) in convs:
     x = torch.randn(B, H, H, Ci, device="cuda").to(BF)
     w = (torch.randn(Co, Ci, 3, 3, device="cuda") * (9 * Ci) ** -0.5)

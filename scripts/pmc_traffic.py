@@ -12,7 +12,7 @@ def load(d, counter):
     return vals
 fetch, write = load(sys.argv[1], "FETCH_SIZE"), load(sys.argv[2], "WRITE_SIZE")
 out = {}
-for fam in ("gemm_lcp_kernel", "gemm_lc_kernel", "gemm_pipe_kernel", "gemm_bf16_kernel"):
+for fam in ("gemm_lcp_kernel", "gemm_lc_kernel"):
     fk = [v for k, vs in fetch.items() if fam in k for v in vs]
     wk = [v for k, vs in write.items() if fam in k for v in vs]
     if fk:

@@ -28,7 +28,7 @@ def test_header_parses_and_all_symbols_exported(built):
 
 def test_library_has_gfx950_code_object():
     data = open(_lib.LIB_PATH, "rb").read()
-    assert b"gfx950" in data and b"gemm_bf16_kernel" in data
+    assert b"gfx950" in data and b"gemm_lcp_kernel" in data
 
 
 def test_version_and_error_string(built):
