@@ -519,3 +519,86 @@ def test_sd15_full_size_step_vs_oracle(gpu):
     """BASELINE configs[0]: SD1.5 512x512 (batch 2 so that both mask values occur) -- full 859.5 M-parameter UNet, the whole KD step on the MI355X
     against the fp32 CPU oracle (train_sd_zh.py path; head dims 40/80/160)"""
     _sd15_step_check("sd15_config", B=2, L=77, hw=64, enc_dim=1024, hidden=2048, tol_fwd=3e-2, tol_grad=6e-2)
+
+
+def _fast_fill_(module, seed=0):
+    """deterministic weights without torch's single-threaded default init of 2.57 B parameters: every >= 2-D tensor is
+    filled from one seeded uniform buffer read at a per-tensor offset, scaled to variance 1/(3 fan_in); norm weights 1,
+    biases small"""
+    g = torch.Generator().manual_seed(seed)
+    buf = torch.rand(1 << 24, generator=g) - 0.5
+    off = 0
+    with torch.no_grad():
+        for n, p in module.named_parameters():
+            if p.dim() >= 2:
+                fan = p[0].numel()
+                flat = p.view(-1)
+                for o in range(0, flat.numel(), 1 << 22):
+                    k = min(1 << 22, flat.numel() - o)
+                    off = (off * 31 + 7919) % (buf.numel() - (1 << 22))
+                    flat[o:o + k].copy_(buf[off:off + k])
+                flat.mul_(2.0 * fan ** -0.5)
+            elif n.endswith("weight"):
+                p.fill_(1.0)
+            else:
+                p.copy_(0.02 * buf[:p.numel()])
+
+
+def test_sdxl_full_model_step_vs_oracle_512(gpu):
+    """The full 2.57 B-parameter SDXL UNet (BASELINE configs[1] model, 512x512 so the fp32 CPU oracle finishes in about a
+    minute; batch 2 so both mask values occur): the whole KD step -- merged passes, since the teacher is the student
+    checkpoint -- against the oracle: eps, the four logged scalars, the flat adapter gradient."""
+    import copy
+    from oracle import unet_ref as ou
+    from oracle.step_ref import AdapterRef, synthetic_batch, training_step_ref
+    from pea_diffusion_amd import config as pc
+    from pea_diffusion_amd.adapter import PEAAdapter
+    from pea_diffusion_amd.train import PEATrainer
+    from pea_diffusion_amd.unet import HipUNet
+    torch.set_num_threads(min(64, len(__import__("os").sched_getaffinity(0))))
+    cfg = ou.sdxl_config()
+    B, L, hw = 2, 77, 64
+    # build without the default init (torch.nn.init on 2.57 B parameters takes about a minute): allocate, then fill
+    orig = torch.nn.init.kaiming_uniform_, torch.nn.init.uniform_
+    torch.nn.init.kaiming_uniform_ = lambda t, *a, **k: t
+    torch.nn.init.uniform_ = lambda t, *a, **k: t
+    try:
+        us = ou.UNet2DConditionRef(cfg)
+    finally:
+        torch.nn.init.kaiming_uniform_, torch.nn.init.uniform_ = orig
+    _fast_fill_(us, seed=5)
+    round_weights_bf16_(us)
+    for p in us.parameters():
+        p.requires_grad_(False)
+    ut = copy.deepcopy(us)
+    torch.manual_seed(6)
+    ad_ref = AdapterRef(1024, cfg.pooled_dim, 1024, cfg.cross_attention_dim, False)
+    ad = PEAAdapter(1024, cfg.pooled_dim, 1024, cfg.cross_attention_dim, False)
+    ad.load_state_dict(ad_ref.state_dict())
+    ad = ad.cuda()
+    round_weights_bf16_(ad_ref)
+    hs = HipUNet(pc.sdxl_config(), B, hw, hw, L, needs_grad=True)
+    missing, unexpected = hs.load_state_dict(us.state_dict())
+    assert not missing and not unexpected
+    ht = HipUNet(pc.sdxl_config(), B, hw, hw, L, share_weights_from=hs)
+    batch = synthetic_batch(cfg, B, L=L, enc_dim=1024, seed=2, latent_hw=hw)
+    tr = PEATrainer(ad, hs, ht)
+    out = tr.training_step(batch, 0, sync=True)
+    assert lib_merge_state(tr) == 1
+    bq = dict(batch)
+    for k in ("enc", "enc_uncond", "teacher_ehs", "teacher_neg", "teacher_pooled"):
+        bq[k] = batch[k].to(torch.bfloat16).float()
+    ref = training_step_ref(ad_ref, us, ut, bq, ou.cast_hook_ref)
+    ref["loss"].backward()
+    e_s, e_t = rel_l2(tr.export("eps_student"), ref["noise_pred"]), rel_l2(tr.export("eps_teacher"), ref["noise_pred_teacher"])
+    print(f"[sdxl full model 512x512 step] eps_student rel_l2={e_s:.3e} eps_teacher rel_l2={e_t:.3e}")
+    assert e_s < 3e-2 and e_t < 3e-2
+    total = abs(float(ref["loss"]))
+    for k in tr.LOG_KEYS:
+        h, r = float(out[k]), float(ref[k])
+        print(f"   {k}: hip={h:.6f} oracle={r:.6f}")
+        assert abs(h - r) <= 2e-2 * abs(r) + 5e-3 * total, k
+    g_ref = torch.cat([p.grad.reshape(-1) for p in ad_ref.parameters()])
+    eg = rel_l2(ad.flat_grad, g_ref)
+    print(f"   adapter grad rel_l2={eg:.3e} |ref|={g_ref.norm():.3e}")
+    assert eg < 6e-2
