@@ -207,6 +207,12 @@ int pea_vae_encoder_create(const pea_unet_config* cfg, int B, int H, int W, void
 int pea_vae_latent_shape(void* vae, int* C, int* H, int* W);
 int pea_vae_encode(void* vae, const float* pixels, const float* noise, float scaling, float* moments, float* latents,
                    void* stream);
+/* VAE decoder (`image = self.vae.decode(latents / self.vae.config.scaling_factor, return_dict=False)[0]`,
+ * tests/test_sdxl_zh.py:430): cfg.in_channels = latent channels, out_channels = image channels, block_out = the
+ * AutoencoderKL block_out_channels; H x W = LATENT size; diffusers keys `decoder.*`, `post_quant_conv.*`.
+ * latents fp32 [B,4,h,w] (multiplied by inv_scaling first) -> image fp32 [B,3,8h,8w]. */
+int pea_vae_decoder_create(const pea_unet_config* cfg, int B, int H, int W, void** out);
+int pea_vae_decode(void* vae, const float* latents, float inv_scaling, float* image, void* stream);
 int pea_unet_num_weights(void* unet);
 /* diffusers state-dict key + torch shape (d0,d1; conv adds [3][3]) of weight i; kind: 0 vector,
  * 1 linear [d0][d1] (1x1 convs included), 2 conv3x3 [d0][d1][3][3], 3 conv_in, 4 conv_out         */

@@ -160,6 +160,65 @@ class VAEEncoderRef(nn.Module):
         return _EncodeOut(DiagonalGaussianRef(self.moments(x)))
 
 
+class Upsample(nn.Module):                  # Upsample2D(use_conv=True): nearest 2x, then conv 3x3
+    def __init__(self, c):
+        super().__init__()
+        self.conv = nn.Conv2d(c, c, 3, padding=1)
+
+    def forward(self, x):
+        return self.conv(F.interpolate(x, scale_factor=2.0, mode="nearest"))
+
+
+class UpDecoderBlock(nn.Module):
+    def __init__(self, cin, cout, layers, groups, eps, up):
+        super().__init__()
+        self.resnets = nn.ModuleList([ResnetBlock(cin if j == 0 else cout, cout, groups, eps) for j in range(layers)])
+        self.upsamplers = nn.ModuleList([Upsample(cout)]) if up else None
+
+    def forward(self, x):
+        for r in self.resnets:
+            x = r(x)
+        if self.upsamplers is not None:
+            x = self.upsamplers[0](x)
+        return x
+
+
+class Decoder(nn.Module):
+    def __init__(self, cfg: VAEConfig, out_channels: int = 3):
+        super().__init__()
+        boc, g, e = cfg.block_out_channels, cfg.norm_num_groups, cfg.norm_eps
+        rev = list(reversed(boc))
+        self.conv_in = nn.Conv2d(cfg.latent_channels, rev[0], 3, padding=1)
+        self.mid_block = MidBlock(rev[0], g, e)
+        self.up_blocks = nn.ModuleList()
+        c = rev[0]
+        for i, co in enumerate(rev):
+            self.up_blocks.append(UpDecoderBlock(c, co, cfg.layers_per_block + 1, g, e, up=(i != len(rev) - 1)))
+            c = co
+        self.conv_norm_out = nn.GroupNorm(g, c, eps=e)
+        self.conv_out = nn.Conv2d(c, out_channels, 3, padding=1)
+
+    def forward(self, z):
+        x = self.mid_block(self.conv_in(z))
+        for b in self.up_blocks:
+            x = b(x)
+        return self.conv_out(F.silu(self.conv_norm_out(x)))
+
+
+class VAEDecoderRef(nn.Module):
+    """The `decode` half of AutoencoderKL: `vae.decode(latents / scaling_factor, return_dict=False)[0]`
+    (tests/test_sdxl_zh.py:430).  Published totals: decoder 49 490 179 + post_quant_conv 20 parameters."""
+
+    def __init__(self, cfg: VAEConfig):
+        super().__init__()
+        self.config = cfg
+        self.post_quant_conv = nn.Conv2d(cfg.latent_channels, cfg.latent_channels, 1)
+        self.decoder = Decoder(cfg)
+
+    def decode(self, z, return_dict=False):
+        return (self.decoder(self.post_quant_conv(z)),)
+
+
 def vae_encoder_flops(cfg: VAEConfig, H: int, W: int) -> float:
     """analytic FLOPs of one encode (2*MACs of convs, linears and the mid attention), per image"""
     fl, c, h, w = 0.0, cfg.block_out_channels[0], H, W

@@ -152,3 +152,14 @@ def vae_encoder_flops(cfg: VAEConfig, H: int, W: int) -> float:
     fl += 4 * 2.0 * h * w * c * c + 2 * 2.0 * (h * w) ** 2 * c
     fl += 2.0 * h * w * 9 * c * 2 * cfg.latent_channels
     return fl
+
+
+def vae_decoder_to_c(cfg, out_channels: int = 3) -> CUNetConfig:
+    c = CUNetConfig()
+    n = len(cfg.block_out_channels)
+    c.in_channels, c.out_channels, c.n_levels = cfg.latent_channels, out_channels, n
+    for i in range(n):
+        c.block_out[i] = cfg.block_out_channels[i]
+    c.layers_per_block = cfg.layers_per_block
+    c.groups, c.eps = cfg.norm_num_groups, cfg.norm_eps
+    return c

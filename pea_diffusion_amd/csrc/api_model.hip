@@ -158,6 +158,44 @@ int pea_vae_encode(void* h, const float* pixels, const float* noise, float scali
   return launch_vae_posterior(u->vae_h, u->slots[u->w_quant].f32, u->slots[u->b_quant].f32, noise, moments, latents, u->B,
                               u->cfg.out_channels, (long long)t.H * t.W, scaling, s);
 }
+int pea_vae_decoder_create(const pea_unet_config* cfg, int B, int H, int W, void** out) {
+  NOTNULL(cfg, "pea_vae_decoder_create");
+  NOTNULL(out, "pea_vae_decoder_create");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
+    pea_set_error("pea_vae_decoder_create: no HIP device (there is no CPU fallback)");
+    return PEA_E_HIP;
+  }
+  Unet* u = new Unet();
+  memcpy(&u->cfg, cfg, sizeof(PeaUnetCfg));
+  u->graph = 3;
+  u->B = B; u->H = H; u->W = W; u->L = 0; u->needs_grad = false; u->owns_weights = true;
+  int rc = u->build();
+  if (rc == PEA_OK) rc = u->alloc();
+  if (rc != PEA_OK) {
+    delete u;
+    return rc;
+  }
+  *out = u;
+  return PEA_OK;
+}
+int pea_vae_decode(void* h, const float* latents, float inv_scaling, float* image, void* stream) {
+  NOTNULL(h, "pea_vae_decode");
+  NOTNULL(latents, "pea_vae_decode");
+  NOTNULL(image, "pea_vae_decode");
+  Unet* u = (Unet*)h;
+  if (u->graph != 3) { pea_set_error("pea_vae_decode: not a VAE decoder handle"); return PEA_E_INVALID; }
+  hipStream_t s = (hipStream_t)stream;
+  std::string miss;
+  if (!u->all_loaded(&miss)) {
+    pea_set_error("vae decoder: weight '%s' was never loaded", miss.c_str());
+    return PEA_E_STATE;
+  }
+  int rc = launch_vae_post_quant(latents, u->slots[u->w_quant].f32, u->slots[u->b_quant].f32, u->vae_h, u->B,
+                                 u->cfg.in_channels, (long long)u->H * u->W, inv_scaling, s);
+  if (rc != PEA_OK) return rc;
+  return u->forward(u->vae_h, nullptr, nullptr, 0, nullptr, 0, nullptr, image, s);
+}
 int pea_unet_destroy(void* h) {
   delete (Unet*)h;
   return PEA_OK;

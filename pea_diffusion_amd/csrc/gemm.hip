@@ -1011,7 +1011,14 @@ __global__ __launch_bounds__(256) void conv_in_kernel(const float* __restrict__ 
 int launch_conv_in(const float* x, const float* w, const float* bias, bf16* y, int B, int Cin, int H, int W,
                    int Cout, hipStream_t s, int ldy, int silu) {
   if (ldy <= 0) ldy = Cout;
-  SHAPECHK(Cout % 8 == 0 && Cout / 8 <= 256 && Cin * 9 * Cout * 4 <= 64 * 1024, "conv_in: Cout=%d Cin=%d", Cout, Cin);
+  SHAPECHK(Cout % 8 == 0 && Cout / 8 <= 256 && Cin * 9 * Cout * 4 <= 160 * 1024, "conv_in: Cout=%d Cin=%d", Cout, Cin);
+  if (Cin * 9 * Cout * 4 > 64 * 1024) {           // VAE decoder conv_in (4 -> 512): 72 KB of fp32 weights in LDS
+    static bool attr_set = false;
+    if (!attr_set) {
+      HIPCHK(hipFuncSetAttribute((const void*)conv_in_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      attr_set = true;
+    }
+  }
   const int nchunk = Cout / 8;
   const int ppb = 256 / nchunk;
   const int per = ppb * 8;

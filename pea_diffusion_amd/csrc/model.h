@@ -92,7 +92,7 @@ struct Unet {
   int B, H, W, L;                 // batch, latent H/W, context length
   bool needs_grad;
   int bwd_batch = 0;                 // > 0: backward() differentiates only the first bwd_batch samples (merged passes)
-  int graph = 0;                     // 0: UNet2DConditionModel, 1: AutoencoderKL encoder (VAE), 2: ControlNetModel (1, 2: inference only)
+  int graph = 0;                     // 0: UNet2DConditionModel, 1: AutoencoderKL encoder, 2: ControlNetModel, 3: AutoencoderKL decoder (1-3: inference only)
   std::vector<int> cn_out;           // ControlNet: output tensors (down residuals in diffusers order, mid last)
   int ce_begin = -1, ce_end = -1;    // ControlNet: op range of the conditioning embedding (constant over a generation)
   bool ce_valid = false;             // ... already computed for the current conditioning image
@@ -128,6 +128,7 @@ struct Unet {
 
   int build();
   int build_vae_encoder();
+  int build_vae_decoder();
   int exec_ops(size_t begin, size_t end, bool skip_cached, hipStream_t s);
   int alloc();
   int load_weight(const char* name, const float* dev_ptr, long long numel, hipStream_t s);

@@ -320,8 +320,53 @@ int Unet::build_vae_encoder() {
   return PEA_OK;
 }
 
+// AutoencoderKL.decode (tests/test_sdxl_zh.py:430: `self.vae.decode(latents / scaling_factor)`): post_quant_conv (1x1,
+// applied with the 1/scaling division in a pointwise kernel before the tape) -> conv_in -> mid block (resnet, single-head
+// attention, resnet) -> UpDecoderBlock2D x n (layers_per_block + 1 resnets, nearest-2x + conv folded into one implicit
+// GEMM) -> GroupNorm + SiLU -> conv_out.  cfg: in_channels = latent channels (4), out_channels = image channels (3),
+// block_out = the ENCODER's block_out_channels (the decoder walks them reversed), H x W = LATENT size.
+int Unet::build_vae_decoder() {
+  const PeaUnetCfg& c = cfg;
+  SHAPECHK(c.n_levels >= 2 && c.n_levels <= 4, "vae: n_levels=%d", c.n_levels);
+  SHAPECHK(!needs_grad && !residual_inputs, "vae decoder: inference graph only");
+  SHAPECHK(c.out_channels <= 8, "vae decoder: %d image channels", c.out_channels);
+  SHAPECHK((H * W) % 64 == 0, "vae decoder: latent %dx%d (tokens must be a multiple of 64)", H, W);
+  for (int i = 0; i < c.n_levels; ++i) SHAPECHK(c.block_out[i] % 64 == 0, "vae: block_out_channels[%d]=%d", i, c.block_out[i]);
+  Builder bd(*this);
+  const int n = c.n_levels;
+  const int top = c.block_out[n - 1];
+  int x = bd.T((long long)B * H * W, top, B, H, W);
+  {
+    Op& o = bd.push(OP_CONV_IN);
+    o.out = x;
+    o.w = bd.slot("decoder.conv_in.weight", W_CONV_IN, top, c.in_channels, 9LL * top * c.in_channels);
+    o.bias = bd.vec("decoder.conv_in.bias", top);
+  }
+  x = bd.resnet_plain(x, "decoder.mid_block.resnets.0", top);
+  x = bd.attention_mat(x, "decoder.mid_block.attentions.0");
+  x = bd.resnet_plain(x, "decoder.mid_block.resnets.1", top);
+  for (int i = 0; i < n; ++i) {
+    const std::string p = "decoder.up_blocks." + std::to_string(i);
+    const int co = c.block_out[n - 1 - i];
+    for (int j = 0; j < c.layers_per_block + 1; ++j) x = bd.resnet_plain(x, p + ".resnets." + std::to_string(j), co);
+    if (i != n - 1) x = bd.conv(x, p + ".upsamplers.0.conv", co, 1, 1);
+  }
+  x = bd.gn(x, "decoder.conv_norm_out", true, c.eps);
+  t_out_in = x;
+  {
+    Op& o = bd.push(OP_CONV_OUT);
+    o.a = x;
+    o.w = bd.slot("decoder.conv_out.weight", W_CONV_OUT, c.out_channels, c.block_out[0], 9LL * c.out_channels * c.block_out[0]);
+    o.bias = bd.vec("decoder.conv_out.bias", c.out_channels);
+  }
+  w_quant = bd.vec("post_quant_conv.weight", c.in_channels * c.in_channels);
+  b_quant = bd.vec("post_quant_conv.bias", c.in_channels);
+  return PEA_OK;
+}
+
 int Unet::build() {
   if (graph == 1) return build_vae_encoder();
+  if (graph == 3) return build_vae_decoder();
   const PeaUnetCfg& c = cfg;
   SHAPECHK(c.n_levels >= 2 && c.n_levels <= 4, "unet: n_levels=%d", c.n_levels);
   for (int i = 0; i < c.n_levels; ++i) {
@@ -607,6 +652,7 @@ int Unet::alloc() {
     const Tn& t = tn[t_out_in];
     HIPCHK(hipMalloc((void**)&vae_h, sizeof(float) * (size_t)B * cfg.out_channels * t.H * t.W));
   }
+  if (graph == 3) HIPCHK(hipMalloc((void**)&vae_h, sizeof(float) * (size_t)B * cfg.in_channels * H * W));   // post_quant_conv(z / s)
   RC(pea_zero_page(&zeros));
   return PEA_OK;
 }
@@ -721,7 +767,7 @@ int Unet::forward(const float* x, const float* t, const void* ehs, int ehs_dtype
     return PEA_E_STATE;
   }
   x_in = x; t_in = t; tid_in = time_ids; eps_out = eps;
-  if (graph != 1) {
+  if (graph == 0 || graph == 2) {
     Tn& e = tn[t_ehs];
     const long long n = e.rows * e.cols;
     if ((const void*)e.d != ehs) {

@@ -187,3 +187,5 @@ int launch_residual_import(const void* src, int dtype, bf16* dst, int B, int C, 
 int launch_softmax_rows(bf16* s, long long rows, int cols, int ld, float scale, hipStream_t st);   // in place
 int launch_vae_posterior(const float* h, const float* wq, const float* bq, const float* noise, float* moments,
                          float* latents, int B, int C2, long long HW, float scaling, hipStream_t s);
+int launch_vae_post_quant(const float* z, const float* w, const float* b, float* out, int B, int C, long long HW,
+                          float inv_scaling, hipStream_t s);

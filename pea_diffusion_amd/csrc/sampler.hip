@@ -204,3 +204,27 @@ int launch_softmax_rows(bf16* s, long long rows, int cols, int ld, float scale, 
   HIPCHK(hipGetLastError());
   return PEA_OK;
 }
+
+// ---- VAE decode head: z' = post_quant_conv(latents * inv_scaling)  (1x1 conv over <= 8 channels), NCHW fp32
+__global__ void vae_post_quant_kernel(const float* __restrict__ z, const float* __restrict__ w,
+                                      const float* __restrict__ b, float* __restrict__ out, int B, int C, long long HW,
+                                      float inv_scaling) {
+  SM_LOOP(i, (long long)B * HW) {
+    const long long bb = i / HW, p = i - bb * HW;
+    float in[8];
+    for (int c = 0; c < C; ++c) in[c] = z[(bb * C + c) * HW + p] * inv_scaling;
+    for (int o = 0; o < C; ++o) {
+      float a = b[o];
+      for (int c = 0; c < C; ++c) a += w[o * C + c] * in[c];
+      out[(bb * C + o) * HW + p] = a;
+    }
+  }
+}
+int launch_vae_post_quant(const float* z, const float* w, const float* b, float* out, int B, int C, long long HW,
+                          float inv_scaling, hipStream_t s) {
+  SHAPECHK(C >= 1 && C <= 8, "vae post_quant: %d latent channels", C);
+  hipLaunchKernelGGL(vae_post_quant_kernel, dim3(sm_grid((long long)B * HW)), dim3(256), 0, s, z, w, b, out, B, C, HW,
+                     inv_scaling);
+  HIPCHK(hipGetLastError());
+  return PEA_OK;
+}

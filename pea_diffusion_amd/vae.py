@@ -110,3 +110,47 @@ class HipVAEEncoder:
                                    stream_ptr()))
         self._keep = (x, noise)
         return out
+
+
+class HipVAEDecoder:
+    """`image = self.vae.decode(latents / self.vae.config.scaling_factor, return_dict=False)[0]`
+    (tests/test_sdxl_zh.py:430; tests/test_sdxl_zh_controlnet.py:575) on the HIP tape.  Built for a LATENT size;
+    weights by the AutoencoderKL keys `decoder.*`, `post_quant_conv.*` (encoder keys of a full checkpoint are skipped)."""
+
+    def __init__(self, cfg, batch: int, latent_height: Optional[int] = None, latent_width: Optional[int] = None):
+        if not torch.cuda.is_available():
+            raise PeaError("HipVAEDecoder needs a MI355X (no CPU fallback)")
+        self.cfg, self.config = cfg, _Cfg(cfg)
+        f = 2 ** (len(cfg.block_out_channels) - 1)
+        self.B, self.h, self.w = batch, latent_height or cfg.sample_size // f, latent_width or cfg.sample_size // f
+        self.scale_factor = f
+        self.device = torch.device("cuda", torch.cuda.current_device())
+        self.dtype = torch.float32
+        self._h = ctypes.c_void_p()
+        c = _cfg.vae_decoder_to_c(cfg)
+        check(lib().pea_vae_decoder_create(ctypes.byref(c), self.B, self.h, self.w, ctypes.byref(self._h)))
+
+    __del__ = HipUNet.__del__
+    weight_table = HipUNet.weight_table
+    memory = HipUNet.memory
+
+    def to(self, *a, **k):
+        return self
+
+    def load_state_dict(self, sd: Dict[str, torch.Tensor], strict: bool = True):
+        sd = {k: v for k, v in sd.items() if not (k.startswith("encoder.") or k.startswith("quant_conv."))}
+        return HipUNet.load_state_dict(self, sd, strict)
+
+    def init_random(self, seed: int = 0):
+        check(lib().pea_unet_init_random(self._h, seed, stream_ptr()))
+
+    def decode(self, z, return_dict: bool = False, inv_scaling: float = 1.0):
+        """z: [B, 4, h, w] (already divided by the scaling factor, as the reference passes it; or pass the raw latents
+        with inv_scaling = 1 / scaling_factor and the division happens in the post_quant kernel) -> ([B, 3, 8h, 8w],)"""
+        if tuple(z.shape) != (self.B, self.cfg.latent_channels, self.h, self.w):
+            raise PeaError(f"HipVAEDecoder built for {(self.B, self.cfg.latent_channels, self.h, self.w)}, got {tuple(z.shape)}")
+        zz = z.detach().to(self.device, torch.float32).contiguous()
+        img = torch.empty(self.B, 3, self.h * self.scale_factor, self.w * self.scale_factor, device=self.device)
+        check(lib().pea_vae_decode(self._h, ptr(zz), float(inv_scaling), ptr(img), stream_ptr()))
+        self._keep = zz
+        return (img,)

@@ -28,3 +28,25 @@ for f in range(8):
     t, fl_, by, k = ctypes.c_double(), ctypes.c_double(), ctypes.c_double(), ctypes.c_longlong()
     L.pea_prof_report(f, ctypes.byref(t), ctypes.byref(fl_), ctypes.byref(by), ctypes.byref(k))
     if k.value: print(f"  {L.pea_prof_family_name(f).decode():28s} {t.value:8.2f} ms {k.value:5d} launches {fl_.value/max(t.value,1e-9)/1e9:8.1f} TFLOP/s {by.value/max(t.value,1e-9)/1e6:8.0f} GB/s")
+
+# ---- decode (tests/test_sdxl_zh.py:430): 128x128 latents -> 1024x1024 image
+from pea_diffusion_amd.vae import HipVAEDecoder
+del vae
+torch.cuda.empty_cache()
+dec = HipVAEDecoder(pc.sdxl_vae_config(), B, hw // 8, hw // 8)
+dec.init_random(1)
+z = torch.randn(B, 4, hw // 8, hw // 8, device="cuda")
+for _ in range(2): dec.decode(z)
+torch.cuda.synchronize()
+s.record()
+for _ in range(n): dec.decode(z)
+e.record(); torch.cuda.synchronize()
+ms = s.elapsed_time(e) / n
+print(f"VAE decode B={B} -> {hw}x{hw}: {ms:.2f} ms/batch  ({ms/B:.2f} ms/image)  memory {dec.memory()}")
+L.pea_prof_reset(); L.pea_prof_enable(1)
+dec.decode(z); torch.cuda.synchronize()
+L.pea_prof_enable(0)
+for f in range(8):
+    t, fl_, by, k = ctypes.c_double(), ctypes.c_double(), ctypes.c_double(), ctypes.c_longlong()
+    L.pea_prof_report(f, ctypes.byref(t), ctypes.byref(fl_), ctypes.byref(by), ctypes.byref(k))
+    if k.value: print(f"  {L.pea_prof_family_name(f).decode():28s} {t.value:8.2f} ms {k.value:5d} launches {fl_.value/max(t.value,1e-9)/1e9:8.1f} TFLOP/s {by.value/max(t.value,1e-9)/1e6:8.0f} GB/s")

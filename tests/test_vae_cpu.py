@@ -15,6 +15,15 @@ def test_sdxl_vae_encoder_parameter_total():
     assert abs(vae_encoder_flops(sdxl_vae_config(), 1024, 1024) / 1e12 - 4.879) < 5e-3      # 4.89 TFLOP/img
 
 
+def test_sdxl_vae_decoder_parameter_total():
+    from oracle.vae_ref import VAEDecoderRef
+    with torch.device("meta"):
+        m = VAEDecoderRef(sdxl_vae_config())
+    n_dec = sum(p.numel() for k, p in m.named_parameters() if k.startswith("decoder."))
+    n_pq = sum(p.numel() for k, p in m.named_parameters() if k.startswith("post_quant_conv."))
+    assert (n_dec, n_pq) == (49_490_179, 20)          # encoder 34 163 592 + 72 + these = 83 653 863, the published total
+
+
 def test_encode_geometry_and_posterior():
     torch.manual_seed(0)
     cfg = tiny_vae_config()
