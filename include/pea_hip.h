@@ -197,6 +197,25 @@ int pea_controlnet_num_outputs(void* cn);
 int pea_controlnet_output(void* cn, int i, void** ptr, int* C, int* H, int* W);
 int pea_controlnet_export_nchw(void* cn, int i, float* dst, void* stream);   /* fp32 [B,C,H,W] copy of output i */
 
+/* Text encoders in front of the step, on the same op tape; handle works with the pea_unet_* weight
+ * functions (HF transformers keys).  flavor 0 = CLIPTextModel[WithProjection] -- the teacher's CLIP-L and OpenCLIP-bigG
+ * (train_sdxl_zh.py:147-150; encode_prompt :170-285 takes `hidden_states[-2]` of both and the pooled output of the
+ * second): pre-LN, causal mask, final LayerNorm, pooled = final[EOS position] @ text_projection.  flavor 1 = BERT -- the
+ * Chinese-CLIP text tower (train_sdxl_zh.py:103-107; `self.text_encoder.encode_text(batch["input_ids"])` :327-329 returns
+ * the per-token states): post-LN, right-padding mask from pad id `eos_id`.  head_dim must be 64 (true for all three).
+ * forward: ids int64 [B,L] device; hidden_index -1 = last state (CLIP: after the final LayerNorm), -2 = hidden_states[-2],
+ * k >= 0 = hidden_states[k]; hidden_out fp32 [B,L,width] and / or pooled_out fp32 [B,proj_dim] (CLIP only). */
+typedef struct pea_text_config {
+  int vocab, max_pos, width, heads, layers, intermediate;
+  int act;          /* 1 GELU(erf), 3 quick-GELU */
+  int flavor;       /* 0 CLIP, 1 BERT */
+  int proj_dim;     /* CLIP text_projection width, 0 = none */
+  float eps;
+  long long eos_id; /* CLIP: EOS id (< 0: argmax of the ids); BERT: pad id */
+} pea_text_config;
+int pea_text_create(const pea_text_config* cfg, int B, int L, void** out);
+int pea_text_forward(void* enc, const long long* ids, int hidden_index, float* hidden_out, float* pooled_out, void* stream);
+
 /* VAE encoder (AutoencoderKL.encode, train_sdxl_zh.py:306-309; train_sd_zh.py:188-189) on the same op tape: cfg uses
  * in_channels (3), out_channels (2 * latent channels = 8), n_levels, block_out, layers_per_block, groups, eps.
  * The handle works with pea_unet_num_weights / weight_info / load_weight / init_random / memory / destroy (diffusers

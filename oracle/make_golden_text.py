@@ -1,0 +1,64 @@
+"""Golden vectors for the text encoders from the INSTALLED transformers release (third-party; the reference pins 4.31.0,
+this container has 5.x -- both implement the same CLIP text model and BERT): seeded tiny configurations, weights + ids +
+outputs -> tests/golden/text_clip.npz, tests/golden/text_bert.npz.  Run: PYTHONDONTWRITEBYTECODE=1 python oracle/make_golden_text.py"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from transformers import BertConfig, BertModel, CLIPTextConfig, CLIPTextModelWithProjection  # noqa: E402
+
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+
+
+def main():
+    torch.manual_seed(0)
+    c = CLIPTextConfig(vocab_size=1000, hidden_size=128, intermediate_size=512, num_hidden_layers=3, num_attention_heads=2,
+                       max_position_embeddings=77, hidden_act="quick_gelu", projection_dim=64, eos_token_id=999,
+                       bos_token_id=998, pad_token_id=1)
+    m = CLIPTextModelWithProjection(c).eval()
+    with torch.no_grad():
+        for p in m.parameters():                      # HF init is N(0, 0.02): scale up so every term matters
+            if p.dim() >= 2:
+                p.mul_(3.0)
+            else:
+                p.add_(0.05 * torch.randn_like(p))
+    ids = torch.randint(2, 998, (2, 77))
+    ids[:, 0] = 998
+    ids[0, 10:] = 1; ids[0, 10] = 999
+    ids[1, 40:] = 1; ids[1, 40] = 999
+    with torch.no_grad():
+        o = m(ids, output_hidden_states=True)
+    d = {"w." + k: v.numpy() for k, v in m.state_dict().items()}
+    d.update(ids=ids.numpy(), last_hidden_state=o.last_hidden_state.numpy(), text_embeds=o.text_embeds.numpy())
+    for i, h in enumerate(o.hidden_states):
+        d[f"hidden_{i}"] = h.numpy()
+    np.savez_compressed(os.path.join(OUT, "text_clip.npz"), **d)
+
+    torch.manual_seed(1)
+    b = BertConfig(vocab_size=1000, hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=512,
+                   max_position_embeddings=64, type_vocab_size=2, layer_norm_eps=1e-12)
+    bm = BertModel(b, add_pooling_layer=False).eval()
+    with torch.no_grad():
+        for p in bm.parameters():
+            if p.dim() >= 2:
+                p.mul_(3.0)
+            else:
+                p.add_(0.05 * torch.randn_like(p))
+    ids = torch.randint(1, 1000, (2, 52))
+    ids[0, 20:] = 0
+    ids[1, 45:] = 0
+    with torch.no_grad():
+        ob = bm(ids, attention_mask=(ids != 0).long(), output_hidden_states=True)
+    d = {"w." + k: v.numpy() for k, v in bm.state_dict().items()}
+    d.update(ids=ids.numpy(), last_hidden_state=ob.last_hidden_state.numpy())
+    for i, h in enumerate(ob.hidden_states):
+        d[f"hidden_{i}"] = h.numpy()
+    np.savez_compressed(os.path.join(OUT, "text_bert.npz"), **d)
+    print("wrote", [(f, os.path.getsize(os.path.join(OUT, f))) for f in ("text_clip.npz", "text_bert.npz")])
+
+
+if __name__ == "__main__":
+    main()

@@ -163,3 +163,62 @@ def vae_decoder_to_c(cfg, out_channels: int = 3) -> CUNetConfig:
     c.layers_per_block = cfg.layers_per_block
     c.groups, c.eps = cfg.norm_num_groups, cfg.norm_eps
     return c
+
+
+# ---- text encoders (train_sdxl_zh.py:103-107,147-150)
+@dataclass
+class TextConfig:
+    vocab_size: int = 49408
+    max_position_embeddings: int = 77
+    hidden_size: int = 768
+    num_attention_heads: int = 12
+    num_hidden_layers: int = 12
+    intermediate_size: int = 3072
+    hidden_act: str = "quick_gelu"          # "quick_gelu" | "gelu"
+    flavor: str = "clip"                    # "clip" (pre-LN, causal, EOS pooling) | "bert" (post-LN, padding mask)
+    projection_dim: int = 0
+    layer_norm_eps: float = 1e-5
+    eos_token_id: int = -1                  # clip: EOS id (-1: argmax of the ids, the original CLIP vocabulary); bert: pad id
+    name: str = "clip_l"
+
+
+def clip_l_config() -> TextConfig:           # SDXL text_encoder (CLIP ViT-L/14 text tower)
+    return TextConfig()
+
+
+def openclip_bigg_config() -> TextConfig:    # SDXL text_encoder_2 (OpenCLIP ViT-bigG/14 text tower, CLIPTextModelWithProjection)
+    return TextConfig(hidden_size=1280, num_attention_heads=20, num_hidden_layers=32, intermediate_size=5120,
+                      hidden_act="gelu", projection_dim=1280, name="openclip_bigg")
+
+
+def cnclip_bert_large_config() -> TextConfig:   # Chinese-CLIP ViT-H/14 text tower (RoBERTa-wwm-ext-large), 52 tokens
+    return TextConfig(vocab_size=21128, max_position_embeddings=512, hidden_size=1024, num_attention_heads=16,
+                      num_hidden_layers=24, intermediate_size=4096, hidden_act="gelu", flavor="bert",
+                      layer_norm_eps=1e-12, eos_token_id=0, name="cnclip_bert_large")
+
+
+def tiny_clip_config() -> TextConfig:
+    return TextConfig(vocab_size=1000, max_position_embeddings=77, hidden_size=128, num_attention_heads=2,
+                      num_hidden_layers=3, intermediate_size=512, projection_dim=64, eos_token_id=999, name="tiny_clip")
+
+
+def tiny_bert_config() -> TextConfig:
+    return TextConfig(vocab_size=1000, max_position_embeddings=64, hidden_size=128, num_attention_heads=2,
+                      num_hidden_layers=2, intermediate_size=512, hidden_act="gelu", flavor="bert", layer_norm_eps=1e-12,
+                      eos_token_id=0, name="tiny_bert")
+
+
+class CTextConfig(ctypes.Structure):
+    _fields_ = [("vocab", ctypes.c_int), ("max_pos", ctypes.c_int), ("width", ctypes.c_int), ("heads", ctypes.c_int),
+                ("layers", ctypes.c_int), ("intermediate", ctypes.c_int), ("act", ctypes.c_int), ("flavor", ctypes.c_int),
+                ("proj_dim", ctypes.c_int), ("eps", ctypes.c_float), ("eos_id", ctypes.c_longlong)]
+
+
+def text_to_c(cfg) -> CTextConfig:
+    c = CTextConfig()
+    c.vocab, c.max_pos, c.width = cfg.vocab_size, cfg.max_position_embeddings, cfg.hidden_size
+    c.heads, c.layers, c.intermediate = cfg.num_attention_heads, cfg.num_hidden_layers, cfg.intermediate_size
+    c.act = {"quick_gelu": 3, "gelu": 1}[cfg.hidden_act]
+    c.flavor = {"clip": 0, "bert": 1}[cfg.flavor]
+    c.proj_dim, c.eps, c.eos_id = cfg.projection_dim, cfg.layer_norm_eps, cfg.eos_token_id
+    return c

@@ -196,6 +196,66 @@ int pea_vae_decode(void* h, const float* latents, float inv_scaling, float* imag
   if (rc != PEA_OK) return rc;
   return u->forward(u->vae_h, nullptr, nullptr, 0, nullptr, 0, nullptr, image, s);
 }
+static_assert(sizeof(pea_text_config) == sizeof(PeaTextCfg), "text config struct mismatch");
+int pea_text_create(const pea_text_config* cfg, int B, int L, void** out) {
+  NOTNULL(cfg, "pea_text_create");
+  NOTNULL(out, "pea_text_create");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
+    pea_set_error("pea_text_create: no HIP device (there is no CPU fallback)");
+    return PEA_E_HIP;
+  }
+  Unet* u = new Unet();
+  memset(&u->cfg, 0, sizeof(PeaUnetCfg));
+  memcpy(&u->tcfg, cfg, sizeof(PeaTextCfg));
+  u->graph = 4;
+  u->B = B; u->H = 1; u->W = L; u->L = L; u->needs_grad = false; u->owns_weights = true;
+  int rc = u->build();
+  if (rc == PEA_OK) rc = u->alloc();
+  if (rc != PEA_OK) {
+    delete u;
+    return rc;
+  }
+  *out = u;
+  return PEA_OK;
+}
+int pea_text_forward(void* h, const long long* ids, int hidden_index, float* hidden_out, float* pooled_out, void* stream) {
+  NOTNULL(h, "pea_text_forward");
+  NOTNULL(ids, "pea_text_forward");
+  Unet* u = (Unet*)h;
+  if (u->graph != 4) { pea_set_error("pea_text_forward: not a text-encoder handle"); return PEA_E_INVALID; }
+  hipStream_t s = (hipStream_t)stream;
+  std::string miss;
+  if (!u->all_loaded(&miss)) {
+    pea_set_error("text encoder: weight '%s' was never loaded", miss.c_str());
+    return PEA_E_STATE;
+  }
+  u->ids_in = ids;
+  if (u->tcfg.flavor == 1) {
+    int rc = launch_kv_len(ids, u->kvlen, u->B, u->L, u->tcfg.eos_id, s);
+    if (rc != PEA_OK) return rc;
+  }
+  int rc = u->exec_ops(0, u->ops.size(), false, s);
+  if (rc != PEA_OK) return rc;
+  if (hidden_out) {
+    const int nh = (int)u->hidden.size();
+    int t = u->t_final;
+    if (hidden_index != -1) {
+      const int k = hidden_index < 0 ? nh + hidden_index : hidden_index;
+      if (k < 0 || k >= nh) { pea_set_error("pea_text_forward: hidden_index %d out of range (%d states)", hidden_index, nh); return PEA_E_INVALID; }
+      t = u->hidden[k];
+    }
+    rc = launch_cast_bf16_f32(u->tn[t].d, hidden_out, u->tn[t].rows * u->tn[t].cols, s);
+    if (rc != PEA_OK) return rc;
+  }
+  if (pooled_out) {
+    if (u->t_pooled < 0) { pea_set_error("pea_text_forward: this encoder has no pooled output"); return PEA_E_INVALID; }
+    const Tn& t = u->tn[u->t_pooled];
+    rc = launch_cast_bf16_f32(t.d, pooled_out, t.rows * t.cols, s);
+    if (rc != PEA_OK) return rc;
+  }
+  return PEA_OK;
+}
 int pea_unet_destroy(void* h) {
   delete (Unet*)h;
   return PEA_OK;

@@ -82,8 +82,8 @@ __device__ __forceinline__ bf16x8 read_row_frag(const char* tile, int row, int s
 // K/V (Q/dO) tile is kept as ND sub-tiles of 64 x 64 so all LDS images stay 128-byte-row images.
 // MODE 0 produces all ND output chunks in one pass; MODE 1 produces ONE 64-wide chunk of dQ per workgroup
 // (blockIdx.x enumerates query blocks x ND chunks) so its register budget does not grow with ND.
-template <int MODE, bool USE_TR, int ND>
-__global__ __launch_bounds__(256, (ND == 1 ? (MODE == 0 ? 4 : 2) : 1)) void attn_q_kernel(const AttnP p) {
+template <int MODE, bool USE_TR, int ND, bool TXT = false>
+__global__ __launch_bounds__(256, (ND == 1 ? (MODE == 0 ? (TXT ? 3 : 4) : 2) : 1)) void attn_q_kernel(const AttnP p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 stages][K sub-tiles ND | V sub-tiles ND]
   constexpr int STG = 2 * ND * TILE_BYTES;
   constexpr int NO = MODE == 0 ? ND : 1;                         // output chunks held by this workgroup
@@ -180,14 +180,20 @@ __global__ __launch_bounds__(256, (ND == 1 ? (MODE == 0 ? 4 : 2) : 1)) void attn
       // online softmax in the log2 domain: p = exp2(c*s - c*m); the scale rides in the FMA, the running max is kept
       // on the RAW scores (c > 0), keys beyond Skv are masked only in the tile that contains them, and the O rescale
       // is skipped when no lane's running max moved (exact: alpha == 1 for every lane).
-      const bool boundary = kv0 + 64 > p.Skv;            // wave-uniform
+      // TXT (text encoders, inference): causal mask and / or a per-sample key count (padding) -- a separate instance
+      // so the UNet's kernel keeps its register budget
+      int skv_b = p.Skv;
+      if constexpr (TXT) skv_b = p.kv_len ? p.kv_len[b] : p.Skv;
+      const bool boundary = (TXT && p.causal) || kv0 + 64 > skv_b;   // wave-uniform
       if (boundary) {
+        int kmax = skv_b;
+        if constexpr (TXT) kmax = p.causal ? min(skv_b, qrow + 1) : skv_b;
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             const int key = kv0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
-            sacc[kb][r] = key < p.Skv ? sacc[kb][r] : -INFINITY;
+            sacc[kb][r] = key < kmax ? sacc[kb][r] : -INFINITY;
           }
       }
       float mx = fmaxf(sacc[0][0], sacc[1][0]);
@@ -536,7 +542,6 @@ extern "C" void pea_debug_set_attn_tr(int v) { g_attn_use_tr = v; }
 static int attn_check(const AttnP& p) {
   SHAPECHK(p.B > 0 && p.H > 0 && p.Sq > 0 && p.Skv > 0, "attention: empty problem");
   SHAPECHK(p.nd >= 1 && p.nd <= 3, "attention: padded head_dim must be 64, 128 or 192 (nd=%d)", p.nd);
-  SHAPECHK(p.Sq % 4 == 0, "attention: Sq=%d must be a multiple of 4", p.Sq);
   SHAPECHK(p.ldq % 8 == 0 && p.ldk % 8 == 0 && p.ldv % 8 == 0, "attention: leading dims must be multiples of 8");
   return PEA_OK;
 }
@@ -567,6 +572,19 @@ static int attn_fwd_nd(const AttnP& p, hipStream_t s) {
   int rc = attn_set_lds_attr<ND>();
   if (rc) return rc;
   const dim3 grid(cdiv(p.Sq, 128), p.H, p.B);
+  if (p.causal || p.kv_len) {                 // text-encoder masks: separate instance (head_dim 64 only)
+    SHAPECHK(ND == 1, "attention: causal / key-length masks need head_dim 64");
+    if constexpr (ND == 1) {
+      static bool attr = false;
+      if (!attr) {
+        HIPCHK(hipFuncSetAttribute((const void*)attn_q_kernel<0, true, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   2 * 2 * TILE_BYTES));
+        attr = true;
+      }
+      hipLaunchKernelGGL((attn_q_kernel<0, true, 1, true>), grid, dim3(256), 2 * 2 * TILE_BYTES, s, p);
+    }
+    return PEA_OK;
+  }
   ATTN_DISPATCH((attn_q_kernel<0, true, ND>), (attn_q_kernel<0, false, ND>), grid, 2 * 2 * ND * TILE_BYTES);
   return PEA_OK;
 }
@@ -611,6 +629,7 @@ int launch_attention_bwd(const AttnP& p0, hipStream_t s) {
   int rc = attn_check(p);
   if (rc) return rc;
   SHAPECHK(p.lse && p.delta && p.dO && p.O, "attention bwd: lse/delta/dO/O required");
+  SHAPECHK(p.Sq % 4 == 0, "attention bwd: Sq=%d must be a multiple of 4", p.Sq);
   const long long total = (long long)p.B * p.Sq * p.H * 8;
   // algorithmic: 5 products (S, dP, dV, dK, dQ) = 10*B*H*Sq*Skv*D flops (the two-kernel form recomputes S and dP)
   if (g_prof_on) { g_prof_tag[0] = p.B * p.H; g_prof_tag[1] = p.Sq; g_prof_tag[2] = p.Skv; g_prof_tag[3] = p.nd; }

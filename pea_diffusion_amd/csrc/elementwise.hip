@@ -655,3 +655,72 @@ int launch_permute_geglu_vec(const float* src, float* dst, int inner, hipStream_
   HIPCHK(hipGetLastError());
   return PEA_OK;
 }
+
+// ---- text encoders: embeddings (token + position [+ token type 0]) and the EOS-token row (CLIP pooled output)
+__global__ void embed_tokens_kernel(const long long* __restrict__ ids, const bf16* __restrict__ tok,
+                                    const bf16* __restrict__ pos, const bf16* __restrict__ type0,
+                                    bf16* __restrict__ out, int B, int L, int width, int vocab) {
+  const int ck = width / 8;
+  EW_LOOP(i, (long long)B * L * ck) {
+    const int c = (int)(i % ck);
+    const long long r = i / ck;
+    const int l = (int)(r % L);
+    long long id = ids[r];
+    id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+    const bf16x8 t = *(const bf16x8*)(tok + id * width + c * 8);
+    const bf16x8 p = *(const bf16x8*)(pos + (long long)l * width + c * 8);
+    bf16x8 o;
+    if (type0) {
+      const bf16x8 ty = *(const bf16x8*)(type0 + c * 8);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] = (bf16)((float)t[j] + (float)p[j] + (float)ty[j]);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] = (bf16)((float)t[j] + (float)p[j]);
+    }
+    *(bf16x8*)(out + r * width + c * 8) = o;
+  }
+}
+int launch_embed_tokens(const long long* ids, const bf16* tok, const bf16* pos, const bf16* type0, bf16* out, int B, int L,
+                        int width, int vocab, hipStream_t s) {
+  SHAPECHK(width % 8 == 0, "embed: width %% 8");
+  hipLaunchKernelGGL(embed_tokens_kernel, dim3(EW_GRID((long long)B * L * width / 8)), dim3(256), 0, s, ids, tok, pos,
+                     type0, out, B, L, width, vocab);
+  HIPCHK(hipGetLastError());
+  return PEA_OK;
+}
+// out[b] = x[b][first l with ids[b][l] == eos_id]  (eos_id < 0: argmax of the ids, the CLIP tokenizer's EOS is the largest id)
+__global__ void gather_eos_kernel(const long long* __restrict__ ids, const bf16* __restrict__ x, bf16* __restrict__ out,
+                                  int L, int width, long long eos_id) {
+  const int b = blockIdx.x;
+  int pos = 0;
+  if (eos_id >= 0) {
+    pos = L - 1;
+    for (int l = 0; l < L; ++l)
+      if (ids[(long long)b * L + l] == eos_id) { pos = l; break; }
+  } else {
+    long long best = ids[(long long)b * L];
+    for (int l = 1; l < L; ++l)
+      if (ids[(long long)b * L + l] > best) { best = ids[(long long)b * L + l]; pos = l; }
+  }
+  for (int c = threadIdx.x; c < width; c += blockDim.x) out[(long long)b * width + c] = x[((long long)b * L + pos) * width + c];
+}
+int launch_gather_eos(const long long* ids, const bf16* x, bf16* out, int B, int L, int width, long long eos_id, hipStream_t s) {
+  hipLaunchKernelGGL(gather_eos_kernel, dim3(B), dim3(256), 0, s, ids, x, out, L, width, eos_id);
+  HIPCHK(hipGetLastError());
+  return PEA_OK;
+}
+// len[b] = number of leading tokens != pad_id  (BERT-style right padding -> key count for the attention mask)
+__global__ void kv_len_kernel(const long long* __restrict__ ids, int* __restrict__ len, int B, int L, long long pad_id) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  int n = 0;
+  for (int l = 0; l < L; ++l)
+    if (ids[(long long)b * L + l] != pad_id) n = l + 1;
+  len[b] = n > 0 ? n : 1;
+}
+int launch_kv_len(const long long* ids, int* len, int B, int L, long long pad_id, hipStream_t s) {
+  hipLaunchKernelGGL(kv_len_kernel, dim3(cdiv(B, 64)), dim3(64), 0, s, ids, len, B, L, pad_id);
+  HIPCHK(hipGetLastError());
+  return PEA_OK;
+}

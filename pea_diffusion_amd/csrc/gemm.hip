@@ -74,6 +74,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x16 (&acc)[NI][
         } else if (p.act == 2) {
 #pragma unroll
           for (int j = 0; j < 4; ++j) v[j] = siluf_(v[j]);
+        } else if (p.act == 3) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] = v[j] * sigmoidf_(1.702f * v[j]);
         }
         if (p.res) {
           const bf16x4 rr = *(const bf16x4*)(p.res + (long long)m * p.ldres + n);
@@ -141,6 +144,9 @@ __device__ __forceinline__ void gemm_epilogue16(const GemmP& p, f32x4 (&acc)[NT]
     } else if (p.act == 2) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) v[j] = siluf_(v[j]);
+    } else if (p.act == 3) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] = v[j] * sigmoidf_(1.702f * v[j]);
     }
     if (p.res) {
       const bf16x4 rr = *(const bf16x4*)(p.res + (long long)m * p.ldres + n);
@@ -802,6 +808,9 @@ __global__ __launch_bounds__((WM * WN + LW + SW) * 64) void gemm_lcp_kernel(cons
           } else if (p.act == 2) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) v[j] = siluf_(v[j]);
+          } else if (p.act == 3) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = v[j] * sigmoidf_(1.702f * v[j]);
           }
           bf16x4 o;
 #pragma unroll

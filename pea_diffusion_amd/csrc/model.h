@@ -28,6 +28,15 @@ struct PeaUnetCfg {          // mirrors `pea_unet_config` of include/pea_hip.h
   int proj_in_dim;           // projection_class_embeddings_input_dim
 };
 
+struct PeaTextCfg {          // mirrors `pea_text_config` of include/pea_hip.h
+  int vocab, max_pos, width, heads, layers, intermediate;
+  int act;                   // GEMM epilogue activation of the MLP: 1 GELU(erf), 3 quick-GELU
+  int flavor;                // 0: CLIP text model (pre-LN, causal, final LN, EOS pooling), 1: BERT (post-LN, key padding)
+  int proj_dim;              // CLIP text_projection width (0: none)
+  float eps;
+  long long eos_id;          // CLIP: EOS token id (< 0: argmax of the ids);  BERT: pad token id
+};
+
 enum WKind { W_VEC, W_LINEAR, W_CONV3, W_CONV_IN, W_CONV_OUT };
 
 struct WSlot {
@@ -70,7 +79,7 @@ struct Tn {
 };
 
 enum OpKind { OP_CONV_IN, OP_CONV3, OP_LINEAR, OP_GN, OP_LN, OP_ATTN, OP_GEGLU, OP_CONCAT, OP_SILU, OP_TEMB,
-              OP_CONV_OUT, OP_ADD, OP_ATTN_MAT };
+              OP_CONV_OUT, OP_ADD, OP_ATTN_MAT, OP_EMBED, OP_GATHER_EOS };
 
 struct Op {
   int kind;
@@ -85,6 +94,7 @@ struct Op {
   float f0 = 0.f;
   float* aux = nullptr; size_t aux_off = 0, aux_bytes = 0;   // GN/LN stats, attention lse
   int src = 0;                    // OP_TEMB: 0 = timesteps, 1 = time_ids
+  int mask = 0;                   // OP_ATTN: 1 causal, 2 per-sample key count (text encoders)
 };
 
 struct Unet {
@@ -92,7 +102,7 @@ struct Unet {
   int B, H, W, L;                 // batch, latent H/W, context length
   bool needs_grad;
   int bwd_batch = 0;                 // > 0: backward() differentiates only the first bwd_batch samples (merged passes)
-  int graph = 0;                     // 0: UNet2DConditionModel, 1: AutoencoderKL encoder, 2: ControlNetModel, 3: AutoencoderKL decoder (1-3: inference only)
+  int graph = 0;                     // 0: UNet2DConditionModel, 1: AutoencoderKL encoder, 2: ControlNetModel, 3: AutoencoderKL decoder, 4: text encoder (1-4: inference only)
   std::vector<int> cn_out;           // ControlNet: output tensors (down residuals in diffusers order, mid last)
   int ce_begin = -1, ce_end = -1;    // ControlNet: op range of the conditioning embedding (constant over a generation)
   bool ce_valid = false;             // ... already computed for the current conditioning image
@@ -129,6 +139,12 @@ struct Unet {
   int build();
   int build_vae_encoder();
   int build_vae_decoder();
+  int build_text();
+  PeaTextCfg tcfg{};                 // graph 4: text encoder
+  std::vector<int> hidden;           // graph 4: hidden_states[0..layers] tensor ids; t_final = final LN output, t_pooled
+  int t_final = -1, t_pooled = -1;
+  const long long* ids_in = nullptr;
+  int* kvlen = nullptr;              // graph 4 (BERT): per-sample valid token count
   int exec_ops(size_t begin, size_t end, bool skip_cached, hipStream_t s);
   int alloc();
   int load_weight(const char* name, const float* dev_ptr, long long numel, hipStream_t s);

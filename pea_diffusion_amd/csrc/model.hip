@@ -100,12 +100,12 @@ struct Builder {
     o.p0 = silu; o.f0 = eps; o.aux_bytes = sizeof(float) * 2 * u.B * u.cfg.groups;
     return out;
   }
-  int ln(int x, const std::string& pfx) {
+  int ln(int x, const std::string& pfx, float eps = 1e-5f) {
     const int C = u.tn[x].cols;
     const int out = T(u.tn[x].rows, C, u.tn[x].B, u.tn[x].H, u.tn[x].W);
     Op& o = push(OP_LN);
     o.a = x; o.out = out; o.w = vec(pfx + ".weight", C); o.bias = vec(pfx + ".bias", C);
-    o.f0 = 1e-5f; o.aux_bytes = sizeof(float) * 2 * u.tn[x].rows;
+    o.f0 = eps; o.aux_bytes = sizeof(float) * 2 * u.tn[x].rows;
     return out;
   }
   int silu(int x) {
@@ -364,7 +364,71 @@ int Unet::build_vae_decoder() {
   return PEA_OK;
 }
 
+// Text encoders in front of the step.  flavor 0: CLIPTextModel[WithProjection] (the teacher's two
+// encoders, train_sdxl_zh.py:147-150,170-285; HF transformers keys `text_model.*`, `text_projection.weight`): token +
+// position embeddings, pre-LN blocks with causal attention, final LayerNorm, pooled = final[EOS] @ text_projection.
+// flavor 1: BERT (the Chinese-CLIP text tower, train_sdxl_zh.py:103-107,327-329; keys `embeddings.*`,
+// `encoder.layer.N.*`): word + position + token-type embeddings -> LN, post-LN blocks, key-padding mask.
+int Unet::build_text() {
+  const PeaTextCfg& c = tcfg;
+  SHAPECHK(!needs_grad, "text encoder: inference graph only");
+  SHAPECHK(c.width % 64 == 0 && c.heads > 0 && c.width / c.heads == 64 && c.width % c.heads == 0,
+           "text encoder: width %d / heads %d (head_dim must be 64)", c.width, c.heads);
+  SHAPECHK(c.intermediate % 64 == 0 && c.layers >= 1 && L <= c.max_pos && c.proj_dim % 4 == 0, "text encoder: dims");
+  Builder bd(*this);
+  const bool bert = c.flavor == 1;
+  const std::string emb = bert ? "embeddings." : "text_model.embeddings.";
+  const int W = c.width;
+  int x = bd.T((long long)B * L, W, B, 1, L);
+  {
+    Op& o = bd.push(OP_EMBED);
+    o.out = x;
+    o.w = bd.lin(emb + (bert ? "word_embeddings.weight" : "token_embedding.weight"), c.vocab, W);
+    o.bias = bd.lin(emb + (bert ? "position_embeddings.weight" : "position_embedding.weight"), c.max_pos, W);
+    if (bert) o.c = bd.lin(emb + "token_type_embeddings.weight", 2, W);
+  }
+  if (bert) x = bd.ln(x, emb + "LayerNorm", c.eps);
+  hidden.push_back(x);
+  const float scale = 0.125f;
+  for (int i = 0; i < c.layers; ++i) {
+    const std::string p = (bert ? "encoder.layer." : "text_model.encoder.layers.") + std::to_string(i);
+    const int a_in = bert ? x : bd.ln(x, p + ".layer_norm1", c.eps);
+    const int qkv = bert ? bd.fused_linear(a_in, {p + ".attention.self.query", p + ".attention.self.key", p + ".attention.self.value"}, {W, W, W}, true)
+                         : bd.fused_linear(a_in, {p + ".self_attn.q_proj", p + ".self_attn.k_proj", p + ".self_attn.v_proj"}, {W, W, W}, true);
+    const int att = bd.T((long long)B * L, W, B, 1, L);
+    {
+      Op& o = bd.push(OP_ATTN);
+      o.a = qkv; o.acol = 0; o.b = qkv; o.bcol = W; o.c = qkv; o.ccol = 2 * W; o.out = att;
+      o.p0 = c.heads; o.p1 = L; o.p2 = L; o.p3 = 1; o.f0 = scale; o.mask = bert ? 2 : 1;
+    }
+    if (bert) {
+      int y = bd.linear(att, p + ".attention.output.dense", W, true, x);
+      x = bd.ln(y, p + ".attention.output.LayerNorm", c.eps);
+      int f = bd.linear(x, p + ".intermediate.dense", c.intermediate, true);
+      ops.back().p2 = c.act;
+      y = bd.linear(f, p + ".output.dense", W, true, x);
+      x = bd.ln(y, p + ".output.LayerNorm", c.eps);
+    } else {
+      x = bd.linear(att, p + ".self_attn.out_proj", W, true, x);
+      const int n2 = bd.ln(x, p + ".layer_norm2", c.eps);
+      int f = bd.linear(n2, p + ".mlp.fc1", c.intermediate, true);
+      ops.back().p2 = c.act;
+      x = bd.linear(f, p + ".mlp.fc2", W, true, x);
+    }
+    hidden.push_back(x);
+  }
+  t_final = x;
+  if (!bert) {
+    t_final = bd.ln(x, "text_model.final_layer_norm", c.eps);
+    const int eos = bd.T(B, W, B);
+    { Op& o = bd.push(OP_GATHER_EOS); o.a = t_final; o.out = eos; }
+    t_pooled = c.proj_dim ? bd.linear(eos, "text_projection", c.proj_dim, false) : eos;
+  }
+  return PEA_OK;
+}
+
 int Unet::build() {
+  if (graph == 4) return build_text();
   if (graph == 1) return build_vae_encoder();
   if (graph == 3) return build_vae_decoder();
   const PeaUnetCfg& c = cfg;
@@ -652,6 +716,7 @@ int Unet::alloc() {
     const Tn& t = tn[t_out_in];
     HIPCHK(hipMalloc((void**)&vae_h, sizeof(float) * (size_t)B * cfg.out_channels * t.H * t.W));
   }
+  if (graph == 4) HIPCHK(hipMalloc((void**)&kvlen, sizeof(int) * B));
   if (graph == 3) HIPCHK(hipMalloc((void**)&vae_h, sizeof(float) * (size_t)B * cfg.in_channels * H * W));   // post_quant_conv(z / s)
   RC(pea_zero_page(&zeros));
   return PEA_OK;
@@ -673,6 +738,7 @@ Unet::~Unet() {
   if (am_scores) hipFree(am_scores);
   if (am_vt) hipFree(am_vt);
   if (vae_h) hipFree(vae_h);
+  if (kvlen) hipFree(kvlen);
 }
 
 int Unet::load_weight(const char* name, const float* src, long long numel, hipStream_t s) {
@@ -807,7 +873,7 @@ int Unet::exec_ops(size_t begin, size_t end, bool skip_cached, hipStream_t s) {
         p.A = a.d; p.lda = a.cols; p.M = (int)a.rows; p.K = a.cols; p.N = out.cols;
         if (o.fused >= 0) { FusedMat& f = fused[o.fused]; p.W = f.w; p.ldw = f.K; p.bias = f.bias; }
         else { WSlot& w = slots[o.w]; p.W = w.w; p.ldw = w.ldw; p.bias = o.bias >= 0 ? slots[o.bias].f32 : nullptr; }
-        p.C = out.d; p.ldc = out.cols;
+        p.C = out.d; p.ldc = out.cols; p.act = o.p2;
         if (o.p3 == 3) {                  // fused GEGLU: N = 8C interleaved, y -> out, pre-activation -> op.c (student only)
           p.N = 2 * out.cols; p.geglu_y = out.d; p.ldy = out.cols;
           p.C = o.c >= 0 ? tn[o.c].d : nullptr; p.ldc = 2 * out.cols;
@@ -833,6 +899,16 @@ int Unet::exec_ops(size_t begin, size_t end, bool skip_cached, hipStream_t s) {
         }
         break;
       }
+      case OP_EMBED: {
+        SHAPECHK(ids_in != nullptr, "text encoder: no input ids");
+        Tn& out = tn[o.out];
+        RC(launch_embed_tokens(ids_in, slots[o.w].w, slots[o.bias].w, o.c >= 0 ? slots[o.c].w : nullptr, out.d, B, L, out.cols,
+                               tcfg.vocab, s));
+        break;
+      }
+      case OP_GATHER_EOS:
+        RC(launch_gather_eos(ids_in, tn[o.a].d, tn[o.out].d, B, L, tn[o.a].cols, tcfg.eos_id, s));
+        break;
       case OP_ADD:
         RC(launch_add(tn[o.a].d, tn[o.b].d, tn[o.out].d, tn[o.out].rows * tn[o.out].cols, s));
         break;
@@ -882,6 +958,7 @@ int Unet::exec_ops(size_t begin, size_t end, bool skip_cached, hipStream_t s) {
         p.Q = tn[o.a].d + o.acol; p.ldq = tn[o.a].cols; p.K = tn[o.b].d + o.bcol; p.ldk = tn[o.b].cols;
         p.V = tn[o.c].d + o.ccol; p.ldv = tn[o.c].cols; p.O = tn[o.out].d; p.ldo = tn[o.out].cols; p.lse = o.aux;
         p.B = B; p.H = o.p0; p.Sq = o.p1; p.Skv = o.p2; p.scale = o.f0; p.nd = o.p3;
+        p.causal = o.mask & 1; p.kv_len = (o.mask & 2) ? kvlen : nullptr;
         RC(launch_attention_fwd(p, s));
         break;
       }

@@ -17,7 +17,7 @@ struct GemmP {
   float alpha;
   const float* bias;               // [N] fp32 or null
   const bf16* rowvec; int ldrv; int rows_per_batch;   // + rowvec[m / rows_per_batch][n]
-  int act;                         // 0 none, 1 GELU(erf), 2 SiLU   (applied after bias/rowvec)
+  int act;                         // 0 none, 1 GELU(erf), 2 SiLU, 3 quick-GELU x*sigmoid(1.702x)  (after bias/rowvec)
   bf16* preact; int ldpre;         // optional: store the pre-activation value (bf16)
   const bf16* res; int ldres;      // + res[m][n] after activation (may alias C: accumulate)
   // conv (mode 1): source NHWC [B][Hs][Ws][Cin]; output pixels [B][Ho][Wo]; M = B*Ho*Wo
@@ -80,6 +80,8 @@ struct AttnP {
   int accum_dq, accum_dkv;         // += into existing gradients
   float* dkv_part; int nsplit;     // optional fp32 scratch (attention_bwd_scratch_bytes) enabling the query split
   int nd;                          // padded head_dim / 64 (0 is read as 1)
+  int causal;                      // forward only: key index <= query index (text encoders)
+  const int* kv_len;               // forward only: per-sample number of valid keys (key padding mask), may be null
 };
 int attention_bwd_nsplit(int B, int H, int Sq, int Skv);
 size_t attention_bwd_scratch_bytes(int B, int H, int Sq, int Skv, int nd = 1);
@@ -189,3 +191,7 @@ int launch_vae_posterior(const float* h, const float* wq, const float* bq, const
                          float* latents, int B, int C2, long long HW, float scaling, hipStream_t s);
 int launch_vae_post_quant(const float* z, const float* w, const float* b, float* out, int B, int C, long long HW,
                           float inv_scaling, hipStream_t s);
+int launch_embed_tokens(const long long* ids, const bf16* tok, const bf16* pos, const bf16* type0, bf16* out, int B, int L,
+                        int width, int vocab, hipStream_t s);
+int launch_gather_eos(const long long* ids, const bf16* x, bf16* out, int B, int L, int width, long long eos_id, hipStream_t s);
+int launch_kv_len(const long long* ids, int* len, int B, int L, long long pad_id, hipStream_t s);
