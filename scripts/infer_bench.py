@@ -14,6 +14,7 @@ ap.add_argument("--images", type=int, default=4)
 ap.add_argument("--steps", type=int, default=30)
 ap.add_argument("--no-controlnet", action="store_true")
 ap.add_argument("--latent", type=int, default=128)
+ap.add_argument("--end-to-end", action="store_true", help="also: Chinese-CLIP text tower + adapter in front, VAE decode behind")
 a = ap.parse_args()
 cfg = pc.sdxl_config()
 N, hw = a.images, a.latent
@@ -52,3 +53,27 @@ print(f"SDXL{'' if cn is None else ' + ControlNet'} {hw*8}x{hw*8}, {N} images (U
       f"{dt:.3f} s/generation = {dt/N:.3f} s/image, {a.steps/dt:.2f} it/s, "
       f"{tf_img_step*N*a.steps/dt:.0f} TFLOP/s; latents finite={bool(torch.isfinite(out).all())}; "
       f"unet mem {unet.memory()['activation_bytes']/2**30:.1f} GiB act" + ("" if cn is None else f", controlnet {cn.memory()['activation_bytes']/2**30:.1f} GiB act"))
+
+if a.end_to_end:
+    # tests/test_sdxl_zh.py:153-290 (encode_prompt through the adapter) and :408-431 (VAE decode)
+    from pea_diffusion_amd.adapter import PEAAdapter
+    from pea_diffusion_amd.text import HipTextEncoder
+    from pea_diffusion_amd.vae import HipVAEDecoder
+    zh = HipTextEncoder(pc.cnclip_bert_large_config(), 2 * N, 52); zh.init_random(3)
+    proj = PEAAdapter(1024, 1280, 2048, 2048, False).to(dev)
+    dec = HipVAEDecoder(pc.sdxl_vae_config(), N, hw, hw); dec.init_random(4)
+    unet52 = None
+    ids = torch.randint(1, 21000, (2 * N, 52), generator=g); ids[:, 30:] = 0
+    ids = ids.to(dev)
+    def front():
+        tok, _ = zh.encode_text(ids)
+        pooled, tokens = proj(tok.to(torch.float32))
+        return pooled, tokens
+    def back(lat_):
+        return dec.decode(lat_, inv_scaling=1.0 / pc.sdxl_vae_config().scaling_factor)[0]
+    front(); back(out); torch.cuda.synchronize()
+    t0 = time.perf_counter(); pooled, tokens = front(); torch.cuda.synchronize(); t_front = time.perf_counter() - t0
+    t0 = time.perf_counter(); img = back(out); torch.cuda.synchronize(); t_back = time.perf_counter() - t0
+    print(f"end to end: text tower + adapter {t_front*1e3:.1f} ms (tokens {tuple(tokens.shape)}, pooled {tuple(pooled.shape)}), "
+          f"denoise {dt:.3f} s, VAE decode {t_back*1e3:.1f} ms (image {tuple(img.shape)}, finite={bool(torch.isfinite(img).all())}) "
+          f"=> {t_front + dt + t_back:.3f} s for {N} images")
