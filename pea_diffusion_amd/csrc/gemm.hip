@@ -107,9 +107,24 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x16 (&acc)[NI][
 }
 
 // ---- epilogue for the 16x16x32 accumulator layout: acc[nt][mt][j] = D[n = 4*(lane>>4) + j][m = lane&15]
-template <int MT, int NT, int M0 = 0, int M1 = MT>
+template <int MT, int NT, int M0 = 0, int M1 = MT, bool PRELOAD_RES = false>
 __device__ __forceinline__ void gemm_epilogue16(const GemmP& p, f32x4 (&acc)[NT][MT], int m_base, int n_base, int r16,
                                                 int q4) {
+  // PRELOAD_RES (one-tile-per-workgroup kernel, where the K-loop's fragment registers are dead by now): the residual
+  // tile first -- all of its 8-byte quads are requested before any arithmetic, so the tile pays ONE global-load latency
+  // instead of one per (mt, nt) group.  The persistent kernel keeps the next tile's fragments live and has no room.
+  bf16x4 resq[PRELOAD_RES ? NT : 1][PRELOAD_RES ? MT : 1];
+  if (PRELOAD_RES && p.res) {
+#pragma unroll
+    for (int mt = M0; mt < M1; ++mt) {
+      const int m = min(m_base + mt * 16 + r16, p.M - 1);
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const int n = min(n_base + nt * 16 + 4 * q4, p.N - 4);
+        resq[nt][mt] = *(const bf16x4*)(p.res + (long long)m * p.ldres + n);
+      }
+    }
+  }
   // everything of the epilogue except the final store of C; false: nothing to store (GEGLU without the stash)
   auto value = [&](int mt, int nt, int m, int bidx, float (&v)[4]) -> bool {
     const int n = n_base + nt * 16 + 4 * q4;
@@ -149,7 +164,9 @@ __device__ __forceinline__ void gemm_epilogue16(const GemmP& p, f32x4 (&acc)[NT]
       for (int j = 0; j < 4; ++j) v[j] = v[j] * sigmoidf_(1.702f * v[j]);
     }
     if (p.res) {
-      const bf16x4 rr = *(const bf16x4*)(p.res + (long long)m * p.ldres + n);
+      bf16x4 rr;
+      if constexpr (PRELOAD_RES) rr = resq[nt][mt];
+      else rr = *(const bf16x4*)(p.res + (long long)m * p.ldres + n);
 #pragma unroll
       for (int j = 0; j < 4; ++j) v[j] += (float)rr[j];
     }
@@ -434,7 +451,7 @@ __global__ __launch_bounds__((WM * WN + LW) * 64, MINW) void gemm_lc_kernel(cons
     }
     GemmP q = p;
     if (p.ksplit > 1) q.C = (float*)p.C + (long long)blockIdx.y * p.split_stride;
-    gemm_epilogue16<MT, NT>(q, acc, bm * BM + wr * (BM / WM), bn * BN + wc * (BN / WN), r16, q4);
+    gemm_epilogue16<MT, NT, 0, MT, true>(q, acc, bm * BM + wr * (BM / WM), bn * BN + wc * (BN / WN), r16, q4);
     return;
   }
   const int wr = wave / WN, wc = wave % WN;

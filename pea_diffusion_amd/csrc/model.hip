@@ -880,6 +880,13 @@ int Unet::exec_ops(size_t begin, size_t end, bool skip_cached, hipStream_t s) {
           if (bwd_batch > 0) p.stash_rows = (int)(out.rows / B * bwd_batch);   // only the differentiated samples are stashed
         }
         if (o.res >= 0) { p.res = tn[o.res].d; p.ldres = tn[o.res].cols; }
+        static const bool geglu_unfused = getenv("PEA_GEGLU_UNFUSED") != nullptr;   // A/B switch for experiments
+        if (o.p3 == 3 && geglu_unfused && o.c >= 0) {
+          p.geglu_y = nullptr; p.stash_rows = 0;
+          RC(launch_gemm(p, s));
+          RC(launch_geglu_fwd_il(tn[o.c].d, out.d, out.rows, out.cols, s));
+          break;
+        }
         RC(launch_gemm(p, s));
         break;
       }
