@@ -255,6 +255,7 @@ int pea_unet_tap_export_nchw(void* unet, int k, int grad, float* out, void* stre
  * pea_unet_input_grads -> bf16 d(ehs) [B][L][cross], d(text_embeds) [B][pooled].                 */
 int pea_unet_backward(void* unet, const float* deps, unsigned tap_seed_mask, void* stream);
 int pea_unet_input_grads(void* unet, void** d_ehs, void** d_text);
+/* resident bytes: weights; activations and gradients (allocated on the first forward / backward, 0 before) */
 int pea_unet_memory(void* unet, long long* weight_bytes, long long* act_bytes, long long* grad_bytes, int* n_ops);
 
 /* The PEA adapter `MLP(in_dim, out_dim, hidden_dim, out_dim1, use_residual)` (train_sdxl_zh.py:43-67);

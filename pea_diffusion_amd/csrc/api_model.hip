@@ -97,6 +97,7 @@ int pea_controlnet_output(void* h, int i, void** ptr, int* C, int* H, int* W) {
     pea_set_error("pea_controlnet_output: index %d out of range (%d outputs)", i, (int)u->cn_out.size());
     return PEA_E_INVALID;
   }
+  { int rc = u->ensure_acts(); if (rc != PEA_OK) return rc; }
   const Tn& t = u->tn[u->cn_out[i]];
   if (ptr) *ptr = t.d;
   if (C) *C = t.cols;
@@ -152,6 +153,7 @@ int pea_vae_encode(void* h, const float* pixels, const float* noise, float scali
   Unet* u = (Unet*)h;
   if (u->graph != 1) { pea_set_error("pea_vae_encode: not a VAE encoder handle"); return PEA_E_INVALID; }
   hipStream_t s = (hipStream_t)stream;
+  { int rc0 = u->ensure_acts(); if (rc0 != PEA_OK) return rc0; }
   int rc = u->forward(pixels, nullptr, nullptr, 0, nullptr, 0, nullptr, u->vae_h, s);
   if (rc != PEA_OK) return rc;
   const Tn& t = u->tn[u->t_out_in];
@@ -191,6 +193,7 @@ int pea_vae_decode(void* h, const float* latents, float inv_scaling, float* imag
     pea_set_error("vae decoder: weight '%s' was never loaded", miss.c_str());
     return PEA_E_STATE;
   }
+  { int rc0 = u->ensure_acts(); if (rc0 != PEA_OK) return rc0; }
   int rc = launch_vae_post_quant(latents, u->slots[u->w_quant].f32, u->slots[u->b_quant].f32, u->vae_h, u->B,
                                  u->cfg.in_channels, (long long)u->H * u->W, inv_scaling, s);
   if (rc != PEA_OK) return rc;
@@ -230,6 +233,7 @@ int pea_text_forward(void* h, const long long* ids, int hidden_index, float* hid
     pea_set_error("text encoder: weight '%s' was never loaded", miss.c_str());
     return PEA_E_STATE;
   }
+  { int rc0 = u->ensure_acts(); if (rc0 != PEA_OK) return rc0; }
   u->ids_in = ids;
   if (u->tcfg.flavor == 1) {
     int rc = launch_kv_len(ids, u->kvlen, u->B, u->L, u->tcfg.eos_id, s);
@@ -286,6 +290,7 @@ int pea_unet_set_residuals(void* h, int n, const void* const* ptrs, int dtype, f
                   (int)u->ext_res.size());
     return PEA_E_SHAPE;
   }
+  { int rc = u->ensure_acts(); if (rc != PEA_OK) return rc; }
   for (int i = 0; i < n; ++i) {
     Tn& t = u->tn[u->ext_res[i]];
     if (!ptrs[i]) {
@@ -347,6 +352,7 @@ int pea_unet_tap_info(void* h, int k, void** data, void** grad, int* B, int* H, 
     pea_set_error("pea_unet_tap_info: tap %d out of range", k);
     return PEA_E_INVALID;
   }
+  { int rc = u->ensure_acts(); if (rc != PEA_OK) return rc; }
   const Tn& t = u->tn[u->taps[k]];
   if (data) *data = t.d;
   if (grad) *grad = t.g;
@@ -363,6 +369,7 @@ int pea_unet_tap_export_nchw(void* h, int k, int grad, float* out, void* stream)
     pea_set_error("pea_unet_tap_export_nchw: tap %d out of range", k);
     return PEA_E_INVALID;
   }
+  { int rc = u->ensure_acts(); if (rc != PEA_OK) return rc; }
   const Tn& t = u->tn[u->taps[k]];
   const bf16* src = grad ? t.g : t.d;
   NOTNULL(src, "pea_unet_tap_export_nchw(grad)");
@@ -387,8 +394,9 @@ int pea_unet_memory(void* h, long long* weight_bytes, long long* act_bytes, long
   NOTNULL(h, "pea_unet_memory");
   Unet* u = (Unet*)h;
   if (weight_bytes) *weight_bytes = (long long)u->wbytes;
-  if (act_bytes) *act_bytes = (long long)u->abytes;
-  if (grad_bytes) *grad_bytes = (long long)u->gbytes;
+  /* activations / gradients are allocated on first use: report what is resident */
+  if (act_bytes) *act_bytes = u->aarena ? (long long)u->abytes : 0;
+  if (grad_bytes) *grad_bytes = u->garena ? (long long)u->gbytes : 0;
   if (n_ops) *n_ops = (int)u->ops.size();
   return PEA_OK;
 }
@@ -509,7 +517,7 @@ int pea_trainer_get_option(void* h, const char* name) {
   if (!strcmp(name, "merge_state")) return t->merge_state;     /* 0 undecided, 1 merged, -1 not eligible */
   if (!strcmp(name, "nan_guard")) return t->nan_guard;
   if (!strcmp(name, "merged_mib"))                                /* activations + gradients of the merged-pass context */
-    return t->merged ? (int)((t->merged->abytes + t->merged->gbytes) >> 20) : 0;
+    return t->merged && t->merged->aarena ? (int)((t->merged->abytes + t->merged->gbytes) >> 20) : 0;
   return PEA_E_INVALID;
 }
 int pea_trainer_export(void* h, int which, float* out, void* stream) {

@@ -146,6 +146,7 @@ struct Unet {
   const long long* ids_in = nullptr;
   int* kvlen = nullptr;              // graph 4 (BERT): per-sample valid token count
   int exec_ops(size_t begin, size_t end, bool skip_cached, hipStream_t s);
+  int ensure_acts();                 // lazy allocation of the activation / gradient arenas and scratch
   int alloc();
   int load_weight(const char* name, const float* dev_ptr, long long numel, hipStream_t s);
   int init_random(unsigned long long seed, hipStream_t s);

@@ -666,6 +666,14 @@ int Unet::alloc() {
   for (Op& o : ops)
     if (o.aux_bytes) { o.aux_off = ao; ao += al256(o.aux_bytes); }
   abytes = ao; gbytes = go;
+  return PEA_OK;
+}
+
+// Activation / gradient arenas and scratch are allocated on first use, not at creation: a trainer that runs merged
+// passes never touches the activations of the student and teacher contexts it was given (they only carry the weights),
+// which is half of the resident HBM at the benchmark size.
+int Unet::ensure_acts() {
+  if (aarena) return PEA_OK;
   HIPCHK(hipMalloc((void**)&aarena, abytes));
   if (gbytes) HIPCHK(hipMalloc((void**)&garena, gbytes));
   for (Tn& t : tn) {
@@ -832,6 +840,7 @@ int Unet::forward(const float* x, const float* t, const void* ehs, int ehs_dtype
     pea_set_error("unet: weight '%s' was never loaded", miss.c_str());
     return PEA_E_STATE;
   }
+  RC(ensure_acts());
   x_in = x; t_in = t; tid_in = time_ids; eps_out = eps;
   if (graph == 0 || graph == 2) {
     Tn& e = tn[t_ehs];
@@ -857,6 +866,7 @@ int Unet::forward(const float* x, const float* t, const void* ehs, int ehs_dtype
 
 // ops [begin, end) of the tape in order; skip_cached: leave out the ControlNet conditioning embedding when it is valid
 int Unet::exec_ops(size_t begin, size_t end, bool skip_cached, hipStream_t s) {
+  RC(ensure_acts());
   for (size_t oi = begin; oi < end; ++oi) {
     Op& o = ops[oi];
     if (skip_cached && ce_valid && (int)oi >= ce_begin && (int)oi < ce_end) continue;   // cached conditioning embedding
@@ -988,6 +998,7 @@ void Unet::begin_backward() {
 
 int Unet::backward(const float* deps, hipStream_t s) {
   SHAPECHK(needs_grad, "unet: created without gradient support");
+  RC(ensure_acts());
   // bwd_batch < B: the forward ran on B samples (student rows first, teacher rows behind them: merged passes of a
   // trainer whose teacher IS the student checkpoint) and only the first bwd_batch samples are differentiated.
   // Every tensor is batch-major, so the restricted pass is the same tape on the leading rows of every tensor.
@@ -1391,6 +1402,8 @@ int Trainer::step(const float* latents, const float* noise, const long long* tim
   if (merge_passes && merge_state == 1)
     return step_merged(latents, noise, timesteps, enc, enc_uncond, prompt_mask, zh, teacher_ehs, teacher_neg,
                        teacher_pooled, time_ids, grad_scale, grads, accumulate, losses_out, s);
+  RC(S.ensure_acts());
+  RC(Tt.ensure_acts());
   const long long per_img = (long long)S.cfg.in_channels * S.H * S.W;
   if (!t_f32) HIPCHK(hipMalloc((void**)&t_f32, sizeof(float) * B));
   RC(launch_add_noise(latents, noise, timesteps, ac, xt, B, per_img, s));
@@ -1467,6 +1480,7 @@ int Trainer::step_merged(const float* latents, const float* noise, const long lo
                          const float* time_ids, float grad_scale, float* grads, int accumulate, float* losses_out,
                          hipStream_t s) {
   Unet& M = *merged;
+  RC(M.ensure_acts());
   Adapter& A = *ad;
   const int B = student->B;
   const long long per_img = (long long)M.cfg.in_channels * M.H * M.W;
