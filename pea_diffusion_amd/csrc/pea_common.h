@@ -73,14 +73,31 @@ __device__ __forceinline__ float silu_grad(float x) {
   return s * (1.0f + x * (1.0f - s));
 }
 
+// Butterfly reductions over the 64 lanes.  The four steps inside a 16-lane row are DPP moves (one VALU instruction each:
+// quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_half_mirror, row_mirror -- after each step every lane of the group holds
+// the group's value, so the mirrors act as the xor-4 / xor-8 exchanges); only the two cross-row steps go through
+// ds_bpermute.  The all-__shfl_xor form compiled to six dependent ds_bpermute round trips (the LayerNorm kernels spent
+// most of their time in them).
+template <int CTRL>
+__device__ __forceinline__ float dpp_move(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  v += dpp_move<0xB1>(v);
+  v += dpp_move<0x4E>(v);
+  v += dpp_move<0x141>(v);
+  v += dpp_move<0x140>(v);
+  v += __shfl_xor(v, 16, 64);
+  v += __shfl_xor(v, 32, 64);
   return v;
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  v = fmaxf(v, dpp_move<0xB1>(v));
+  v = fmaxf(v, dpp_move<0x4E>(v));
+  v = fmaxf(v, dpp_move<0x141>(v));
+  v = fmaxf(v, dpp_move<0x140>(v));
+  v = fmaxf(v, __shfl_xor(v, 16, 64));
+  v = fmaxf(v, __shfl_xor(v, 32, 64));
   return v;
 }
 
