@@ -228,47 +228,42 @@ __device__ __forceinline__ void gemm_epilogue16(const GemmP& p, f32x4 (&acc)[NT]
   }
 }
 
-// lean slice epilogue for the deferred form: alpha, optional bias, bf16 output, every n-tile pair inside N (the launcher
-// guarantees N % 32 == 0, ldc % 8 == 0, C 16-byte aligned); few live values, so it can sit inside the K-loop
+// lean slice epilogue for the deferred form: alpha, optional bias, bf16 output (ldc % 8 == 0, C 16-byte aligned: the
+// launcher's rule); few live values, so it can sit inside the K-loop
 template <int MT, int NT, int M0, int M1>
 __device__ __forceinline__ void gemm_epilogue16_lean(const GemmP& p, f32x4 (&acc)[NT][MT], int m_base, int n_base,
                                                      int r16, int q4) {
   typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+  auto quad = [&](int mt, int nt) -> bf16x4 {
+    const int n = min(n_base + nt * 16 + 4 * q4, p.N - 4);
+    f32x4 b0 = {0.f, 0.f, 0.f, 0.f};
+    if (p.bias) b0 = *(const f32x4*)(p.bias + n);
+    bf16x4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = (bf16)(acc[nt][mt][j] * p.alpha + b0[j]);
+    return o;
+  };
 #pragma unroll
   for (int mt = M0; mt < M1; ++mt) {
     const int m = m_base + mt * 16 + r16;
-    if (m >= p.M) continue;
+    if (m >= p.M) continue;               // depends on r16 only: the four q4 lanes of a row leave together
     bf16* crow = (bf16*)p.C + (long long)m * p.ldc;
 #pragma unroll
-    for (int nt = 0; nt < NT; nt += 2) {
-      if (nt + 1 < NT) {
-        if (n_base + nt * 16 >= p.N) continue;
+    for (int nt = 0; nt < NT; ++nt) {
+      if ((nt & 1) == 0 && nt + 1 < NT && n_base + (nt + 2) * 16 <= p.N) {      // both n-tiles inside N: 16-byte stores
         union { bf16x4 h; unsigned u[2]; } a, b;
-        f32x4 b0 = {0.f, 0.f, 0.f, 0.f}, b1 = {0.f, 0.f, 0.f, 0.f};
-        if (p.bias) {
-          b0 = *(const f32x4*)(p.bias + n_base + nt * 16 + 4 * q4);
-          b1 = *(const f32x4*)(p.bias + n_base + (nt + 1) * 16 + 4 * q4);
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          a.h[j] = (bf16)(acc[nt][mt][j] * p.alpha + b0[j]);
-          b.h[j] = (bf16)(acc[nt + 1][mt][j] * p.alpha + b1[j]);
-        }
+        a.h = quad(mt, nt);
+        b.h = quad(mt, nt + 1);
         const auto lo = __builtin_amdgcn_permlane16_swap(a.u[0], b.u[0], false, false);
         const auto hi = __builtin_amdgcn_permlane16_swap(a.u[1], b.u[1], false, false);
         const u32x4 o = {lo[0], hi[0], lo[1], hi[1]};
-        if (p.debug & 64) { if (o[0] == 0x12345678u) *(u32x4*)crow = o; }   // timing experiment: no store traffic
-        else *(u32x4*)(crow + n_base + (nt + (q4 & 1)) * 16 + 8 * (q4 >> 1)) = o;
-      } else {
-        const int n = n_base + nt * 16 + 4 * q4;
-        if (n >= p.N) continue;
-        f32x4 b0 = {0.f, 0.f, 0.f, 0.f};
-        if (p.bias) b0 = *(const f32x4*)(p.bias + n);
-        bf16x4 o;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) o[j] = (bf16)(acc[nt][mt][j] * p.alpha + b0[j]);
-        *(bf16x4*)(crow + n) = o;
+        *(u32x4*)(crow + n_base + (nt + (q4 & 1)) * 16 + 8 * (q4 >> 1)) = o;
+        continue;
       }
+      if ((nt & 1) == 1 && n_base + (nt + 1) * 16 <= p.N) continue;              // stored with its left neighbour
+      const int n = n_base + nt * 16 + 4 * q4;
+      if (n >= p.N) continue;
+      *(bf16x4*)(crow + n) = quad(mt, nt);
     }
   }
 }
@@ -619,10 +614,11 @@ __global__ __launch_bounds__((WM * WN + LW + SW) * 64) void gemm_lcp_kernel(cons
     };
     __builtin_amdgcn_s_barrier();                              // prologue barrier
     int ti = 0, t = 0;
-    for (int g = 0; g + 1 < G; ++g) {
+    for (int g = 0; g < G; ++g) {                              // SW > 0: every K-step has its barrier, the last one too
       __builtin_amdgcn_s_barrier();                            // barrier_g
       // tile ti-1 was staged before the barrier of this tile's first K-step; spread its NP passes over K-steps
-      // 0 .. nt-2 (after the last one the MFMA waves overwrite the image)
+      // 0 .. nt-2 (the MFMA waves overwrite the image after barrier nt-1, which this wave reaches only when its
+      // reads of the last slice have returned)
       if (ti > 0 && t < nt - 1) drain(ti - 1, t * NP / (nt - 1), (t + 1) * NP / (nt - 1));
       if (++t == nt) { t = 0; ++ti; }
     }
@@ -721,7 +717,10 @@ __global__ __launch_bounds__((WM * WN + LW + SW) * 64) void gemm_lcp_kernel(cons
       if (g + S < G) produce(cur);
       cur = cur + 1 == S ? 0 : cur + 1;
     }
-    if (SW > 0) __builtin_amdgcn_s_barrier();                  // final barrier (store waves drain the last tile after it)
+    if (SW > 0) {
+      __builtin_amdgcn_s_barrier();                            // barrier of the last K-step (staged form only)
+      __builtin_amdgcn_s_barrier();                            // final barrier (store waves drain the last tile after it)
+    }
     return;
   }
 
@@ -774,6 +773,8 @@ __global__ __launch_bounds__((WM * WN + LW + SW) * 64) void gemm_lcp_kernel(cons
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();                      // barrier_g
             load_frags(0, smem + nxt * STAGE, 0);              // first fragments of K-step g+1 (maybe the next tile's)
+          } else if (SW > 0) {
+            __builtin_amdgcn_s_barrier();                      // staged form: the last K-step keeps its barrier
           }
         } else {
           load_frags(1, tile, 1);

@@ -83,6 +83,37 @@ def test_gemm_epilogues(ops):
     close_bf16("gemm bf16 accumulate", gbuf, a.float() @ w.float().T + res.float())
 
 
+@pytest.mark.parametrize("variant", [18, 19, 22, 23, 24, 25, 27, 28, 29, 30, 31, 33, 34, 35])
+def test_gemm_every_variant_ragged_shapes(ops, variant):
+    """Every kernel form the launcher can pick (or that an experiment switch selects), forced on shapes that do not fit its
+    tiles: ragged M, N that ends inside a tile / inside a 32-column store pair, fewer and more tiles than CUs (the
+    persistent kernels' tile walk), with the epilogue terms each form supports."""
+    import ctypes
+    from pea_diffusion_amd._lib import lib
+    L = lib()
+    g = torch.Generator().manual_seed(variant)
+    shapes = [(308, 640, 128), (1000, 104, 192), (4100, 1288, 256), (130, 3840, 64), (33000, 336, 128), (64, 160, 640)]
+    try:
+        for (M, N, K) in shapes:
+            a = (torch.randn(M, K, generator=g)).to(BF)
+            w = (torch.randn(N, K, generator=g) * K ** -0.5).to(BF)
+            bias = torch.randn(N, generator=g)
+            res = torch.randn(M, N, generator=g).to(BF)
+            ref = a.float() @ w.float().T
+            L.pea_debug_set_gemm_variant(variant)
+            out = ops.gemm(a.cuda(), w.cuda())
+            close_bf16(f"v{variant} plain {M}x{N}x{K}", out, ref)
+            out = ops.gemm(a.cuda(), w.cuda(), bias=bias.cuda())
+            close_bf16(f"v{variant} bias {M}x{N}x{K}", out, ref + bias)
+            if variant not in (34, 35):            # staged / deferred epilogues: bf16 output, bias only (the launcher's rule)
+                out = ops.gemm(a.cuda(), w.cuda(), bias=bias.cuda(), act=2, res=res.cuda())
+                close_bf16(f"v{variant} bias+silu+res {M}x{N}x{K}", out, F.silu(ref + bias) + res.float())
+                o32 = ops.gemm(a.cuda(), w.cuda(), out_f32=True)
+                close_f32(f"v{variant} fp32 {M}x{N}x{K}", o32, ref, rtol=2e-3, atol=2e-3)
+    finally:
+        L.pea_debug_set_gemm_variant(-1)
+
+
 # ------------------------------------------------------------------------------------ conv
 def _nhwc(x_nchw):
     return x_nchw.permute(0, 2, 3, 1).contiguous()
@@ -101,6 +132,26 @@ def test_conv3x3_fwd(ops, B, H, Cin, Cout, stride, ups):
     wp = ops.pack_conv(wq.cuda())
     y = ops.conv3x3(_nhwc(x).cuda(), wp, bias=bias.cuda(), stride=stride, upsample2x=ups)
     close_bf16(f"conv3x3 B{B} H{H} {Cin}->{Cout} s{stride} ups{ups}", y, _nhwc(ref))
+
+
+@pytest.mark.parametrize("variant", [22, 23, 24, 25, 27, 28, 29, 30, 31, 33])
+def test_conv3x3_every_variant(ops, variant):
+    """the implicit-GEMM gather (padding, stride 2, folded nearest-2x upsample) under every tile shape / kernel form"""
+    from pea_diffusion_amd._lib import lib
+    L = lib()
+    try:
+        for (B, H, Cin, Cout, stride, ups) in [(2, 20, 64, 192, 1, False), (3, 18, 128, 128, 2, False), (1, 12, 64, 320, 1, True)]:
+            x = bfr(B, Cin, H, H, seed=variant)
+            wq = (torch.randn(Cout, Cin, 3, 3, generator=torch.Generator().manual_seed(2)) * (9 * Cin) ** -0.5).to(BF).float()
+            bias = torch.randn(Cout, generator=torch.Generator().manual_seed(3))
+            xin = F.interpolate(x.float(), scale_factor=2.0, mode="nearest") if ups else x.float()
+            ref = F.conv2d(xin, wq, bias, stride=stride, padding=1)
+            wp = ops.pack_conv(wq.cuda())
+            L.pea_debug_set_gemm_variant(variant)
+            y = ops.conv3x3(_nhwc(x).cuda(), wp, bias=bias.cuda(), stride=stride, upsample2x=ups)
+            close_bf16(f"v{variant} conv B{B} H{H} {Cin}->{Cout} s{stride} ups{ups}", y, _nhwc(ref))
+    finally:
+        L.pea_debug_set_gemm_variant(-1)
 
 
 def test_conv3x3_epilogue_rowvec_res(ops):
