@@ -86,6 +86,11 @@ int pea_op_layernorm_bwd(const void* x, const void* dy, const float* gamma, cons
  * 64*nd is zero padded (SD1.5: 40 -> 64, 80 -> 128, 160 -> 192) and `scale` stays head_dim^-0.5.  lse fp32 [B][H][Sq]. */
 int pea_op_attention_fwd(const void* Q, int ldq, const void* K, int ldk, const void* V, int ldv, void* O, int ldo,
                          float* lse, int B, int H, int Sq, int Skv, float scale, int nd, void* stream);
+/* text-encoder attention (head_dim 64, forward only): `causal` = key index <= query index (CLIP text model), kv_len =
+ * device int[B] of valid key counts (BERT right padding) or NULL */
+int pea_op_attention_fwd_masked(const void* Q, int ldq, const void* K, int ldk, const void* V, int ldv, void* O, int ldo,
+                                float* lse, int B, int H, int Sq, int Skv, float scale, int causal, const int* kv_len,
+                                void* stream);
 /* dQ/dK/dV (dQ may be NULL; dK and dV together); delta: fp32 scratch [B][H][Sq]; scratch: optional device
  * buffer of pea_op_attention_bwd_scratch_bytes(...) bytes enabling the query-split dK/dV form used when the
  * key count is small (cross-attention); NULL = single pass                                            */

@@ -118,6 +118,16 @@ int pea_op_attention_fwd(const void* Q, int ldq, const void* K, int ldk, const v
   p.O = (bf16*)O; p.ldo = ldo; p.lse = lse; p.B = B; p.H = H; p.Sq = Sq; p.Skv = Skv; p.scale = scale; p.nd = nd;
   return launch_attention_fwd(p, (hipStream_t)stream);
 }
+int pea_op_attention_fwd_masked(const void* Q, int ldq, const void* K, int ldk, const void* V, int ldv, void* O, int ldo,
+                                float* lse, int B, int H, int Sq, int Skv, float scale, int causal, const int* kv_len,
+                                void* stream) {
+  AttnP p;
+  memset(&p, 0, sizeof(p));
+  p.Q = (const bf16*)Q; p.K = (const bf16*)K; p.V = (const bf16*)V; p.ldq = ldq; p.ldk = ldk; p.ldv = ldv;
+  p.O = (bf16*)O; p.ldo = ldo; p.lse = lse; p.B = B; p.H = H; p.Sq = Sq; p.Skv = Skv; p.scale = scale; p.nd = 1;
+  p.causal = causal; p.kv_len = kv_len;
+  return launch_attention_fwd(p, (hipStream_t)stream);
+}
 int pea_op_attention_bwd(const void* Q, int ldq, const void* K, int ldk, const void* V, int ldv, const void* O,
                          int ldo, const void* dO, int lddo, const float* lse, float* delta, void* dQ, int lddq,
                          void* dK, int lddk, void* dV, int lddv, int B, int H, int Sq, int Skv, float scale,

@@ -135,6 +135,17 @@ def attention_fwd(q, k, v, heads, scale=None):
     return o, lse
 
 
+def attention_fwd_masked(q, k, v, heads, causal=False, kv_len=None, scale=None):
+    """text-encoder attention: head_dim 64, optional causal mask and per-sample key counts (int32 [B])"""
+    B, Sq, C = q.shape
+    Skv = k.shape[1]
+    scale = scale if scale is not None else (C // heads) ** -0.5
+    o = torch.empty(B, Sq, C, device=q.device, dtype=BF)
+    check(lib().pea_op_attention_fwd_masked(ptr(q), q.stride(1), ptr(k), k.stride(1), ptr(v), v.stride(1), ptr(o), C, None,
+                                            B, heads, Sq, Skv, scale, int(causal), ptr(kv_len), stream_ptr()))
+    return o
+
+
 def attention_bwd(q, k, v, o, do, lse, heads, scale=None):
     B, Sq, C = q.shape
     Skv = k.shape[1]

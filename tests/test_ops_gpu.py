@@ -370,3 +370,24 @@ def test_attention_padded_heads(ops, d, H, Sq, Skv):
         gg = g.float().cpu().view(B, S, H, dp)
         close_bf16(f"attn d{d} {name}", gg[..., :d], r, ulps=4.0)
         assert d == dp or gg[..., d:].abs().max() == 0
+
+
+@pytest.mark.parametrize("B,H,S,causal,padded", [(2, 2, 77, True, False), (3, 4, 52, False, True), (2, 3, 200, True, True),
+                                                 (1, 2, 130, True, False), (2, 2, 64, False, True)])
+def test_attention_text_masks(ops, B, H, S, causal, padded):
+    """causal and key-padding masks of the text encoders (separate instance of the forward kernel) vs torch SDPA"""
+    C = H * 64
+    q, k, v = bfr(B, S, C, seed=1), bfr(B, S, C, seed=2), bfr(B, S, C, seed=3)
+    g = torch.Generator().manual_seed(4)
+    lens = torch.randint(1, S + 1, (B,), generator=g) if padded else torch.full((B,), S)
+    mask = torch.zeros(B, 1, S, S)
+    if causal:
+        mask = mask + torch.full((S, S), float("-inf")).triu(1)
+    for b in range(B):
+        mask[b, :, :, int(lens[b]):] = float("-inf")
+    sp = lambda t: t.float().view(B, S, H, 64).transpose(1, 2)
+    ref = F.scaled_dot_product_attention(sp(q), sp(k), sp(v), attn_mask=mask).transpose(1, 2).reshape(B, S, C)
+    o = ops.attention_fwd_masked(q.cuda(), k.cuda(), v.cuda(), H, causal=causal,
+                                 kv_len=lens.to(torch.int32).cuda() if padded else None)
+    # with causal + padding a query row can lie beyond the valid keys only through padding; every row keeps key 0
+    close_bf16(f"attn text B{B} H{H} S{S} causal={causal} padded={padded}", o, ref, ulps=2.0)   # as the other attention outputs
