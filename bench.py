@@ -49,7 +49,7 @@ def pmc_traffic():
     same command (profiles/r01_pmc_traffic.json; gfx950 FETCH_SIZE x2 correction applied); None if absent."""
     try:
         d = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
-        return {"MB_per_launch": d["gemm_family"]["traffic_MB_per_launch"], "source": "profiles/r01_pmc_traffic.json"}
+        return round(d["gemm_family"]["traffic_MB_per_launch"] * 1e6)      # bytes per launch
     except Exception:
         return None
 
@@ -283,6 +283,8 @@ def main():
         roof = {"bound": "mfma", "kernel": "gemm_lc_kernel / gemm_lcp_kernel (plain + implicit-GEMM conv3x3)",
                 "achieved": round(ach, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(ach / MFMA_PEAK_TFLOPS, 4), "traffic": pmc_traffic(),
+                "traffic_unit": "bytes per launch, TCC FETCH_SIZE x2 (gfx950) + WRITE_SIZE over the family's launches, from "
+                                "two separate rocprofv3 --pmc passes of this command (profiles/r01_pmc_traffic.json)",
                 "launches_per_step": g_n // nprof, "avg_launch_us": round(g_ms * 1e3 / max(g_n, 1), 2),
                 "gflop_per_launch": round(g_fl / max(g_n, 1) / 1e9, 3),
                 "ms_per_step_single_stream": round(g_ms / nprof, 2),
