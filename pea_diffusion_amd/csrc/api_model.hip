@@ -19,54 +19,45 @@
 
 static_assert(sizeof(pea_unet_config) == sizeof(PeaUnetCfg), "config struct mismatch");
 
+// shared tail of every pea_*_create: build the graph, plan and allocate the weights
+static int finish_create(Tape* u, const char* what, void** out) {
+  return finish_create(u, __func__, out);
+}
+static int require_device(const char* what) {
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
+    pea_set_error("%s: no HIP device (there is no CPU fallback)", what);
+    return PEA_E_HIP;
+  }
+  return PEA_OK;
+}
+
 extern "C" {
 
 int pea_unet_create(const pea_unet_config* cfg, int B, int H, int W, int L, int flags, int own_weights,
                     void** out) {
   NOTNULL(cfg, "pea_unet_create");
   NOTNULL(out, "pea_unet_create");
-  int ndev = 0;
-  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
-    pea_set_error("pea_unet_create: no HIP device (there is no CPU fallback)");
-    return PEA_E_HIP;
-  }
-  Unet* u = new Unet();
+  RCX(require_device("pea_unet_create"));
+  Tape* u = new Tape();
   memcpy(&u->cfg, cfg, sizeof(PeaUnetCfg));
   u->B = B; u->H = H; u->W = W; u->L = L; u->needs_grad = (flags & 1) != 0; u->residual_inputs = (flags & 2) != 0;
   u->owns_weights = own_weights != 0;
-  int rc = u->build();
-  if (rc == PEA_OK) rc = u->alloc();
-  if (rc != PEA_OK) {
-    delete u;
-    return rc;
-  }
-  *out = u;
-  return PEA_OK;
+  return finish_create(u, __func__, out);
 }
 int pea_controlnet_create(const pea_unet_config* cfg, int B, int H, int W, int L, void** out) {
   NOTNULL(cfg, "pea_controlnet_create");
   NOTNULL(out, "pea_controlnet_create");
-  int ndev = 0;
-  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
-    pea_set_error("pea_controlnet_create: no HIP device (there is no CPU fallback)");
-    return PEA_E_HIP;
-  }
-  Unet* u = new Unet();
+  RCX(require_device("pea_controlnet_create"));
+  Tape* u = new Tape();
   memcpy(&u->cfg, cfg, sizeof(PeaUnetCfg));
   u->graph = 2;
   u->B = B; u->H = H; u->W = W; u->L = L; u->needs_grad = false; u->owns_weights = true;
-  int rc = u->build();
-  if (rc == PEA_OK) rc = u->alloc();
-  if (rc != PEA_OK) {
-    delete u;
-    return rc;
-  }
-  *out = u;
-  return PEA_OK;
+  return finish_create(u, __func__, out);
 }
 #define CN_HANDLE(h, what)                                                        \
   NOTNULL(h, what);                                                               \
-  Unet* u = (Unet*)h;                                                             \
+  Tape* u = (Tape*)h;                                                             \
   if (u->graph != 2) { pea_set_error("%s: not a ControlNet handle", what); return PEA_E_INVALID; }
 int pea_controlnet_set_cond(void* h, const float* image, void* stream) {
   CN_HANDLE(h, "pea_controlnet_set_cond");
@@ -90,7 +81,7 @@ int pea_controlnet_forward(void* h, const float* x, const float* t, const void* 
   if (!u->ce_valid) { pea_set_error("pea_controlnet_forward: call pea_controlnet_set_cond first"); return PEA_E_STATE; }
   return u->forward(x, t, ehs, ehs_dtype, text, text_dtype, time_ids, nullptr, (hipStream_t)stream);
 }
-int pea_controlnet_num_outputs(void* h) { return h ? (int)((Unet*)h)->cn_out.size() : 0; }
+int pea_controlnet_num_outputs(void* h) { return h ? (int)((Tape*)h)->cn_out.size() : 0; }
 int pea_controlnet_output(void* h, int i, void** ptr, int* C, int* H, int* W) {
   CN_HANDLE(h, "pea_controlnet_output");
   if (i < 0 || i >= (int)u->cn_out.size()) {
@@ -118,27 +109,16 @@ int pea_controlnet_export_nchw(void* h, int i, float* dst, void* stream) {
 int pea_vae_encoder_create(const pea_unet_config* cfg, int B, int H, int W, void** out) {
   NOTNULL(cfg, "pea_vae_encoder_create");
   NOTNULL(out, "pea_vae_encoder_create");
-  int ndev = 0;
-  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
-    pea_set_error("pea_vae_encoder_create: no HIP device (there is no CPU fallback)");
-    return PEA_E_HIP;
-  }
-  Unet* u = new Unet();
+  RCX(require_device("pea_vae_encoder_create"));
+  Tape* u = new Tape();
   memcpy(&u->cfg, cfg, sizeof(PeaUnetCfg));
   u->graph = 1;
   u->B = B; u->H = H; u->W = W; u->L = 0; u->needs_grad = false; u->owns_weights = true;
-  int rc = u->build();
-  if (rc == PEA_OK) rc = u->alloc();
-  if (rc != PEA_OK) {
-    delete u;
-    return rc;
-  }
-  *out = u;
-  return PEA_OK;
+  return finish_create(u, __func__, out);
 }
 int pea_vae_latent_shape(void* h, int* C, int* H, int* W) {
   NOTNULL(h, "pea_vae_latent_shape");
-  Unet* u = (Unet*)h;
+  Tape* u = (Tape*)h;
   if (u->graph != 1) { pea_set_error("pea_vae_latent_shape: not a VAE encoder handle"); return PEA_E_INVALID; }
   const Tn& t = u->tn[u->t_out_in];
   if (C) *C = u->cfg.out_channels / 2;
@@ -150,7 +130,7 @@ int pea_vae_encode(void* h, const float* pixels, const float* noise, float scali
                    void* stream) {
   NOTNULL(h, "pea_vae_encode");
   NOTNULL(pixels, "pea_vae_encode");
-  Unet* u = (Unet*)h;
+  Tape* u = (Tape*)h;
   if (u->graph != 1) { pea_set_error("pea_vae_encode: not a VAE encoder handle"); return PEA_E_INVALID; }
   hipStream_t s = (hipStream_t)stream;
   { int rc0 = u->ensure_acts(); if (rc0 != PEA_OK) return rc0; }
@@ -163,29 +143,18 @@ int pea_vae_encode(void* h, const float* pixels, const float* noise, float scali
 int pea_vae_decoder_create(const pea_unet_config* cfg, int B, int H, int W, void** out) {
   NOTNULL(cfg, "pea_vae_decoder_create");
   NOTNULL(out, "pea_vae_decoder_create");
-  int ndev = 0;
-  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
-    pea_set_error("pea_vae_decoder_create: no HIP device (there is no CPU fallback)");
-    return PEA_E_HIP;
-  }
-  Unet* u = new Unet();
+  RCX(require_device("pea_vae_decoder_create"));
+  Tape* u = new Tape();
   memcpy(&u->cfg, cfg, sizeof(PeaUnetCfg));
   u->graph = 3;
   u->B = B; u->H = H; u->W = W; u->L = 0; u->needs_grad = false; u->owns_weights = true;
-  int rc = u->build();
-  if (rc == PEA_OK) rc = u->alloc();
-  if (rc != PEA_OK) {
-    delete u;
-    return rc;
-  }
-  *out = u;
-  return PEA_OK;
+  return finish_create(u, __func__, out);
 }
 int pea_vae_decode(void* h, const float* latents, float inv_scaling, float* image, void* stream) {
   NOTNULL(h, "pea_vae_decode");
   NOTNULL(latents, "pea_vae_decode");
   NOTNULL(image, "pea_vae_decode");
-  Unet* u = (Unet*)h;
+  Tape* u = (Tape*)h;
   if (u->graph != 3) { pea_set_error("pea_vae_decode: not a VAE decoder handle"); return PEA_E_INVALID; }
   hipStream_t s = (hipStream_t)stream;
   std::string miss;
@@ -203,29 +172,18 @@ static_assert(sizeof(pea_text_config) == sizeof(PeaTextCfg), "text config struct
 int pea_text_create(const pea_text_config* cfg, int B, int L, void** out) {
   NOTNULL(cfg, "pea_text_create");
   NOTNULL(out, "pea_text_create");
-  int ndev = 0;
-  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
-    pea_set_error("pea_text_create: no HIP device (there is no CPU fallback)");
-    return PEA_E_HIP;
-  }
-  Unet* u = new Unet();
+  RCX(require_device("pea_text_create"));
+  Tape* u = new Tape();
   memset(&u->cfg, 0, sizeof(PeaUnetCfg));
   memcpy(&u->tcfg, cfg, sizeof(PeaTextCfg));
   u->graph = 4;
   u->B = B; u->H = 1; u->W = L; u->L = L; u->needs_grad = false; u->owns_weights = true;
-  int rc = u->build();
-  if (rc == PEA_OK) rc = u->alloc();
-  if (rc != PEA_OK) {
-    delete u;
-    return rc;
-  }
-  *out = u;
-  return PEA_OK;
+  return finish_create(u, __func__, out);
 }
 int pea_text_forward(void* h, const long long* ids, int hidden_index, float* hidden_out, float* pooled_out, void* stream) {
   NOTNULL(h, "pea_text_forward");
   NOTNULL(ids, "pea_text_forward");
-  Unet* u = (Unet*)h;
+  Tape* u = (Tape*)h;
   if (u->graph != 4) { pea_set_error("pea_text_forward: not a text-encoder handle"); return PEA_E_INVALID; }
   hipStream_t s = (hipStream_t)stream;
   std::string miss;
@@ -261,13 +219,13 @@ int pea_text_forward(void* h, const long long* ids, int hidden_index, float* hid
   return PEA_OK;
 }
 int pea_unet_destroy(void* h) {
-  delete (Unet*)h;
+  delete (Tape*)h;
   return PEA_OK;
 }
-int pea_unet_num_residuals(void* h) { return h ? (int)((Unet*)h)->ext_res.size() : 0; }
+int pea_unet_num_residuals(void* h) { return h ? (int)((Tape*)h)->ext_res.size() : 0; }
 int pea_unet_residual_info(void* h, int i, int* C, int* H, int* W) {
   NOTNULL(h, "pea_unet_residual_info");
-  Unet* u = (Unet*)h;
+  Tape* u = (Tape*)h;
   if (i < 0 || i >= (int)u->ext_res.size()) {
     pea_set_error("pea_unet_residual_info: index %d out of range (%d residual inputs)", i, (int)u->ext_res.size());
     return PEA_E_INVALID;
@@ -280,7 +238,7 @@ int pea_unet_residual_info(void* h, int i, int* C, int* H, int* W) {
 }
 int pea_unet_set_residuals(void* h, int n, const void* const* ptrs, int dtype, float scale, void* stream) {
   NOTNULL(h, "pea_unet_set_residuals");
-  Unet* u = (Unet*)h;
+  Tape* u = (Tape*)h;
   if (!u->residual_inputs) {
     pea_set_error("pea_unet_set_residuals: context created without PEA_UNET_RESIDUAL_INPUTS");
     return PEA_E_STATE;
@@ -302,10 +260,10 @@ int pea_unet_set_residuals(void* h, int n, const void* const* ptrs, int dtype, f
   }
   return PEA_OK;
 }
-int pea_unet_num_weights(void* h) { return h ? (int)((Unet*)h)->slots.size() : 0; }
+int pea_unet_num_weights(void* h) { return h ? (int)((Tape*)h)->slots.size() : 0; }
 int pea_unet_weight_info(void* h, int i, char* name, int name_len, long long* numel, int* kind, int* d0, int* d1) {
   NOTNULL(h, "pea_unet_weight_info");
-  Unet* u = (Unet*)h;
+  Tape* u = (Tape*)h;
   if (i < 0 || i >= (int)u->slots.size()) {
     pea_set_error("pea_unet_weight_info: index %d out of range", i);
     return PEA_E_INVALID;
@@ -323,7 +281,7 @@ int pea_unet_weight_info(void* h, int i, char* name, int name_len, long long* nu
 }
 int pea_unet_load_weight(void* h, const char* name, const float* src, long long numel, void* stream) {
   NOTNULL(h, "pea_unet_load_weight");
-  Unet* u = (Unet*)h;
+  Tape* u = (Tape*)h;
   if (!u->owns_weights) {
     pea_set_error("pea_unet_load_weight: context borrows its weights");
     return PEA_E_STATE;
@@ -332,22 +290,22 @@ int pea_unet_load_weight(void* h, const char* name, const float* src, long long 
 }
 int pea_unet_init_random(void* h, unsigned long long seed, void* stream) {
   NOTNULL(h, "pea_unet_init_random");
-  return ((Unet*)h)->init_random(seed, (hipStream_t)stream);
+  return ((Tape*)h)->init_random(seed, (hipStream_t)stream);
 }
 int pea_unet_share_weights(void* dst, void* src) {
   NOTNULL(dst, "pea_unet_share_weights");
   NOTNULL(src, "pea_unet_share_weights");
-  return ((Unet*)dst)->share_weights_from(*(Unet*)src);
+  return ((Tape*)dst)->share_weights_from(*(Tape*)src);
 }
 int pea_unet_forward(void* h, const float* x, const float* t, const void* ehs, int ehs_dtype, const void* text,
                      int text_dtype, const float* time_ids, float* eps_out, void* stream) {
   NOTNULL(h, "pea_unet_forward");
-  return ((Unet*)h)->forward(x, t, ehs, ehs_dtype, text, text_dtype, time_ids, eps_out, (hipStream_t)stream);
+  return ((Tape*)h)->forward(x, t, ehs, ehs_dtype, text, text_dtype, time_ids, eps_out, (hipStream_t)stream);
 }
-int pea_unet_num_taps(void* h) { return h ? (int)((Unet*)h)->taps.size() : 0; }
+int pea_unet_num_taps(void* h) { return h ? (int)((Tape*)h)->taps.size() : 0; }
 int pea_unet_tap_info(void* h, int k, void** data, void** grad, int* B, int* H, int* W, int* C) {
   NOTNULL(h, "pea_unet_tap_info");
-  Unet* u = (Unet*)h;
+  Tape* u = (Tape*)h;
   if (k < 0 || k >= (int)u->taps.size()) {
     pea_set_error("pea_unet_tap_info: tap %d out of range", k);
     return PEA_E_INVALID;
@@ -364,7 +322,7 @@ int pea_unet_tap_info(void* h, int k, void** data, void** grad, int* B, int* H, 
 }
 int pea_unet_tap_export_nchw(void* h, int k, int grad, float* out, void* stream) {
   NOTNULL(h, "pea_unet_tap_export_nchw");
-  Unet* u = (Unet*)h;
+  Tape* u = (Tape*)h;
   if (k < 0 || k >= (int)u->taps.size()) {
     pea_set_error("pea_unet_tap_export_nchw: tap %d out of range", k);
     return PEA_E_INVALID;
@@ -377,7 +335,7 @@ int pea_unet_tap_export_nchw(void* h, int k, int grad, float* out, void* stream)
 }
 int pea_unet_backward(void* h, const float* deps, unsigned tap_seed_mask, void* stream) {
   NOTNULL(h, "pea_unet_backward");
-  Unet* u = (Unet*)h;
+  Tape* u = (Tape*)h;
   u->begin_backward();
   for (size_t k = 0; k < u->taps.size(); ++k)
     if (tap_seed_mask & (1u << k)) u->tn[u->taps[k]].gw = true;
@@ -385,14 +343,14 @@ int pea_unet_backward(void* h, const float* deps, unsigned tap_seed_mask, void* 
 }
 int pea_unet_input_grads(void* h, void** d_ehs, void** d_text) {
   NOTNULL(h, "pea_unet_input_grads");
-  Unet* u = (Unet*)h;
+  Tape* u = (Tape*)h;
   if (d_ehs) *d_ehs = u->tn[u->t_ehs].gw ? u->tn[u->t_ehs].g : nullptr;
   if (d_text) *d_text = (u->t_text >= 0 && u->tn[u->t_text].gw) ? u->tn[u->t_text].g : nullptr;
   return PEA_OK;
 }
 int pea_unet_memory(void* h, long long* weight_bytes, long long* act_bytes, long long* grad_bytes, int* n_ops) {
   NOTNULL(h, "pea_unet_memory");
-  Unet* u = (Unet*)h;
+  Tape* u = (Tape*)h;
   if (weight_bytes) *weight_bytes = (long long)u->wbytes;
   /* activations / gradients are allocated on first use: report what is resident */
   if (act_bytes) *act_bytes = u->aarena ? (long long)u->abytes : 0;
@@ -423,11 +381,7 @@ int pea_adapter_bind(void* h, float* flat_params) {
 }
 int pea_adapter_prepare(void* h, int batch, int L) {
   NOTNULL(h, "pea_adapter_prepare");
-  int ndev = 0;
-  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
-    pea_set_error("pea_adapter_prepare: no HIP device (there is no CPU fallback)");
-    return PEA_E_HIP;
-  }
+  RCX(require_device("pea_adapter_prepare"));
   return ((Adapter*)h)->prepare(batch, L);
 }
 int pea_adapter_sync(void* h, void* stream) {
@@ -471,7 +425,7 @@ int pea_trainer_create(void* adapter, void* student, void* teacher, float feat_w
   NOTNULL(student, "pea_trainer_create");
   NOTNULL(teacher, "pea_trainer_create");
   Trainer* t = new Trainer();
-  t->ad = (Adapter*)adapter; t->student = (Unet*)student; t->teacher = (Unet*)teacher;
+  t->ad = (Adapter*)adapter; t->student = (Tape*)student; t->teacher = (Tape*)teacher;
   t->feat_weight = feat_weight; t->nan_guard = nan_guard;
   int rc = t->prepare();
   if (rc == PEA_OK && alphas_cumprod)

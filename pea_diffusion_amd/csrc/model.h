@@ -73,7 +73,7 @@ struct Tn {
   bool rg = false;           // requires grad
   bool zero_init = false;    // channel-padded tensor: the padding columns are never written and must read as zeros
   bool gw = false;           // gradient already written in the current backward pass
-  const bf16* gpend = nullptr;   // gradient passed on by a residual, not yet added into g (Unet::backward)
+  const bf16* gpend = nullptr;   // gradient passed on by a residual, not yet added into g (Tape::backward)
   size_t off_d = 0, off_g = 0;
   bool external = false;     // no buffer of its own
 };
@@ -97,7 +97,9 @@ struct Op {
   int mask = 0;                   // OP_ATTN: 1 causal, 2 per-sample key count (text encoders)
 };
 
-struct Unet {
+// The static op tape: tensors, weight slots and ops of ONE graph, built once per (config, batch, size).  graph selects the
+// builder: the UNet of the KD step (0), AutoencoderKL encoder / decoder (1 / 3), ControlNet (2), a text encoder (4).
+struct Tape {
   PeaUnetCfg cfg;
   int B, H, W, L;                 // batch, latent H/W, context length
   bool needs_grad;
@@ -150,13 +152,13 @@ struct Unet {
   int alloc();
   int load_weight(const char* name, const float* dev_ptr, long long numel, hipStream_t s);
   int init_random(unsigned long long seed, hipStream_t s);
-  int share_weights_from(const Unet& src);
+  int share_weights_from(const Tape& src);
   int forward(const float* x, const float* t, const void* ehs, int ehs_dtype, const void* text, int text_dtype,
               const float* time_ids, float* eps, hipStream_t s);
   int backward(const float* deps, hipStream_t s);   // tap grads must have been seeded (or zero-flagged) first
   void begin_backward();
   int all_loaded(std::string* missing) const;
-  ~Unet();
+  ~Tape();
 };
 
 struct Adapter {
@@ -181,7 +183,7 @@ struct Adapter {
 };
 
 struct Trainer {
-  Adapter* ad; Unet* student; Unet* teacher;
+  Adapter* ad; Tape* student; Tape* teacher;
   float feat_weight = 0.1f; int nan_guard = 0;
   float* xt = nullptr; float* eps_s = nullptr; float* eps_t = nullptr; float* deps = nullptr; float* ac = nullptr;
   bf16* t_ehs_sel = nullptr; bf16* dehs_full = nullptr;
@@ -197,7 +199,7 @@ struct Trainer {
   // merged passes: when the teacher IS the student checkpoint (shared weights, reference default) both forwards run
   // as ONE pass over 2B samples (student rows first) and the backward differentiates the first B only
   int merge_passes = 1; int merge_state = 0;   // state: 0 undecided, 1 merged, -1 not eligible
-  Unet* merged = nullptr;
+  Tape* merged = nullptr;
   float *xt2 = nullptr, *eps2 = nullptr, *t2 = nullptr, *tid2 = nullptr;
   int step_merged(const float* latents, const float* noise, const long long* timesteps, const float* enc,
                   const float* enc_uncond, const unsigned char* prompt_mask, const long long* zh, const float* teacher_ehs,

@@ -21,8 +21,8 @@ int pea_zero_page(const bf16** out);
 // ============================================================================ graph construction
 namespace {
 struct Builder {
-  Unet& u;
-  explicit Builder(Unet& un) : u(un) {}
+  Tape& u;
+  explicit Builder(Tape& un) : u(un) {}
   int T(long long rows, int cols, int B = 0, int H = 0, int W = 0) {
     Tn t;
     t.rows = rows; t.cols = cols; t.B = B; t.H = H; t.W = W;
@@ -279,7 +279,7 @@ std::vector<std::pair<std::string, int>> enumerate_resnets(const PeaUnetCfg& c, 
 }
 }  // namespace
 
-int Unet::build_vae_encoder() {
+int Tape::build_vae_encoder() {
   const PeaUnetCfg& c = cfg;
   SHAPECHK(c.n_levels >= 2 && c.n_levels <= 4, "vae: n_levels=%d", c.n_levels);
   SHAPECHK(!needs_grad && !residual_inputs, "vae encoder: inference graph only");
@@ -325,7 +325,7 @@ int Unet::build_vae_encoder() {
 // attention, resnet) -> UpDecoderBlock2D x n (layers_per_block + 1 resnets, nearest-2x + conv folded into one implicit
 // GEMM) -> GroupNorm + SiLU -> conv_out.  cfg: in_channels = latent channels (4), out_channels = image channels (3),
 // block_out = the ENCODER's block_out_channels (the decoder walks them reversed), H x W = LATENT size.
-int Unet::build_vae_decoder() {
+int Tape::build_vae_decoder() {
   const PeaUnetCfg& c = cfg;
   SHAPECHK(c.n_levels >= 2 && c.n_levels <= 4, "vae: n_levels=%d", c.n_levels);
   SHAPECHK(!needs_grad && !residual_inputs, "vae decoder: inference graph only");
@@ -369,7 +369,7 @@ int Unet::build_vae_decoder() {
 // position embeddings, pre-LN blocks with causal attention, final LayerNorm, pooled = final[EOS] @ text_projection.
 // flavor 1: BERT (the Chinese-CLIP text tower, train_sdxl_zh.py:103-107,327-329; keys `embeddings.*`,
 // `encoder.layer.N.*`): word + position + token-type embeddings -> LN, post-LN blocks, key-padding mask.
-int Unet::build_text() {
+int Tape::build_text() {
   const PeaTextCfg& c = tcfg;
   SHAPECHK(!needs_grad, "text encoder: inference graph only");
   SHAPECHK(c.width % 64 == 0 && c.heads > 0 && c.width / c.heads == 64 && c.width % c.heads == 0,
@@ -427,7 +427,7 @@ int Unet::build_text() {
   return PEA_OK;
 }
 
-int Unet::build() {
+int Tape::build() {
   if (graph == 4) return build_text();
   if (graph == 1) return build_vae_encoder();
   if (graph == 3) return build_vae_decoder();
@@ -606,7 +606,7 @@ int Unet::build() {
   return PEA_OK;
 }
 
-int Unet::alloc() {
+int Tape::alloc() {
   // ---- weights
   size_t off = 0;
   size_t max_numel = 0;
@@ -672,7 +672,7 @@ int Unet::alloc() {
 // Activation / gradient arenas and scratch are allocated on first use, not at creation: a trainer that runs merged
 // passes never touches the activations of the student and teacher contexts it was given (they only carry the weights),
 // which is half of the resident HBM at the benchmark size.
-int Unet::ensure_acts() {
+int Tape::ensure_acts() {
   if (aarena) return PEA_OK;
   HIPCHK(hipMalloc((void**)&aarena, abytes));
   if (gbytes) HIPCHK(hipMalloc((void**)&garena, gbytes));
@@ -730,7 +730,7 @@ int Unet::ensure_acts() {
   return PEA_OK;
 }
 
-Unet::~Unet() {
+Tape::~Tape() {
   if (owns_weights && warena) hipFree(warena);
   if (tmp_f32) hipFree(tmp_f32);
   if (aarena) hipFree(aarena);
@@ -749,7 +749,7 @@ Unet::~Unet() {
   if (kvlen) hipFree(kvlen);
 }
 
-int Unet::load_weight(const char* name, const float* src, long long numel, hipStream_t s) {
+int Tape::load_weight(const char* name, const float* src, long long numel, hipStream_t s) {
   auto it = slot_by_name.find(name);
   if (it == slot_by_name.end()) {
     pea_set_error("unet: unknown weight '%s'", name);
@@ -790,7 +790,7 @@ static bool ends_with(const std::string& s, const char* suf) {
   return s.size() >= n && s.compare(s.size() - n, n, suf) == 0;
 }
 
-int Unet::init_random(unsigned long long seed, hipStream_t s) {
+int Tape::init_random(unsigned long long seed, hipStream_t s) {
   SHAPECHK(owns_weights, "unet: init_random on a context that shares weights");
   unsigned long long i = 0;
   for (WSlot& w : slots) {
@@ -805,7 +805,7 @@ int Unet::init_random(unsigned long long seed, hipStream_t s) {
   return PEA_OK;
 }
 
-int Unet::share_weights_from(const Unet& src) {
+int Tape::share_weights_from(const Tape& src) {
   SHAPECHK(!owns_weights, "unet: share_weights_from needs a context created without its own weights");
   SHAPECHK(src.slots.size() == slots.size() && src.fused.size() == fused.size(), "unet: configs differ");
   for (size_t i = 0; i < slots.size(); ++i) {
@@ -821,7 +821,7 @@ int Unet::share_weights_from(const Unet& src) {
   return PEA_OK;
 }
 
-int Unet::all_loaded(std::string* missing) const {
+int Tape::all_loaded(std::string* missing) const {
   for (const WSlot& w : slots)
     if (!w.loaded) {
       if (missing) *missing = w.name;
@@ -833,7 +833,7 @@ int Unet::all_loaded(std::string* missing) const {
 // ============================================================================ forward
 static void fill_gemm(GemmP& p) { memset(&p, 0, sizeof(p)); p.alpha = 1.f; p.rows_per_batch = 1; }
 
-int Unet::forward(const float* x, const float* t, const void* ehs, int ehs_dtype, const void* text, int text_dtype,
+int Tape::forward(const float* x, const float* t, const void* ehs, int ehs_dtype, const void* text, int text_dtype,
                   const float* time_ids, float* eps, hipStream_t s) {
   std::string miss;
   if (!all_loaded(&miss)) {
@@ -865,7 +865,7 @@ int Unet::forward(const float* x, const float* t, const void* ehs, int ehs_dtype
 }
 
 // ops [begin, end) of the tape in order; skip_cached: leave out the ControlNet conditioning embedding when it is valid
-int Unet::exec_ops(size_t begin, size_t end, bool skip_cached, hipStream_t s) {
+int Tape::exec_ops(size_t begin, size_t end, bool skip_cached, hipStream_t s) {
   RC(ensure_acts());
   for (size_t oi = begin; oi < end; ++oi) {
     Op& o = ops[oi];
@@ -992,11 +992,11 @@ int Unet::exec_ops(size_t begin, size_t end, bool skip_cached, hipStream_t s) {
 }
 
 // ============================================================================ backward
-void Unet::begin_backward() {
+void Tape::begin_backward() {
   for (Tn& t : tn) { t.gw = false; t.gpend = nullptr; }
 }
 
-int Unet::backward(const float* deps, hipStream_t s) {
+int Tape::backward(const float* deps, hipStream_t s) {
   SHAPECHK(needs_grad, "unet: created without gradient support");
   RC(ensure_acts());
   // bwd_batch < B: the forward ran on B samples (student rows first, teacher rows behind them: merged passes of a
@@ -1317,8 +1317,8 @@ Trainer::~Trainer() {
 int Trainer::prepare() {
   if (const char* e = getenv("PEA_TWO_STREAM")) two_stream = atoi(e);
   if (const char* e = getenv("PEA_MERGE_PASSES")) merge_passes = atoi(e);
-  Unet& S = *student;
-  Unet& Tt = *teacher;
+  Tape& S = *student;
+  Tape& Tt = *teacher;
   SHAPECHK(S.needs_grad, "trainer: student context needs gradient support");
   SHAPECHK(S.B == Tt.B && S.H == Tt.H && S.W == Tt.W, "trainer: student/teacher shapes differ");
   SHAPECHK(S.taps.size() == Tt.taps.size(), "trainer: tap counts differ");
@@ -1367,8 +1367,8 @@ int Trainer::step(const float* latents, const float* noise, const long long* tim
                   const float* teacher_ehs, const float* teacher_neg, const float* teacher_pooled,
                   const float* time_ids, float grad_scale, float* grads, int accumulate, float* losses_out,
                   hipStream_t s) {
-  Unet& S = *student;
-  Unet& Tt = *teacher;
+  Tape& S = *student;
+  Tape& Tt = *teacher;
   Adapter& A = *ad;
   const int B = S.B;
   SHAPECHK(A.B2 == 2 * B && A.L == S.L, "trainer: adapter is prepared for %d x %d rows, the step needs %d x %d", A.B2, A.L,
@@ -1385,7 +1385,7 @@ int Trainer::step(const float* latents, const float* noise, const long long* tim
       ok = S.slots[i].w == Tt.slots[i].w && S.slots[i].f32 == Tt.slots[i].f32;
     merge_state = ok ? 1 : -1;
     if (ok) {
-      merged = new Unet();
+      merged = new Tape();
       merged->cfg = S.cfg;
       merged->B = 2 * B; merged->H = S.H; merged->W = S.W; merged->L = S.L;
       merged->needs_grad = true; merged->owns_weights = false; merged->bwd_batch = B;
@@ -1472,14 +1472,14 @@ int Trainer::step(const float* latents, const float* noise, const long long* tim
 // rows [B, 2B): teacher conditioning, same noisy latents and timesteps), possible when the teacher context shares the
 // student's weights.  Every GEMM / conv / attention launch then works on twice the rows -- at B = 4 that is the
 // difference between one and two 128-row tiles per CU in most launches -- and the backward pass walks the tape on
-// the leading B samples only (Unet::bwd_batch).  The teacher half runs without `no_grad` bookkeeping differences:
+// the leading B samples only (Tape::bwd_batch).  The teacher half runs without `no_grad` bookkeeping differences:
 // nothing in the forward depends on whether a gradient will be taken.
 int Trainer::step_merged(const float* latents, const float* noise, const long long* timesteps, const float* enc,
                          const float* enc_uncond, const unsigned char* prompt_mask, const long long* zh,
                          const float* teacher_ehs, const float* teacher_neg, const float* teacher_pooled,
                          const float* time_ids, float grad_scale, float* grads, int accumulate, float* losses_out,
                          hipStream_t s) {
-  Unet& M = *merged;
+  Tape& M = *merged;
   RC(M.ensure_acts());
   Adapter& A = *ad;
   const int B = student->B;
