@@ -20,8 +20,15 @@
 static_assert(sizeof(pea_unet_config) == sizeof(PeaUnetCfg), "config struct mismatch");
 
 // shared tail of every pea_*_create: build the graph, plan and allocate the weights
-static int finish_create(Tape* u, const char* what, void** out) {
-  return finish_create(u, __func__, out);
+static int finish_create(Tape* u, void** out) {
+  int rc = u->build();
+  if (rc == PEA_OK) rc = u->alloc();
+  if (rc != PEA_OK) {
+    delete u;
+    return rc;
+  }
+  *out = u;
+  return PEA_OK;
 }
 static int require_device(const char* what) {
   int ndev = 0;
@@ -43,7 +50,7 @@ int pea_unet_create(const pea_unet_config* cfg, int B, int H, int W, int L, int 
   memcpy(&u->cfg, cfg, sizeof(PeaUnetCfg));
   u->B = B; u->H = H; u->W = W; u->L = L; u->needs_grad = (flags & 1) != 0; u->residual_inputs = (flags & 2) != 0;
   u->owns_weights = own_weights != 0;
-  return finish_create(u, __func__, out);
+  return finish_create(u, out);
 }
 int pea_controlnet_create(const pea_unet_config* cfg, int B, int H, int W, int L, void** out) {
   NOTNULL(cfg, "pea_controlnet_create");
@@ -53,7 +60,7 @@ int pea_controlnet_create(const pea_unet_config* cfg, int B, int H, int W, int L
   memcpy(&u->cfg, cfg, sizeof(PeaUnetCfg));
   u->graph = 2;
   u->B = B; u->H = H; u->W = W; u->L = L; u->needs_grad = false; u->owns_weights = true;
-  return finish_create(u, __func__, out);
+  return finish_create(u, out);
 }
 #define CN_HANDLE(h, what)                                                        \
   NOTNULL(h, what);                                                               \
@@ -114,7 +121,7 @@ int pea_vae_encoder_create(const pea_unet_config* cfg, int B, int H, int W, void
   memcpy(&u->cfg, cfg, sizeof(PeaUnetCfg));
   u->graph = 1;
   u->B = B; u->H = H; u->W = W; u->L = 0; u->needs_grad = false; u->owns_weights = true;
-  return finish_create(u, __func__, out);
+  return finish_create(u, out);
 }
 int pea_vae_latent_shape(void* h, int* C, int* H, int* W) {
   NOTNULL(h, "pea_vae_latent_shape");
@@ -148,7 +155,7 @@ int pea_vae_decoder_create(const pea_unet_config* cfg, int B, int H, int W, void
   memcpy(&u->cfg, cfg, sizeof(PeaUnetCfg));
   u->graph = 3;
   u->B = B; u->H = H; u->W = W; u->L = 0; u->needs_grad = false; u->owns_weights = true;
-  return finish_create(u, __func__, out);
+  return finish_create(u, out);
 }
 int pea_vae_decode(void* h, const float* latents, float inv_scaling, float* image, void* stream) {
   NOTNULL(h, "pea_vae_decode");
@@ -178,7 +185,7 @@ int pea_text_create(const pea_text_config* cfg, int B, int L, void** out) {
   memcpy(&u->tcfg, cfg, sizeof(PeaTextCfg));
   u->graph = 4;
   u->B = B; u->H = 1; u->W = L; u->L = L; u->needs_grad = false; u->owns_weights = true;
-  return finish_create(u, __func__, out);
+  return finish_create(u, out);
 }
 int pea_text_forward(void* h, const long long* ids, int hidden_index, float* hidden_out, float* pooled_out, void* stream) {
   NOTNULL(h, "pea_text_forward");
