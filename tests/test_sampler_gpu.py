@@ -103,3 +103,63 @@ def test_denoise_loop_tiny_vs_oracle(gpu):
     e = rel_l2(got, want)
     print(f"[denoise loop tiny, 6 steps, cfg 5.0, rescale 0.7] latents rel_l2={e:.3e}")
     assert torch.isfinite(got).all() and e < 3e-2
+
+
+def test_end_to_end_generation_tiny_vs_oracle(gpu):
+    """The reference's generation program end to end on tiny models (tests/test_sdxl_zh.py `StableDiffusionTest.__call__`,
+    :153-290 encode_prompt through the Chinese-CLIP tower and the adapter, :350-406 denoise loop, :430 VAE decode): every
+    stage on the HIP path against the same chain of CPU oracles."""
+    from oracle.sampler_ref import DPMSolverMultistepRef, denoise_ref
+    from oracle.step_ref import AdapterRef
+    from oracle.text_ref import BertTextRef
+    from oracle.unet_ref import tiny_config
+    from oracle.vae_ref import VAEDecoderRef, tiny_vae_config
+    from pea_diffusion_amd import config as pc
+    from pea_diffusion_amd.adapter import PEAAdapter
+    from pea_diffusion_amd.sampler import DPMSolverMultistep, denoise
+    from pea_diffusion_amd.text import HipTextEncoder
+    from pea_diffusion_amd.vae import HipVAEDecoder
+    from test_model_gpu import round_weights_bf16_
+    B, L = 2, 52
+    torch.manual_seed(0)
+    # --- text tower (BERT flavour, width 128) -> adapter (128 -> pooled / 128-wide tokens = the tiny UNet's cross dim)
+    tcfg = pc.tiny_bert_config()
+    t_ref = BertTextRef(tcfg)
+    with torch.no_grad():
+        for p in t_ref.parameters():
+            if p.dim() >= 2:
+                p.mul_(3.0)
+    round_weights_bf16_(t_ref)
+    t_hip = HipTextEncoder(tcfg, 2 * B, L)
+    t_hip.load_state_dict(t_ref.state_dict())
+    cfg, u_ref, u_hip = make_pair(tiny_config, 2 * B, L, needs_grad=False)
+    a_ref = AdapterRef(128, cfg.pooled_dim, 192, cfg.cross_attention_dim, False)
+    a_hip = PEAAdapter(128, cfg.pooled_dim, 192, cfg.cross_attention_dim, False)
+    a_hip.load_state_dict(a_ref.state_dict())
+    a_hip = a_hip.cuda()
+    round_weights_bf16_(a_ref)
+    vcfg = tiny_vae_config()
+    v_ref = VAEDecoderRef(vcfg)
+    round_weights_bf16_(v_ref)
+    v_hip = HipVAEDecoder(pc.tiny_vae_config(), B, cfg.sample_size, cfg.sample_size)
+    v_hip.load_state_dict(v_ref.state_dict())
+    g = torch.Generator().manual_seed(1)
+    ids = torch.randint(1, 1000, (2 * B, L), generator=g)          # [negative prompts | prompts]
+    ids[:, 30:] = 0
+    lat = torch.randn(B, 4, cfg.sample_size, cfg.sample_size, generator=g)
+    time_ids = torch.tensor([[128, 128, 0, 0, 128, 128]] * (2 * B))
+    with torch.no_grad():
+        tok = t_ref(ids)["last_hidden_state"].to(torch.bfloat16).float()
+        pooled, tokens = a_ref(tok)
+        want_lat = denoise_ref(lambda *a, **k: u_ref(*a, **k), DPMSolverMultistepRef(), lat.clone(),
+                               tokens.to(torch.bfloat16).float(), {"text_embeds": pooled, "time_ids": time_ids},
+                               num_inference_steps=4, guidance_scale=5.0)
+        want_img = v_ref.decode(want_lat / vcfg.scaling_factor)[0]
+    tok_h, _ = t_hip.encode_text(ids.cuda())
+    pooled_h, tokens_h = a_hip(tok_h)
+    got_lat = denoise(u_hip, DPMSolverMultistep(), lat.cuda(), tokens_h, {"text_embeds": pooled_h, "time_ids": time_ids.cuda()},
+                      num_inference_steps=4, guidance_scale=5.0)
+    got_img = v_hip.decode(got_lat, inv_scaling=1.0 / vcfg.scaling_factor)[0]
+    e_tok, e_lat, e_img = rel_l2(tokens_h, tokens), rel_l2(got_lat, want_lat), rel_l2(got_img, want_img)
+    print(f"[end to end tiny] adapter tokens rel_l2={e_tok:.3e} latents rel_l2={e_lat:.3e} image rel_l2={e_img:.3e}")
+    assert e_tok < 2e-2 and e_lat < 3e-2 and e_img < 4e-2 and torch.isfinite(got_img).all()
