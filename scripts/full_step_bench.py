@@ -63,6 +63,35 @@ for _ in range(a.steps):
     vae.encode_latents(pixels); te1.encode(ids_t); te2.encode(ids_t); zh.encode_text(ids_z)
 torch.cuda.synchronize()
 fe = (time.perf_counter() - t1) / a.steps
+# the same with the frozen front end of the NEXT batch on a side HIP stream, overlapped with this batch's step
+side = torch.cuda.Stream()
+def front():
+    latents = vae.encode_latents(pixels)
+    h1, _ = te1.encode(ids_t, hidden_index=-2)
+    h2, pooled = te2.encode(ids_t, hidden_index=-2)
+    enc, _ = zh.encode_text(ids_z)
+    return latents, torch.cat([h1, h2], -1), pooled, enc
+def step_overlapped(cur):
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        nxt = front()
+    latents, pe, pooled, enc = cur
+    noise = torch.randn_like(latents) + 0.5 * torch.randn(B, 4, 1, 1, device=dev)
+    t = torch.randint(0, 1000, (B,), device=dev)
+    batch = {"latents": latents, "noise": noise, "timesteps": t, "enc": enc[:B], "enc_uncond": enc[B:],
+             "prompt_mask": torch.rand(B, device=dev) < 0.1, "zh_or_not": torch.randint(0, 2, (B,), device=dev),
+             "teacher_ehs": pe[:B], "teacher_neg": pe[B:], "teacher_pooled": pooled[:B], "time_ids": time_ids}
+    trainer.training_step(batch)
+    trainer.optimizer_step()
+    torch.cuda.current_stream().wait_stream(side)
+    return nxt
+cur = front()
+for _ in range(2): cur = step_overlapped(cur)
+torch.cuda.synchronize(); t2 = time.perf_counter()
+for _ in range(a.steps): cur = step_overlapped(cur)
+torch.cuda.synchronize()
+ov = (time.perf_counter() - t2) / a.steps
+print(f"front end of the next batch on a side stream: {ov*1e3:.1f} ms/step = {B/ov:.2f} images/s")
 print(f"full reference training_step incl. VAE encode + 3 text encoders, SDXL 1024x1024, batch {B}, ctx {L}: "
       f"{dt*1e3:.1f} ms/step = {B/dt:.2f} images/s (loss {float(out['loss']):.4f}); frozen front end alone {fe*1e3:.1f} ms "
       f"(VAE + CLIP-L + OpenCLIP-bigG on 2B prompts + BERT-large on 2B prompts)")
