@@ -298,7 +298,8 @@ __global__ __launch_bounds__((WM * WN + LW) * 64, MINW) void gemm_lc_kernel(cons
     const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
   }
-  const int GROUP = 8;
+  constexpr int GROUP = BM >= 256 ? 4 : 8;      // m-tiles sharing an n-tile column in the tile order: the tiles an XCD works on at a time
+                                                // touch GROUP A panels and 32 / GROUP W panels; 4 balances 256-row A against 160-row W panels
   const int per_group = GROUP * nbn;
   const int gid = bid / per_group;
   const int first_m = gid * GROUP;
@@ -575,7 +576,8 @@ __global__ __launch_bounds__((WM * WN + LW + SW) * 64) void gemm_lcp_kernel(cons
   const int nt = p.K / BK;
   const int G = my_n * nt;                                      // K-steps of this block, all tiles
   if (G == 0) return;
-  const int GROUP = 8;
+  constexpr int GROUP = BM >= 256 ? 4 : 8;      // m-tiles sharing an n-tile column in the tile order: the tiles an XCD works on at a time
+                                                // touch GROUP A panels and 32 / GROUP W panels; 4 balances 256-row A against 160-row W panels
   const int per_group = GROUP * nbn;
   auto tile_of = [&](int i, int& bm, int& bn) {
     const int bid = start_x + idx + i * nbx;
