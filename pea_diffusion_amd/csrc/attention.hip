@@ -15,6 +15,8 @@
 // row-wise for S / dP and through the transpose read for the two gradient products.
 // K/V (or Q/dO) tiles are 64 x 64 bf16 (128-byte rows) staged by LDS-DMA into a 2-deep ring
 // with the same source-side XOR swizzle as gemm.hip.
+#include <stdlib.h>
+
 #include "pea_kernels.h"
 
 #define TILE_BYTES 8192   // 64 rows x 128 bytes
@@ -76,6 +78,24 @@ __device__ __forceinline__ bf16x8 read_row_frag(const char* tile, int row, int s
   return *(const bf16x8*)(tile + row * 128 + ((((2 * s + h)) ^ ((row >> 1) & 7)) << 4));
 }
 
+// XCD-aware workgroup order.  Workgroups are handed to the 8 XCDs round-robin in dispatch order (x fastest), so the
+// query blocks of one head -- which all stream that head's K and V (or Q and dO) -- would land on 8 different L2s and
+// every XCD would see every head: a working set of all heads per 4-MB L2.  Remapped, XCD x runs a contiguous range of
+// (batch, head, block) triples, i.e. whole heads, and a head's operands are read into one L2 once.  `env
+// PEA_ATTN_NO_XCD=1` restores the dispatch order (A/B).
+__device__ __forceinline__ void attn_block_coords(int remap, int& bx, int& by, int& bz) {
+  const unsigned gx = gridDim.x, gy = gridDim.y, gz = gridDim.z;
+  unsigned lin = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
+  if (remap) {
+    const unsigned total = gx * gy * gz, q = total >> 3, r = total & 7, xcd = lin & 7, j = lin >> 3;
+    lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+  }
+  bx = (int)(lin % gx);
+  const unsigned t = lin / gx;
+  by = (int)(t % gy);
+  bz = (int)(t / gy);
+}
+
 // ============================================================================= forward / dQ
 // MODE 0: forward (writes O, lse).  MODE 1: dQ (reads dO, lse, delta; writes dQ).
 // ND = head_dim / 64 (heads are stored padded to ND*64 columns; the padding columns of Q/K/V are zero).  Every
@@ -89,9 +109,10 @@ __global__ __launch_bounds__(256, (ND == 1 ? (MODE == 0 ? (TXT ? 3 : 4) : 2) : 1
   constexpr int NO = MODE == 0 ? ND : 1;                         // output chunks held by this workgroup
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int head = blockIdx.y, b = blockIdx.z;
-  const int qblk = MODE == 0 ? blockIdx.x : blockIdx.x / ND;
-  const int chunk = MODE == 0 ? 0 : blockIdx.x % ND;             // dQ output chunk
+  int blk_x, head, b;
+  attn_block_coords(p.xcd_remap, blk_x, head, b);
+  const int qblk = MODE == 0 ? blk_x : blk_x / ND;
+  const int chunk = MODE == 0 ? 0 : blk_x % ND;                  // dQ output chunk
   const int q0 = qblk * 128 + wave * 32;
   const int frow = lane & 31, fh = lane >> 5;
   const float c = p.scale * LOG2E;
@@ -317,10 +338,11 @@ __global__ __launch_bounds__(256, (ND == 1 ? 2 : 1)) void attn_dkv_kernel(const 
   constexpr int STG = 2 * ND * TILE_BYTES + 512;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int head = blockIdx.y, b = blockIdx.z;
+  int blk_x, head, b;
+  attn_block_coords(p.xcd_remap, blk_x, head, b);
   const int nsplit = p.nsplit > 1 ? p.nsplit : 1;
-  const int chunk = blockIdx.x % ND;
-  const int bx = blockIdx.x / ND;
+  const int chunk = blk_x % ND;
+  const int bx = blk_x / ND;
   const int kblk = bx / nsplit, split = bx - kblk * nsplit;
   const int k0 = kblk * 128 + wave * 32;
   const int frow = lane & 31, fh = lane >> 5;
@@ -537,6 +559,7 @@ size_t attention_bwd_scratch_bytes(int B, int H, int Sq, int Skv, int nd) {
 }
 
 static int g_attn_use_tr = 1;
+static int g_attn_xcd = getenv("PEA_ATTN_NO_XCD") ? 0 : 1;
 extern "C" void pea_debug_set_attn_tr(int v) { g_attn_use_tr = v; }
 
 static int attn_check(const AttnP& p) {
@@ -609,6 +632,7 @@ static int attn_bwd_nd(const AttnP& p, hipStream_t s) {
 
 int launch_attention_fwd(const AttnP& p0, hipStream_t s) {
   AttnP p = p0;
+  p.xcd_remap = g_attn_xcd;
   if (p.nd == 0) p.nd = 1;
   int rc = attn_check(p);
   if (rc) return rc;
@@ -624,6 +648,7 @@ int launch_attention_fwd(const AttnP& p0, hipStream_t s) {
 
 int launch_attention_bwd(const AttnP& p0, hipStream_t s) {
   AttnP p = p0;
+  p.xcd_remap = g_attn_xcd;
   if (p.nd == 0) p.nd = 1;
   p.nsplit = p.dkv_part ? attention_bwd_nsplit(p.B, p.H, p.Sq, p.Skv) : 1;
   int rc = attn_check(p);

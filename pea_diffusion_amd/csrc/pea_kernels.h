@@ -80,6 +80,7 @@ struct AttnP {
   int accum_dq, accum_dkv;         // += into existing gradients
   float* dkv_part; int nsplit;     // optional fp32 scratch (attention_bwd_scratch_bytes) enabling the query split
   int nd;                          // padded head_dim / 64 (0 is read as 1)
+  int xcd_remap;                   // set by the launchers: XCD-aware workgroup order
   int causal;                      // forward only: key index <= query index (text encoders)
   const int* kv_len;               // forward only: per-sample number of valid keys (key padding mask), may be null
 };
