@@ -76,7 +76,6 @@ class ControlNetRef(nn.Module):
 
     def forward(self, sample, timestep, encoder_hidden_states, controlnet_cond, conditioning_scale=1.0,
                 guess_mode=False, added_cond_kwargs=None, return_dict=False):
-        assert not guess_mode, "guess_mode is not part of the restated path (reference default False, :376)"
         B = sample.shape[0]
         emb = self.embed(timestep, added_cond_kwargs, B)
         x = self.conv_in(sample) + self.controlnet_cond_embedding(controlnet_cond)
@@ -85,6 +84,13 @@ class ControlNetRef(nn.Module):
             x, outs = blk(x, emb, encoder_hidden_states)
             res += outs
         x = self.mid_block(x, emb, encoder_hidden_states)
-        down = [conv(r) * conditioning_scale for r, conv in zip(res, self.controlnet_down_blocks)]
-        mid = self.controlnet_mid_block(x) * conditioning_scale
+        down = [conv(r) for r, conv in zip(res, self.controlnet_down_blocks)]
+        mid = self.controlnet_mid_block(x)
+        if guess_mode:                       # diffusers 0.23 [ext]: residual i is weighted 0.1 .. 1.0 on a log scale (:516)
+            scales = torch.logspace(-1, 0, len(down) + 1) * conditioning_scale
+            down = [d * s for d, s in zip(down, scales)]
+            mid = mid * scales[-1]
+        else:
+            down = [d * conditioning_scale for d in down]
+            mid = mid * conditioning_scale
         return down, mid

@@ -84,13 +84,19 @@ class HipControlNet:
                                            stream_ptr()))
         self._keep = (x, t, ehs, text, tid)
 
-    def outputs(self, conditioning_scale: float = 1.0):
-        """(down_block_res_samples, mid_block_res_sample) as fp32 NCHW torch tensors, as diffusers returns them"""
+    def outputs(self, conditioning_scale: float = 1.0, guess_mode: bool = False):
+        """(down_block_res_samples, mid_block_res_sample) as fp32 NCHW torch tensors, as diffusers returns them.
+        guess_mode (tests/test_sdxl_zh_controlnet.py:376,516): residual i is weighted on a log scale from 0.1 to 1.0;
+        the caller then concatenates zeros for the unconditional half (:525-526), as in the reference loop."""
+        shapes = self.output_shapes()
+        scales = [conditioning_scale] * len(shapes)
+        if guess_mode:
+            scales = (torch.logspace(-1, 0, len(shapes)) * conditioning_scale).tolist()
         outs = []
-        for i, (c, h, w) in enumerate(self.output_shapes()):
+        for i, (c, h, w) in enumerate(shapes):
             o = torch.empty(self.B, c, h, w, device=self.device, dtype=torch.float32)
             check(lib().pea_controlnet_export_nchw(self._h, i, ptr(o), stream_ptr()))
-            outs.append(o * conditioning_scale if conditioning_scale != 1.0 else o)
+            outs.append(o * scales[i] if scales[i] != 1.0 else o)
         return outs[:-1], outs[-1]
 
     def feed(self, unet: HipUNet, conditioning_scale: float = 1.0):
@@ -107,7 +113,5 @@ class HipControlNet:
 
     def __call__(self, sample, timestep, encoder_hidden_states, controlnet_cond, conditioning_scale: float = 1.0,
                  guess_mode: bool = False, added_cond_kwargs=None, return_dict: bool = False):
-        if guess_mode:
-            raise NotImplementedError("guess_mode (reference default False, tests/test_sdxl_zh_controlnet.py:376)")
         self.run(sample, timestep, encoder_hidden_states, controlnet_cond, added_cond_kwargs)
-        return self.outputs(float(conditioning_scale))
+        return self.outputs(float(conditioning_scale), bool(guess_mode))

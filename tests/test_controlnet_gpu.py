@@ -44,6 +44,14 @@ def test_controlnet_forward_vs_oracle(gpu):
         e = rel_l2(a, b)
         print(f"   controlnet residual {i}: {tuple(a.shape)} rel_l2={e:.3e}")
         assert a.shape == b.shape and e < 2e-2, i
+    # guess_mode: log-spaced residual weights (diffusers 0.23; the reference passes the flag through, :516)
+    with torch.no_grad():
+        dg, mg = ref(x, t, ehs, img, conditioning_scale=0.8, guess_mode=True, added_cond_kwargs=added)
+    down_g, mid_g = hip(x.cuda(), t.cuda(), encoder_hidden_states=ehs.cuda(), controlnet_cond=img.cuda(),
+                        conditioning_scale=0.8, guess_mode=True, added_cond_kwargs=cadd, return_dict=False)
+    for a, b in zip(down_g + [mid_g], dg + [mg]):
+        assert rel_l2(a, b) < 2e-2
+    assert abs(float(down_g[0].abs().mean() / down[0].abs().mean()) - 0.1) < 1e-3
     # the cached conditioning embedding is reused for the same image tensor and recomputed for a new one
     down2, _ = hip(x.cuda(), t.cuda(), ehs.cuda(), img.cuda(), 0.8, added_cond_kwargs=cadd)
     img_c = img.cuda()
