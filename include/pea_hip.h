@@ -216,6 +216,7 @@ typedef struct pea_text_config {
   int flavor;       /* 0 CLIP, 1 BERT */
   int proj_dim;     /* CLIP text_projection width, 0 = none */
   float eps;
+  int pos_offset;   /* position row = token index + pos_offset: 2 for RoBERTa / XLM-R towers (mul_clip, alt_clip), else 0 */
   long long eos_id; /* CLIP: EOS id (< 0: argmax of the ids); BERT: pad id */
 } pea_text_config;
 int pea_text_create(const pea_text_config* cfg, int B, int L, void** out);

@@ -8,7 +8,8 @@ import numpy as np
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from transformers import BertConfig, BertModel, CLIPTextConfig, CLIPTextModelWithProjection  # noqa: E402
+from transformers import (BertConfig, BertModel, CLIPTextConfig, CLIPTextModelWithProjection, XLMRobertaConfig,  # noqa: E402
+                          XLMRobertaModel)
 
 OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
 
@@ -57,7 +58,25 @@ def main():
     for i, h in enumerate(ob.hidden_states):
         d[f"hidden_{i}"] = h.numpy()
     np.savez_compressed(os.path.join(OUT, "text_bert.npz"), **d)
-    print("wrote", [(f, os.path.getsize(os.path.join(OUT, f))) for f in ("text_clip.npz", "text_bert.npz")])
+    torch.manual_seed(2)
+    x = XLMRobertaConfig(vocab_size=1000, hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=512,
+                         max_position_embeddings=66, type_vocab_size=1, pad_token_id=1, layer_norm_eps=1e-5)
+    xm = XLMRobertaModel(x, add_pooling_layer=False).eval()
+    with torch.no_grad():
+        for p in xm.parameters():
+            if p.dim() >= 2:
+                p.mul_(3.0)
+            else:
+                p.add_(0.05 * torch.randn_like(p))
+    ids = torch.randint(2, 1000, (2, 64))
+    ids[0, 25:] = 1
+    ids[1, 50:] = 1
+    with torch.no_grad():
+        ox = xm(ids, attention_mask=(ids != 1).long(), output_hidden_states=True)
+    d = {"w." + k: v.numpy() for k, v in xm.state_dict().items()}
+    d.update(ids=ids.numpy(), last_hidden_state=ox.last_hidden_state.numpy())
+    np.savez_compressed(os.path.join(OUT, "text_xlmr.npz"), **d)
+    print("wrote", [(f, os.path.getsize(os.path.join(OUT, f))) for f in ("text_clip.npz", "text_bert.npz", "text_xlmr.npz")])
 
 
 if __name__ == "__main__":

@@ -101,9 +101,11 @@ class _BertLayer(nn.Module):
 class BertTextRef(nn.Module):
     """keys as HF BertModel: embeddings.{word,position,token_type}_embeddings, embeddings.LayerNorm, encoder.layer.N.*"""
 
-    def __init__(self, cfg, type_vocab_size=2):
+    def __init__(self, cfg, type_vocab_size=None):
         super().__init__()
         self.cfg = cfg
+        self.pos_offset = getattr(cfg, "position_offset", 0)      # RoBERTa / XLM-R: 2
+        type_vocab_size = type_vocab_size or (1 if self.pos_offset else 2)
         w = cfg.hidden_size
         self.embeddings = nn.Module()
         self.embeddings.word_embeddings = nn.Embedding(cfg.vocab_size, w)
@@ -117,7 +119,7 @@ class BertTextRef(nn.Module):
     def forward(self, ids):
         B, L = ids.shape
         e = self.embeddings
-        x = e.LayerNorm(e.word_embeddings(ids) + e.position_embeddings(torch.arange(L))[None] + e.token_type_embeddings.weight[0])
+        x = e.LayerNorm(e.word_embeddings(ids) + e.position_embeddings(torch.arange(L) + self.pos_offset)[None] + e.token_type_embeddings.weight[0])
         valid = ids != self.cfg.eos_token_id                      # pad id; right padding
         mask = torch.zeros(B, 1, 1, L).masked_fill(~valid[:, None, None, :], float("-inf"))
         hs = [x]

@@ -179,6 +179,7 @@ class TextConfig:
     projection_dim: int = 0
     layer_norm_eps: float = 1e-5
     eos_token_id: int = -1                  # clip: EOS id (-1: argmax of the ids, the original CLIP vocabulary); bert: pad id
+    position_offset: int = 0                # RoBERTa / XLM-R: 2 (position = padding_idx + 1 + index)
     name: str = "clip_l"
 
 
@@ -197,6 +198,18 @@ def cnclip_bert_large_config() -> TextConfig:   # Chinese-CLIP ViT-H/14 text tow
                       layer_norm_eps=1e-12, eos_token_id=0, name="cnclip_bert_large")
 
 
+def xlm_roberta_large_config() -> TextConfig:   # text tower of xlm-roberta-large-ViT-H-14 (mul_clip) and of AltCLIP
+    return TextConfig(vocab_size=250002, max_position_embeddings=514, hidden_size=1024, num_attention_heads=16,
+                      num_hidden_layers=24, intermediate_size=4096, hidden_act="gelu", flavor="bert", layer_norm_eps=1e-5,
+                      eos_token_id=1, position_offset=2, name="xlm_roberta_large")
+
+
+def tiny_xlmr_config() -> TextConfig:
+    return TextConfig(vocab_size=1000, max_position_embeddings=66, hidden_size=128, num_attention_heads=2,
+                      num_hidden_layers=2, intermediate_size=512, hidden_act="gelu", flavor="bert", layer_norm_eps=1e-5,
+                      eos_token_id=1, position_offset=2, name="tiny_xlmr")
+
+
 def tiny_clip_config() -> TextConfig:
     return TextConfig(vocab_size=1000, max_position_embeddings=77, hidden_size=128, num_attention_heads=2,
                       num_hidden_layers=3, intermediate_size=512, projection_dim=64, eos_token_id=999, name="tiny_clip")
@@ -211,7 +224,7 @@ def tiny_bert_config() -> TextConfig:
 class CTextConfig(ctypes.Structure):
     _fields_ = [("vocab", ctypes.c_int), ("max_pos", ctypes.c_int), ("width", ctypes.c_int), ("heads", ctypes.c_int),
                 ("layers", ctypes.c_int), ("intermediate", ctypes.c_int), ("act", ctypes.c_int), ("flavor", ctypes.c_int),
-                ("proj_dim", ctypes.c_int), ("eps", ctypes.c_float), ("eos_id", ctypes.c_longlong)]
+                ("proj_dim", ctypes.c_int), ("eps", ctypes.c_float), ("pos_offset", ctypes.c_int), ("eos_id", ctypes.c_longlong)]
 
 
 def text_to_c(cfg) -> CTextConfig:
@@ -221,4 +234,5 @@ def text_to_c(cfg) -> CTextConfig:
     c.act = {"quick_gelu": 3, "gelu": 1}[cfg.hidden_act]
     c.flavor = {"clip": 0, "bert": 1}[cfg.flavor]
     c.proj_dim, c.eps, c.eos_id = cfg.projection_dim, cfg.layer_norm_eps, cfg.eos_token_id
+    c.pos_offset = getattr(cfg, "position_offset", 0)
     return c

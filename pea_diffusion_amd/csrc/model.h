@@ -34,6 +34,7 @@ struct PeaTextCfg {          // mirrors `pea_text_config` of include/pea_hip.h
   int flavor;                // 0: CLIP text model (pre-LN, causal, final LN, EOS pooling), 1: BERT (post-LN, key padding)
   int proj_dim;              // CLIP text_projection width (0: none)
   float eps;
+  int pos_offset;            // position row = token index + pos_offset (RoBERTa / XLM-R: 2, else 0)
   long long eos_id;          // CLIP: EOS token id (< 0: argmax of the ids);  BERT: pad token id
 };
 

@@ -374,7 +374,8 @@ int Tape::build_text() {
   SHAPECHK(!needs_grad, "text encoder: inference graph only");
   SHAPECHK(c.width % 64 == 0 && c.heads > 0 && c.width / c.heads == 64 && c.width % c.heads == 0,
            "text encoder: width %d / heads %d (head_dim must be 64)", c.width, c.heads);
-  SHAPECHK(c.intermediate % 64 == 0 && c.layers >= 1 && L <= c.max_pos && c.proj_dim % 4 == 0, "text encoder: dims");
+  SHAPECHK(c.intermediate % 64 == 0 && c.layers >= 1 && L + c.pos_offset <= c.max_pos && c.pos_offset >= 0 && c.proj_dim % 4 == 0,
+           "text encoder: dims");
   Builder bd(*this);
   const bool bert = c.flavor == 1;
   const std::string emb = bert ? "embeddings." : "text_model.embeddings.";
@@ -385,7 +386,7 @@ int Tape::build_text() {
     o.out = x;
     o.w = bd.lin(emb + (bert ? "word_embeddings.weight" : "token_embedding.weight"), c.vocab, W);
     o.bias = bd.lin(emb + (bert ? "position_embeddings.weight" : "position_embedding.weight"), c.max_pos, W);
-    if (bert) o.c = bd.lin(emb + "token_type_embeddings.weight", 2, W);
+    if (bert) o.c = bd.lin(emb + "token_type_embeddings.weight", c.pos_offset ? 1 : 2, W);   // RoBERTa family: one type row
   }
   if (bert) x = bd.ln(x, emb + "LayerNorm", c.eps);
   hidden.push_back(x);
@@ -919,8 +920,8 @@ int Tape::exec_ops(size_t begin, size_t end, bool skip_cached, hipStream_t s) {
       case OP_EMBED: {
         SHAPECHK(ids_in != nullptr, "text encoder: no input ids");
         Tn& out = tn[o.out];
-        RC(launch_embed_tokens(ids_in, slots[o.w].w, slots[o.bias].w, o.c >= 0 ? slots[o.c].w : nullptr, out.d, B, L, out.cols,
-                               tcfg.vocab, s));
+        RC(launch_embed_tokens(ids_in, slots[o.w].w, slots[o.bias].w + (long long)tcfg.pos_offset * out.cols,
+                               o.c >= 0 ? slots[o.c].w : nullptr, out.d, B, L, out.cols, tcfg.vocab, s));
         break;
       }
       case OP_GATHER_EOS:

@@ -40,6 +40,18 @@ def test_bert_text_restatement_matches_transformers(golden_dir):
         assert torch.allclose(h[valid], torch.from_numpy(z[f"hidden_{i}"])[valid], rtol=1e-4, atol=1e-4), i
 
 
+def test_xlm_roberta_restatement_matches_transformers(golden_dir):
+    """RoBERTa-family tower (mul_clip's xlm-roberta-large, AltCLIP): BERT layers, positions offset by padding_idx + 1"""
+    z = np.load(os.path.join(golden_dir, "text_xlmr.npz"))
+    ref = BertTextRef(pc.tiny_xlmr_config())
+    _load(ref, z)
+    ids = torch.from_numpy(z["ids"])
+    with torch.no_grad():
+        o = ref(ids)
+    valid = ids != 1
+    assert torch.allclose(o["last_hidden_state"][valid], torch.from_numpy(z["last_hidden_state"])[valid], rtol=1e-4, atol=1e-4)
+
+
 def test_text_parameter_totals():
     """structural known-answers of the published encoders"""
     with torch.device("meta"):

@@ -52,6 +52,21 @@ def test_bert_text_encoder_vs_transformers_golden(gpu, golden_dir):
     assert e < 2e-2 and torch.isfinite(tokens).all()
 
 
+def test_xlm_roberta_text_encoder_vs_transformers_golden(gpu, golden_dir):
+    from pea_diffusion_amd import config as pc
+    from pea_diffusion_amd.text import HipTextEncoder
+    z, sd = _golden(golden_dir, "text_xlmr.npz")
+    enc = HipTextEncoder(pc.tiny_xlmr_config(), 2, 64)
+    assert set(enc.weight_table()) == set(sd)
+    enc.load_state_dict(sd)
+    ids = torch.from_numpy(z["ids"])
+    tokens, _ = enc.encode_text(ids.cuda())
+    valid = ids != 1
+    e = rel_l2(tokens.cpu()[valid], torch.from_numpy(z["last_hidden_state"])[valid])
+    print(f"[xlm-r text tiny] per-token states rel_l2={e:.3e} (valid positions)")
+    assert e < 2e-2
+
+
 def test_clip_l_width_vs_oracle(gpu):
     """CLIP-L width and depth (12 x 768, 123 M parameters), 77 tokens, against the fp32 restatement"""
     from oracle.text_ref import CLIPTextRef
