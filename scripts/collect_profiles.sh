@@ -12,6 +12,7 @@ find /tmp/prof_stats -name "*kernel_stats.csv" -exec cp {} $O/rocprofv3_kernel_s
 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d /tmp/prof_fetch -o r --output-format csv -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline > /dev/null 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d /tmp/prof_write -o r --output-format csv -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline > /dev/null 2>&1
 python3 $R/scripts/pmc_traffic.py /tmp/prof_fetch /tmp/prof_write > $O/pmc_traffic.json 2> $O/pmc_err.txt
+python3 $R/scripts/pmc_hbm.py /tmp/prof_fetch /tmp/prof_write > $O/pmc_hbm.json 2>> $O/pmc_err.txt
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace -d /tmp/prof_mfma -o r --output-format csv -- python3 $R/bench.py --single-stream --steps 2 --warmup 1 --no-cpu-baseline --no-roofline > /dev/null 2>&1
 python3 $R/scripts/pmc_mfma.py /tmp/prof_mfma > $O/pmc_mfma.json 2>> $O/pmc_err.txt
 python3 $R/scripts/gemm_bench.py 24,27,25,28,29,23,31 > $O/gemm_variants.log 2>&1
