@@ -303,6 +303,26 @@ int pea_trainer_get_option(void* trainer, const char* name);   /* also "merge_st
 /* intermediate results of the last step (fp32 NCHW [B][4][H][W]): which 0 = x_t, 1 = eps_student, 2 = eps_teacher */
 int pea_trainer_export(void* tr, int which, float* out, void* stream);
 
+/* Data-parallel collective (replaces DeepSpeed ZeRO-1's gradient all-reduce + parameter
+ * all-gather, train_sdxl_zh.sh:22,87 and utils/model_utils.py:57-67): one process per GPU, ONE RCCL all-reduce (sum, then
+ * x 1/world) over the flat fp32 adapter gradient per step, on a dedicated HIP stream owned by the communicator.
+ *   pea_comm_unique_id: rank 0 creates the 128-byte ncclUniqueId; the caller ships it to the other ranks (TCP store / file).
+ *   pea_comm_init:      BLOCKING rendezvous (ncclCommInitRank) on the calling thread's current HIP device.
+ *   pea_allreduce_grads: asynchronous.  The comm stream first waits for everything enqueued on `compute_stream` so far
+ *                        (the adapter wgrad), then all-reduces `grads` in place and scales by 1/world.
+ *   pea_comm_join:      makes `stream` wait for the last all-reduce (call before the optimizer reads `grads`).
+ *   pea_comm_last_ms:   BLOCKING; device time of the last all-reduce + scale in milliseconds.
+ *   pea_comm_broadcast: parameter broadcast from `root` (identical replicas at start), enqueued on `stream`.      */
+int pea_comm_unique_id(void* out128);
+int pea_comm_init(int rank, int world, const void* unique_id128, void** comm_out);
+int pea_comm_destroy(void* comm);
+int pea_comm_world(void* comm);
+int pea_comm_rank(void* comm);
+int pea_allreduce_grads(void* comm, float* grads, long long n, void* compute_stream);
+int pea_comm_join(void* comm, void* stream);
+int pea_comm_last_ms(void* comm, float* ms);
+int pea_comm_broadcast(void* comm, float* buf, long long n, int root, void* stream);
+
 /* per-launch HIP-event timing by kernel family (bench.py roofline leg); families 0..7:
  * gemm<plain>, gemm<conv3x3>, attn_fwd, attn_bwd, groupnorm, layernorm, elementwise, kd_loss.
  * pea_prof_report synchronises the device.                                                       */

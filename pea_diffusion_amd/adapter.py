@@ -60,6 +60,7 @@ class PEAAdapter(nn.Module):
         self.flat_param: Optional[torch.Tensor] = None
         self.flat_grad: Optional[torch.Tensor] = None
         self._synced_version = None
+        self._src_key = None
 
     # ---- flat parameter plumbing
     def _plist(self):
@@ -78,7 +79,11 @@ class PEAAdapter(nn.Module):
         ok = (self.flat_param is not None and self.flat_param.device == dev and all(
             p.dtype == torch.float32 and p.data_ptr() == self.flat_param.data_ptr() + 4 * o
             for p, o in zip(ps, self._offsets)))
-        if ok:
+        # .half() / .bfloat16() modules (tests/test_sdxl_zh.py:92 builds `MLP(...).to(DEVICE).half()`): the presented
+        # parameters cannot alias the fp32 master buffer, so they are re-read only when one of them was replaced or
+        # written in place since the last flatten
+        key = tuple((p.data_ptr(), p._version, p.dtype) for p in ps)
+        if ok or (self.flat_param is not None and self.flat_param.device == dev and key == self._src_key):
             return
         flat = torch.empty(n, device=dev, dtype=torch.float32)
         offs, o = [], 0
@@ -91,6 +96,7 @@ class PEAAdapter(nn.Module):
             for p, oo in zip(ps, offs):
                 p.data = flat[oo:oo + p.numel()].view_as(p)
         self.flat_param, self._offsets = flat, offs
+        self._src_key = tuple((p.data_ptr(), p._version, p.dtype) for p in ps)
         self.flat_grad = torch.zeros_like(flat)
         self._synced_version = None
         if not self._h.value:

@@ -29,7 +29,7 @@ class HipControlNet:
         self._h = ctypes.c_void_p()
         c = _cfg.to_c(cfg)
         check(lib().pea_controlnet_create(ctypes.byref(c), self.B, self.H, self.W, self.L, ctypes.byref(self._h)))
-        self._cond_key = None
+        self._cond_ref, self._cond_version = None, None
 
     __del__ = HipUNet.__del__
     weight_table = HipUNet.weight_table
@@ -51,13 +51,20 @@ class HipControlNet:
         """controlnet_cond: [B, 3, 8H, 8W] (the prepared canny image, values in [0, 1])"""
         if tuple(image.shape) != (self.B, 3, 8 * self.H, 8 * self.W):
             raise PeaError(f"controlnet_cond {tuple(image.shape)} != {(self.B, 3, 8 * self.H, 8 * self.W)}")
-        key = (image.data_ptr(), image._version, tuple(image.shape), image.dtype)
-        if key == self._cond_key:
+        # The embedding is cached per conditioning image.  The key holds a REFERENCE to the tensor it was computed from
+        # (identity + in-place version), so the allocator cannot hand a later image the same address while the key is
+        # live: the reference pipeline builds a fresh prepare_image() tensor per generation
+        # (tests/test_sdxl_zh_controlnet.py:478-497).
+        if self._cond_ref is image and self._cond_version == image._version:
             return
         img = image.detach().to(self.device, torch.float32).contiguous()
         check(lib().pea_controlnet_set_cond(self._h, ptr(img), stream_ptr()))
         torch.cuda.current_stream().synchronize()       # `img` may be a temporary
-        self._cond_key = key
+        self._cond_ref, self._cond_version = image, image._version
+
+    def invalidate_cond(self):
+        """forget the cached conditioning embedding (the next run() recomputes it)"""
+        self._cond_ref, self._cond_version = None, None
 
     def run(self, sample, timestep, encoder_hidden_states, controlnet_cond, added_cond_kwargs=None):
         """forward pass; results stay on the device inside the context (see `feed` / `outputs`)"""

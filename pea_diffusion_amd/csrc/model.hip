@@ -1481,6 +1481,8 @@ int Trainer::step_merged(const float* latents, const float* noise, const long lo
                          const float* time_ids, float grad_scale, float* grads, int accumulate, float* losses_out,
                          hipStream_t s) {
   Tape& M = *merged;
+  SHAPECHK(M.t_text < 0 || (teacher_pooled != nullptr && time_ids != nullptr),
+           "trainer: teacher_pooled / time_ids are required for a text_time UNet (added_cond_kwargs, train_sdxl_zh.py:386-396)");
   RC(M.ensure_acts());
   Adapter& A = *ad;
   const int B = student->B;

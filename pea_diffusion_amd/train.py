@@ -53,7 +53,8 @@ class PEATrainer:
         self.global_step = 0
         self._m = torch.zeros_like(adapter.flat_param)
         self._v = torch.zeros_like(adapter.flat_param)
-        self._comm_stream = None
+        self.comm: Optional[pdist.NativeComm] = None      # RCCL communicator + comm stream inside libpea_hip.so
+        self._pending = None                               # torch.distributed work handle (gloo / torch-NCCL path)
 
     def __del__(self):
         try:
@@ -85,8 +86,8 @@ class PEATrainer:
                                    ptr(tp), ptr(tid), 1.0, ptr(self.adapter.flat_grad), 0, ptr(self.losses),
                                    stream_ptr()))
         self._keep = (b, ts, pm, zh, tp, tid)
-        if world > 1:
-            self.all_reduce_grads()
+        if self.comm is not None or world > 1:
+            self.all_reduce_grads_async()   # launched right behind the adapter wgrad; joined in optimizer_step()
         for p, o in zip(self.adapter._plist(), self.adapter._offsets):
             p.grad = self.adapter.flat_grad[o:o + p.numel()].view_as(p)
         snap = self.losses.clone()          # device-side snapshot: later steps overwrite self.losses
@@ -105,8 +106,30 @@ class PEATrainer:
     def world_size(self) -> int:
         return pdist.world_size()
 
-    def all_reduce_grads(self, async_op: bool = False):
-        return pdist.allreduce_mean_(self.adapter.flat_grad, async_op=async_op)
+    def attach_comm(self, comm: "pdist.NativeComm"):
+        """use the library's own RCCL communicator (dedicated comm stream) for the gradient all-reduce"""
+        self.comm = comm
+
+    def all_reduce_grads_async(self):
+        """ONE all-reduce of the flat adapter gradient, off the compute stream: RCCL on the communicator's own HIP
+        stream (`pea_allreduce_grads`), or -- without an attached communicator -- torch.distributed's asynchronous
+        all-reduce (ProcessGroupNCCL runs it on its internal stream).  `join_grads()` must precede any read."""
+        if self.comm is not None:
+            self.comm.allreduce_mean_async(self.adapter.flat_grad)
+        else:
+            self._pending = pdist.allreduce_mean_(self.adapter.flat_grad, async_op=True)
+
+    def join_grads(self):
+        if self.comm is not None:
+            self.comm.join()
+        elif self._pending is not None:
+            self._pending.wait()
+            self.adapter.flat_grad.div_(self.world_size)
+            self._pending = None
+
+    def all_reduce_grads(self):
+        self.all_reduce_grads_async()
+        self.join_grads()
 
     def export(self, which: str) -> torch.Tensor:
         idx = {"x_t": 0, "eps_student": 1, "eps_teacher": 2}[which]
@@ -121,8 +144,11 @@ class PEATrainer:
         return polynomial_lr(self.global_step, self.lr, self.warmup_steps, self.total_steps, self.lr_end)
 
     def optimizer_step(self):
-        self.global_step += 1
+        # Lightning + transformers' LambdaLR: optimizer step k (1-indexed) runs with lambda(k - 1), so the very first
+        # update has lr = 0 (utils/model_utils.py:98-140); Adam's bias correction uses k.
+        self.join_grads()
         lr = polynomial_lr(self.global_step, self.lr, self.warmup_steps, self.total_steps, self.lr_end)
+        self.global_step += 1
         ops.adamw_(self.adapter.flat_param, self.adapter.flat_grad, self._m, self._v, lr, self.global_step,
                    self.betas[0], self.betas[1], self.eps, self.weight_decay)
         self.adapter.flat_param._version  # noqa: B018  (in-place op below bumps the version counter)

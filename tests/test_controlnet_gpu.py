@@ -62,6 +62,20 @@ def test_controlnet_forward_vs_oracle(gpu):
     with torch.no_grad():
         d_inv, _ = ref(x, t, ehs, 1.0 - img, conditioning_scale=1.0, added_cond_kwargs=added)
     assert not torch.equal(b1[0], a1[0]) and rel_l2(b1[0], d_inv[0]) < 2e-2 and rel_l2(b1[-1], d_inv[-1]) < 2e-2
+    # a fresh conditioning tensor per generation (prepare_image() in the reference pipeline): the caching allocator
+    # hands the next image the address of the freed one at in-place version 0 -- the cache must not mistake it for the old
+    prev = None
+    for k in range(3):
+        cimg = ((img + 0.37 * k) % 1.0).cuda()
+        addr = cimg.data_ptr()
+        r, _ = hip(x.cuda(), t.cuda(), ehs.cuda(), cimg, 1.0, added_cond_kwargs=cadd)
+        with torch.no_grad():
+            d_k, _ = ref(x, t, ehs, (img + 0.37 * k) % 1.0, conditioning_scale=1.0, added_cond_kwargs=added)
+        assert rel_l2(r[0], d_k[0]) < 2e-2, (k, addr)
+        if prev is not None:
+            assert not torch.equal(prev, r[0])
+        prev = r[0].clone()
+        del cimg, r
 
 
 def test_controlnet_denoise_loop_vs_oracle(gpu):

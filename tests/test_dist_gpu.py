@@ -1,0 +1,97 @@
+"""-m gpu: the data-parallel collective on the real RCCL (row a11 / 8(e)).  The box has ONE GPU, so the communicators are
+world-size 1 -- enough to run ncclCommInitRank, the all-reduce on the communicator's own HIP stream, the event hand-offs
+between the compute and comm streams, the broadcast and torch.distributed's nccl backend; the 2-rank arithmetic is
+covered over gloo in tests/test_dp_cpu.py and the N-rank run is the driver's SCALE bench."""
+import ctypes
+import os
+import socket
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+from test_model_gpu import _train_pair, gpu  # noqa: E402,F401
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def test_native_comm_world1_allreduce_broadcast_streams(gpu):
+    """C ABI pea_comm_unique_id / pea_comm_init / pea_allreduce_grads / pea_comm_join / pea_comm_broadcast through ctypes"""
+    from pea_diffusion_amd.dist import NativeComm
+    comm = NativeComm.from_env()
+    assert comm.world == 1 and comm.rank == 0
+    g = torch.randn(6_033_408, device="cuda")             # the 6M adapter's flat gradient (24 MB)
+    ref = g.clone()
+    side = torch.cuda.Stream()
+    # the producer runs on a side stream: the comm stream must wait for it through the event, not through a device sync
+    with torch.cuda.stream(side):
+        g.mul_(3.0)
+        comm.allreduce_mean_async(g, compute_stream=side)
+    comm.join()                                            # current stream waits for the comm stream
+    out = g.clone()
+    torch.cuda.synchronize()
+    assert torch.equal(out, ref * 3.0)                     # sum over one rank, x 1/1
+    assert comm.last_ms() > 0.0
+    p = torch.randn(1000, device="cuda")
+    q = p.clone()
+    comm.broadcast_(p, 0)
+    torch.cuda.synchronize()
+    assert torch.equal(p, q)
+    comm.close()
+
+
+def test_comm_argument_errors(gpu):
+    from pea_diffusion_amd._lib import lib
+    L = lib()
+    h = ctypes.c_void_p()
+    assert L.pea_comm_init(2, 2, b"\0" * 128, ctypes.byref(h)) == -3 and b"rank 2 of 2" in L.pea_last_error()
+    assert L.pea_allreduce_grads(None, None, 4, None) == -1
+    assert L.pea_comm_join(None, None) == -1
+
+
+def test_trainer_step_with_rccl_world1_matches_plain_step(gpu):
+    """the step with the all-reduce launched on the comm stream and joined by optimizer_step() == the step without it
+    (world 1: the all-reduce is the identity), bit for bit; then the torch.distributed nccl path (all_reduce +
+    broadcast_params_) on the same flat buffers."""
+    import torch.distributed as dist
+    from pea_diffusion_amd import dist as pdist
+    cfg, us, ut, ad_ref, ad_hip, hs, ht, batch, tr = _train_pair(2, 12)
+    tr.training_step(batch, 0, sync=True)
+    g0 = ad_hip.flat_grad.clone()
+    comm = pdist.NativeComm.from_env()
+    tr.attach_comm(comm)
+    tr.training_step(batch, 0)
+    tr.join_grads()
+    torch.cuda.synchronize()
+    assert torch.equal(g0, ad_hip.flat_grad)
+    w0 = ad_hip.flat_param.clone()
+    tr.lr, tr.warmup_steps = 1e-3, 0
+    tr.training_step(batch, 0)
+    tr.optimizer_step()                                    # joins the comm stream before AdamW reads the gradient
+    torch.cuda.synchronize()
+    assert not torch.equal(w0, ad_hip.flat_param)
+    tr.comm = None
+    comm.close()
+    # torch.distributed over RCCL (backend "nccl"), one rank
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
+    try:
+        g = ad_hip.flat_grad.clone()
+        dist.all_reduce(ad_hip.flat_grad)
+        pdist.broadcast_params_(ad_hip.flat_param, src=0)
+        c2 = pdist.NativeComm.from_env()                   # unique id shipped through the torch group's object broadcast
+        c2.allreduce_mean_async(ad_hip.flat_grad)
+        c2.join()
+        torch.cuda.synchronize()
+        assert torch.equal(g, ad_hip.flat_grad)
+        c2.close()
+    finally:
+        dist.destroy_process_group()
+        for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR"):
+            os.environ.pop(k, None)

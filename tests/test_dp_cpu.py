@@ -97,3 +97,52 @@ def test_shard_batch_and_lr_schedule():
     assert polynomial_lr(3_000_000, 1e-5, 100, 2232142, 5e-8) == 5e-8
     mid = polynomial_lr(1116121, 1e-5, 100, 2232142, 5e-8)
     assert 4.9e-6 < mid < 5.1e-6
+
+
+def test_lr_used_by_optimizer_step_k_matches_transformers_lambda():
+    """The reference schedules with transformers' polynomial decay through a LambdaLR stepped after every optimizer
+    step (utils/model_utils.py:98-140): optimizer step k (1-indexed) runs with lambda(k - 1), so the first update has
+    lr = 0.  PEATrainer.optimizer_step() computes its lr from global_step BEFORE incrementing it."""
+    sys.path.insert(0, ROOT)
+    from transformers.optimization import get_polynomial_decay_schedule_with_warmup
+    from pea_diffusion_amd.train import polynomial_lr
+    base, warm, total, end = 1e-5, 100, 2000, 5e-8
+    w = torch.nn.Parameter(torch.zeros(1))
+    opt = torch.optim.AdamW([w], lr=base)
+    sch = get_polynomial_decay_schedule_with_warmup(opt, warm, total, lr_end=end, power=1.0)
+    used = []
+    for k in range(1, 2105):
+        used.append(opt.param_groups[0]["lr"])       # what optimizer step k runs with
+        w.grad = torch.ones(1)
+        opt.step()
+        sch.step()
+    for k in (1, 2, 3, 50, warm, warm + 1, warm + 2, 1000, total, total + 1, total + 50):
+        ours = polynomial_lr(k - 1, base, warm, total, end)       # optimizer_step(): lr from the pre-increment step
+        assert abs(ours - used[k - 1]) <= 1e-12 + 1e-9 * used[k - 1], (k, ours, used[k - 1])
+    assert used[0] == 0.0 and polynomial_lr(0, base, warm, total, end) == 0.0
+
+
+def test_bench_launcher_spawns_two_ranks_over_gloo():
+    """`python bench.py --gpus 2` (no torch.distributed.run, no WORLD_SIZE): the script itself starts two ranks before
+    any GPU call, the ranks rendezvous, all-reduce through pea_diffusion_amd.dist and rank 0's single JSON line comes
+    back through the parent.  --dry-run-collective keeps it on CPU tensors over gloo (no kernel runs; the same launcher
+    and rank plumbing carry the RCCL run on the GPU box)."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--dry-run-collective"],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["ranks"] == 2 and out["n_gpus"] == 2 and out["per_gpu_batch"] == 8 and out["global_batch"] == 16
+    assert out["allreduce_max_abs_err"] < 1e-5 and out["dry_run"] is True
+
+
+def test_bench_refuses_a_world_size_that_contradicts_gpus():
+    import subprocess
+    env = dict(os.environ, WORLD_SIZE="3", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run-collective"],
+                       capture_output=True, text=True, timeout=120, env=env)
+    assert r.returncode == 2 and "WORLD_SIZE=3" in r.stderr and not r.stdout.strip()

@@ -160,6 +160,38 @@ def test_adapter_module_matches_reference_golden(gpu, golden_dir):
             assert e < 1e-2
 
 
+def test_adapter_half_surface(gpu):
+    """`proj = MLP(1024, 1280, 2048, 2048, use_residual=False).to(DEVICE).half()` then
+    `proj.load_state_dict(torch.load(proj_path, map_location="cpu"))` and `x1, x2 = proj(text_embeddings)` on fp16
+    encoder states (tests/test_sdxl_zh.py:92,153,207): fp16 parameters are presented, fp16 outputs come back, the fp32
+    master copy is built once (not per call) and follows a later load_state_dict."""
+    from oracle.step_ref import AdapterRef
+    from pea_diffusion_amd.adapter import PEAAdapter
+    torch.manual_seed(5)
+    ref = AdapterRef(1024, 1280, 2048, 2048, False)
+    proj = PEAAdapter(1024, 1280, 2048, 2048, use_residual=False).to("cuda").half()
+    proj.load_state_dict(ref.state_dict())
+    assert all(p.dtype == torch.float16 for p in proj.parameters())
+    with torch.no_grad():
+        for p in ref.parameters():
+            p.copy_(p.half().float())                       # what the fp16 module holds
+    x = torch.randn(2, 77, 1024)
+    with torch.no_grad():
+        x1, x2 = proj(x.cuda().half())
+        flat_id = proj.flat_param.data_ptr()
+        y1, y2 = proj(x.cuda().half())
+        r1, r2 = ref(x.half().float())
+    assert proj.flat_param.data_ptr() == flat_id, "fp32 master buffer was rebuilt on the second call"
+    assert x1.dtype == torch.float16 and x2.dtype == torch.float16 and x1.shape == (2, 1280) and x2.shape == (2, 77, 2048)
+    assert torch.equal(x1, y1) and torch.equal(x2, y2)
+    assert rel_l2(x1, r1) < 1e-2 and rel_l2(x2, r2) < 1e-2
+    sd2 = {k: v * 0.5 for k, v in ref.state_dict().items()}
+    proj.load_state_dict(sd2)                               # in-place copy_: the presented parameters' versions move
+    with torch.no_grad():
+        z1, z2 = proj(x.cuda().half())
+    assert not torch.equal(z2, x2)
+
+
 @pytest.mark.parametrize("args", [(128, 192, 256, 128, False), (128, 128, 64, 192, True), (128, 64, 192, None, False)])
 def test_adapter_forward_backward_vs_oracle(gpu, args):
     from oracle.step_ref import AdapterRef
@@ -249,7 +281,7 @@ def test_training_step_repeatable_and_optimizer(gpu):
     # every reduction has a fixed order (no atomics anywhere on the path): bit-reproducible
     assert torch.equal(l1, tr.losses) and torch.equal(g1, ad_hip.flat_grad), "training step is not bit-reproducible"
     w0 = ad_hip.flat_param.clone()
-    tr.lr, tr.warmup_steps = 1e-3, 1
+    tr.lr, tr.warmup_steps = 1e-3, 0     # (with warm-up the first update runs at lr = lambda(0) = 0, as in the reference)
     tr.optimizer_step()
     assert not torch.equal(w0, ad_hip.flat_param)
     c = tr.training_step(batch, 0, sync=True)
