@@ -162,6 +162,13 @@ typedef struct pea_unet_config {
   int text_time;              /* addition_embed_type == "text_time" */
   int add_time_dim;
   int proj_in_dim;
+  /* per-position transformer depths (diffusers >= 0.22 configs such as SSD-1B, loaded as a downstream UNet at
+   * tests/test_sdxl_zh.py:449-454).  per_layer_depth = 0: the arrays below are ignored and filled from depth[]
+   * (every attention of a level has depth[level], the mid block depth[n_levels - 1], the up path mirrors the down path). */
+  int per_layer_depth;
+  int depth_down[4][4];       /* transformer_layers_per_block[i][j], DOWN order, j < layers_per_block */
+  int depth_up[4][4];         /* reverse_transformer_layers_per_block[i][j], UP order, j <= layers_per_block */
+  int depth_mid;              /* mid block transformer layers; -1: mid_block_type == null (no mid block at all) */
 } pea_unet_config;
 
 /* Builds the static op tape for a fixed (batch B, latent H x W, context length L) and allocates
@@ -254,6 +261,9 @@ int pea_unet_forward(void* unet, const float* x, const float* t, const void* ehs
                      int text_dtype, const float* time_ids, float* eps_out, void* stream);
 /* feature taps in the order of the reference's cast_hook (train_sdxl_zh.py:79-84): d0.., m, u0..  */
 int pea_unet_num_taps(void* unet);
+/* hook name of tap k: "d<i>" (down_blocks[i], the hidden state of its (hidden, res_samples) tuple), "m" (mid_block;
+ * absent when the config has no mid block), "u<i>" (up_blocks[i])                                     */
+int pea_unet_tap_name(void* unet, int k, char* name, int name_len);
 int pea_unet_tap_info(void* unet, int k, void** data, void** grad, int* B, int* H, int* W, int* C);
 int pea_unet_tap_export_nchw(void* unet, int k, int grad, float* out, void* stream);
 /* reverse pass: d(loss)/d(eps) in `deps` (fp32 NCHW, may be NULL) plus tap gradient seeds already

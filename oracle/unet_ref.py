@@ -22,7 +22,7 @@ from __future__ import annotations
 
 import math
 from dataclasses import dataclass, field
-from typing import Optional, Sequence, Tuple
+from typing import Optional, Sequence, Tuple, Union
 
 import torch
 import torch.nn as nn
@@ -38,7 +38,11 @@ class UNetConfig:
     down_block_types: Tuple[str, ...] = ("DownBlock2D", "CrossAttnDownBlock2D", "CrossAttnDownBlock2D")
     up_block_types: Tuple[str, ...] = ("CrossAttnUpBlock2D", "CrossAttnUpBlock2D", "UpBlock2D")
     layers_per_block: int = 2
-    transformer_layers_per_block: Tuple[int, ...] = (1, 2, 10)
+    # per down block: an int, or one int per attention of the block (diffusers >= 0.22 [ext], e.g. SSD-1B)
+    transformer_layers_per_block: Tuple[Union[int, Tuple[int, ...]], ...] = (1, 2, 10)
+    # per UP block, int or one per attention; None = the down list reversed (required when the down list is nested)
+    reverse_transformer_layers_per_block: Optional[Tuple[Union[int, Tuple[int, ...]], ...]] = None
+    mid_block_type: Optional[str] = "UNetMidBlock2DCrossAttn"   # None: `unet.mid_block is None`
     num_attention_heads: Tuple[int, ...] = (5, 10, 20)   # diffusers calls this `attention_head_dim`
     cross_attention_dim: int = 2048
     use_linear_projection: bool = True
@@ -73,11 +77,24 @@ def sd15_config() -> UNetConfig:
 
 
 def ssd1b_config() -> UNetConfig:
-    """SSD-1B student (BASELINE config #4).  Layer-pruned SDXL: same widths, fewer
-    transformer layers / no mid attention.  Recalled from the public model card [ext];
-    used only as an asymmetric teacher/student shape case."""
-    c = UNetConfig(transformer_layers_per_block=(1, 2, 4), name="ssd1b")
-    return c
+    """SSD-1B (BASELINE config #4; the downstream UNet of tests/test_sdxl_zh.py:449-454).  segmind/SSD-1B
+    `unet/config.json` [ext, recalled: no network here]: SDXL widths, attention stacks pruned per position
+    (down [.., [2, 2], [4, 4]], up [[4, 4, 10], [2, 1, 1], ..]) and `mid_block_type: null`.  Known answer: the model
+    card's 1.3 B parameters."""
+    return UNetConfig(transformer_layers_per_block=(1, (2, 2), (4, 4)),
+                      reverse_transformer_layers_per_block=((4, 4, 10), (2, 1, 1), 1),
+                      mid_block_type=None, name="ssd1b")
+
+
+def ssd1b_uniform_config() -> UNetConfig:
+    """round-1 stand-in: uniform depths 1/2/4 with a mid block (an asymmetric shape case only)"""
+    return UNetConfig(transformer_layers_per_block=(1, 2, 4), name="ssd1b_uniform")
+
+
+def _depth_row(v, k):
+    r = [int(v)] * k if isinstance(v, int) else [int(a) for a in v]
+    assert len(r) == k, (v, k)
+    return r
 
 
 def tiny_config(heads64: bool = True) -> UNetConfig:
@@ -258,8 +275,8 @@ class DownBlock(nn.Module):
             [ResnetBlock2D(cin if j == 0 else cout, cout, t, g, e) for j in range(cfg.layers_per_block)])
         if cross:
             self.attentions = nn.ModuleList(
-                [Transformer2DModel(cout, heads, depth, cfg.cross_attention_dim, g, cfg.use_linear_projection)
-                 for _ in range(cfg.layers_per_block)])
+                [Transformer2DModel(cout, heads, d, cfg.cross_attention_dim, g, cfg.use_linear_projection)
+                 for d in _depth_row(depth, cfg.layers_per_block)])
         else:
             self.attentions = None
         self.downsamplers = nn.ModuleList([Downsample2D(cout)]) if down else None
@@ -306,8 +323,8 @@ class UpBlock(nn.Module):
             self.resnets.append(ResnetBlock2D(rin + skip, cout, t, g, e))
         if cross:
             self.attentions = nn.ModuleList(
-                [Transformer2DModel(cout, heads, depth, cfg.cross_attention_dim, g, cfg.use_linear_projection)
-                 for _ in range(n)])
+                [Transformer2DModel(cout, heads, d, cfg.cross_attention_dim, g, cfg.use_linear_projection)
+                 for d in _depth_row(depth, n)])
         else:
             self.attentions = None
         self.upsamplers = nn.ModuleList([Upsample2D(cout)]) if up else None
@@ -344,10 +361,21 @@ class UNet2DConditionRef(nn.Module):
             self.down_blocks.append(DownBlock(cfg, cin, out, cfg.transformer_layers_per_block[i],
                                               cfg.num_attention_heads[i], ty.startswith("CrossAttn"),
                                               down=(i != nb - 1)))
-        self.mid_block = MidBlock(cfg, boc[-1], cfg.transformer_layers_per_block[-1], cfg.num_attention_heads[-1])
+        # diffusers >= 0.22 [ext]: the mid block takes the last down entry (its last element when that is a list);
+        # `mid_block_type: null` leaves `self.mid_block = None`
+        if cfg.mid_block_type is None:
+            self.mid_block = None
+        else:
+            last = cfg.transformer_layers_per_block[-1]
+            self.mid_block = MidBlock(cfg, boc[-1], last if isinstance(last, int) else last[-1], cfg.num_attention_heads[-1])
         self.up_blocks = nn.ModuleList()
         rboc = list(reversed(boc))
-        rdepth = list(reversed(cfg.transformer_layers_per_block))
+        if cfg.reverse_transformer_layers_per_block is not None:
+            rdepth = list(cfg.reverse_transformer_layers_per_block)
+        else:
+            assert all(isinstance(t, int) for t in cfg.transformer_layers_per_block), \
+                "reverse_transformer_layers_per_block is required with nested transformer_layers_per_block"
+            rdepth = list(reversed(cfg.transformer_layers_per_block))
         rheads = list(reversed(cfg.num_attention_heads))
         out = rboc[0]
         for i, ty in enumerate(cfg.up_block_types):
@@ -395,7 +423,8 @@ class UNet2DConditionRef(nn.Module):
         if down_block_additional_residuals is not None:
             assert len(down_block_additional_residuals) == len(res)
             res = tuple(r + a for r, a in zip(res, down_block_additional_residuals))
-        x = self.mid_block(x, emb, encoder_hidden_states)
+        if self.mid_block is not None:
+            x = self.mid_block(x, emb, encoder_hidden_states)
         if mid_block_additional_residual is not None:
             x = x + mid_block_additional_residual
         for blk in self.up_blocks:
@@ -411,7 +440,7 @@ def tap_names(cfg: UNetConfig):
     train_sd_zh.py:69-74): d0..d{n-1}, m, u0..u{n-1} with n = NUM_blocks = number of
     UNet levels (3 for SDXL, 4 for SD1.5)."""
     n = len(cfg.block_out_channels)
-    return [f"d{i}" for i in range(n)] + ["m"] + [f"u{i}" for i in range(n)]
+    return [f"d{i}" for i in range(n)] + (["m"] if cfg.mid_block_type is not None else []) + [f"u{i}" for i in range(n)]
 
 
 def cast_hook_ref(unet: UNet2DConditionRef, store: dict):
@@ -421,7 +450,8 @@ def cast_hook_ref(unet: UNet2DConditionRef, store: dict):
     for i in range(n):
         hs.append(unet.down_blocks[i].register_forward_hook(
             lambda m, inp, out, k=f"d{i}": store.__setitem__(k, out[0])))
-    hs.append(unet.mid_block.register_forward_hook(lambda m, inp, out: store.__setitem__("m", out)))
+    if unet.mid_block is not None:      # (the reference's cast_hook would raise on `None.register_forward_hook`)
+        hs.append(unet.mid_block.register_forward_hook(lambda m, inp, out: store.__setitem__("m", out)))
     for i in range(n):
         hs.append(unet.up_blocks[i].register_forward_hook(
             lambda m, inp, out, k=f"u{i}": store.__setitem__(k, out)))

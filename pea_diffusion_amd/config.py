@@ -6,7 +6,7 @@ from __future__ import annotations
 
 import ctypes
 from dataclasses import dataclass
-from typing import Optional, Tuple
+from typing import Optional, Tuple, Union
 
 
 @dataclass
@@ -18,7 +18,11 @@ class UNetConfig:
     down_block_types: Tuple[str, ...] = ("DownBlock2D", "CrossAttnDownBlock2D", "CrossAttnDownBlock2D")
     up_block_types: Tuple[str, ...] = ("CrossAttnUpBlock2D", "CrossAttnUpBlock2D", "UpBlock2D")
     layers_per_block: int = 2
-    transformer_layers_per_block: Tuple[int, ...] = (1, 2, 10)
+    # per down block: an int (every attention of the block) or one int per attention (diffusers >= 0.22, e.g. SSD-1B)
+    transformer_layers_per_block: Tuple[Union[int, Tuple[int, ...]], ...] = (1, 2, 10)
+    # per UP block (up order), int or one per attention (layers_per_block + 1); None = the down list reversed
+    reverse_transformer_layers_per_block: Optional[Tuple[Union[int, Tuple[int, ...]], ...]] = None
+    mid_block_type: Optional[str] = "UNetMidBlock2DCrossAttn"    # None: the UNet has no mid block
     num_attention_heads: Tuple[int, ...] = (5, 10, 20)   # diffusers: `attention_head_dim`
     cross_attention_dim: int = 2048
     use_linear_projection: bool = True
@@ -39,7 +43,76 @@ def sdxl_config() -> UNetConfig:
 
 
 def ssd1b_config() -> UNetConfig:
-    return UNetConfig(transformer_layers_per_block=(1, 2, 4), name="ssd1b")
+    """segmind/SSD-1B `unet/config.json` (the downstream UNet of tests/test_sdxl_zh.py:449-454; README.md:58) [ext,
+    recalled -- no network in the build image]: SDXL widths, layer-pruned attention stacks given per position
+    (`transformer_layers_per_block` [0, [2, 2], [4, 4]] on the way down, `reverse_transformer_layers_per_block`
+    [[4, 4, 10], [2, 1, 1], 0] on the way up) and no mid block.  Known answer: 1.3 B parameters (model card);
+    this layout has 1 300 195 844 (tests/test_oracle_unet.py).  `unet_config_from_diffusers()` reads the real file."""
+    return UNetConfig(transformer_layers_per_block=(1, (2, 2), (4, 4)),
+                      reverse_transformer_layers_per_block=((4, 4, 10), (2, 1, 1), 1),
+                      mid_block_type=None, name="ssd1b")
+
+
+def ssd1b_uniform_config() -> UNetConfig:
+    """round-1 stand-in (uniform depths 1/2/4 with a mid block); kept as an asymmetric shape case"""
+    return UNetConfig(transformer_layers_per_block=(1, 2, 4), name="ssd1b_uniform")
+
+
+def depth_tables(cfg):
+    """(down[i][j], up[i][j], mid) transformer depths from the diffusers fields, following UNet2DConditionModel.__init__
+    (diffusers >= 0.22 [ext]): ints are broadcast over a block's attentions, the up path defaults to the reversed down
+    list, the mid block takes the LAST down entry (its last element when that is a list)."""
+    n = len(cfg.block_out_channels)
+    lpb = cfg.layers_per_block
+    tl = cfg.transformer_layers_per_block
+    if isinstance(tl, int):
+        tl = (tl,) * n
+    tl = tuple(tl)
+    rev = getattr(cfg, "reverse_transformer_layers_per_block", None)
+    if rev is None:
+        if any(not isinstance(t, int) for t in tl):
+            raise ValueError("reverse_transformer_layers_per_block is required when transformer_layers_per_block is nested")
+        rev = tuple(reversed(tl))
+    if isinstance(rev, int):
+        rev = (rev,) * n
+
+    def row(v, k):
+        r = [int(v)] * k if isinstance(v, int) else [int(a) for a in v]
+        if len(r) != k:
+            raise ValueError(f"transformer depth list {v} must have {k} entries")
+        return r
+    down = [row(tl[i], lpb) for i in range(n)]
+    up = [row(rev[i], lpb + 1) for i in range(n)]
+    if getattr(cfg, "mid_block_type", "UNetMidBlock2DCrossAttn") is None:
+        mid = -1
+    else:
+        last = tl[-1]
+        mid = int(last) if isinstance(last, int) else int(last[-1])
+    return down, up, mid
+
+
+def unet_config_from_diffusers(d: dict, name: str = "from_json") -> UNetConfig:
+    """UNetConfig from a diffusers `unet/config.json` dict (what `UNet2DConditionModel.from_pretrained(model_id,
+    subfolder="unet")` reads, train_sdxl_zh.py:138,151 / tests/test_sdxl_zh.py:144-146)."""
+    def tup(v):
+        return tuple(tup(a) if isinstance(a, (list, tuple)) else a for a in v) if isinstance(v, (list, tuple)) else v
+    n = len(d["block_out_channels"])
+    heads = d.get("num_attention_heads") or d.get("attention_head_dim")
+    if isinstance(heads, int):
+        heads = (heads,) * n
+    tl = d.get("transformer_layers_per_block", 1)
+    if isinstance(tl, int):
+        tl = (tl,) * n
+    return UNetConfig(
+        in_channels=d.get("in_channels", 4), out_channels=d.get("out_channels", 4), sample_size=d.get("sample_size", 128),
+        block_out_channels=tuple(d["block_out_channels"]), down_block_types=tuple(d["down_block_types"]),
+        up_block_types=tuple(d["up_block_types"]), layers_per_block=d.get("layers_per_block", 2),
+        transformer_layers_per_block=tup(tl), reverse_transformer_layers_per_block=tup(d.get("reverse_transformer_layers_per_block")),
+        mid_block_type=d.get("mid_block_type", "UNetMidBlock2DCrossAttn"), num_attention_heads=tuple(heads),
+        cross_attention_dim=d.get("cross_attention_dim", 1280), use_linear_projection=bool(d.get("use_linear_projection", False)),
+        norm_num_groups=d.get("norm_num_groups", 32), norm_eps=d.get("norm_eps", 1e-5),
+        addition_embed_type=d.get("addition_embed_type"), addition_time_embed_dim=d.get("addition_time_embed_dim") or 0,
+        projection_class_embeddings_input_dim=d.get("projection_class_embeddings_input_dim") or 0, name=name)
 
 
 def sd15_config() -> UNetConfig:
@@ -75,7 +148,8 @@ class CUNetConfig(ctypes.Structure):
                 ("layers_per_block", ctypes.c_int), ("depth", ctypes.c_int * 4), ("heads", ctypes.c_int * 4),
                 ("cross_dim", ctypes.c_int), ("linear_proj", ctypes.c_int), ("groups", ctypes.c_int),
                 ("eps", ctypes.c_float), ("text_time", ctypes.c_int), ("add_time_dim", ctypes.c_int),
-                ("proj_in_dim", ctypes.c_int)]
+                ("proj_in_dim", ctypes.c_int), ("per_layer_depth", ctypes.c_int),
+                ("depth_down", (ctypes.c_int * 4) * 4), ("depth_up", (ctypes.c_int * 4) * 4), ("depth_mid", ctypes.c_int)]
 
 
 def to_c(cfg) -> CUNetConfig:
@@ -87,8 +161,15 @@ def to_c(cfg) -> CUNetConfig:
         c.block_out[i] = cfg.block_out_channels[i]
         c.down_cross[i] = int(cfg.down_block_types[i].startswith("CrossAttn"))
         c.up_cross[i] = int(cfg.up_block_types[i].startswith("CrossAttn"))
-        c.depth[i] = cfg.transformer_layers_per_block[i]
         c.heads[i] = cfg.num_attention_heads[i]
+    down, up, mid = depth_tables(cfg)
+    c.per_layer_depth, c.depth_mid = 1, mid
+    for i in range(n):
+        c.depth[i] = max(down[i])
+        for j, v in enumerate(down[i]):
+            c.depth_down[i][j] = v
+        for j, v in enumerate(up[i]):
+            c.depth_up[i][j] = v
     c.layers_per_block = cfg.layers_per_block
     c.cross_dim = cfg.cross_attention_dim
     c.linear_proj = int(cfg.use_linear_projection)

@@ -310,6 +310,17 @@ int pea_unet_forward(void* h, const float* x, const float* t, const void* ehs, i
   return ((Tape*)h)->forward(x, t, ehs, ehs_dtype, text, text_dtype, time_ids, eps_out, (hipStream_t)stream);
 }
 int pea_unet_num_taps(void* h) { return h ? (int)((Tape*)h)->taps.size() : 0; }
+int pea_unet_tap_name(void* h, int k, char* name, int name_len) {
+  NOTNULL(h, "pea_unet_tap_name");
+  NOTNULL(name, "pea_unet_tap_name");
+  Tape* u = (Tape*)h;
+  if (k < 0 || k >= (int)u->taps.size() || name_len < 2) {
+    pea_set_error("pea_unet_tap_name: tap %d out of range", k);
+    return PEA_E_INVALID;
+  }
+  snprintf(name, name_len, "%s", k < (int)u->tap_names.size() ? u->tap_names[k].c_str() : "");
+  return PEA_OK;
+}
 int pea_unet_tap_info(void* h, int k, void** data, void** grad, int* B, int* H, int* W, int* C) {
   NOTNULL(h, "pea_unet_tap_info");
   Tape* u = (Tape*)h;

@@ -26,7 +26,12 @@ struct PeaUnetCfg {          // mirrors `pea_unet_config` of include/pea_hip.h
   int text_time;             // addition_embed_type == "text_time"
   int add_time_dim;          // addition_time_embed_dim
   int proj_in_dim;           // projection_class_embeddings_input_dim
+  int per_layer_depth;       // 0: fill the arrays below from depth[] (normalize_depths)
+  int depth_down[4][4];      // transformer_layers_per_block[i][j] (down order, j < layers_per_block)
+  int depth_up[4][4];        // reverse_transformer_layers_per_block[i][j] (UP order, j <= layers_per_block)
+  int depth_mid;             // mid block transformer layers; -1: no mid block
 };
+void normalize_depths(PeaUnetCfg& c);
 
 struct PeaTextCfg {          // mirrors `pea_text_config` of include/pea_hip.h
   int vocab, max_pos, width, heads, layers, intermediate;
@@ -123,6 +128,7 @@ struct Tape {
   std::vector<Tn> tn;
   std::vector<Op> ops;
   std::vector<int> taps;          // tensor ids: d0.., m, u0..
+  std::vector<std::string> tap_names;   // "d0".., "m" (absent without a mid block), "u0"..
   int t_ehs = -1, t_text = -1, t_tproj = -1, t_out_in = -1, t_kvall = -1;
   int tproj_total = 0, kvall_total = 0, kv_nsplit = 1;
   float* kv_part = nullptr;
@@ -196,6 +202,7 @@ struct Trainer {
            const float* teacher_neg, const float* teacher_pooled, const float* time_ids, float grad_scale,
            float* grads, int accumulate, float* losses_out, hipStream_t s);
   float* t_f32 = nullptr;
+  std::vector<std::pair<int, int>> tap_pairs;   // (student tap, teacher tap) with the same hook name
   int two_stream = 1; hipStream_t side = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   // merged passes: when the teacher IS the student checkpoint (shared weights, reference default) both forwards run
   // as ONE pass over 2B samples (student rows first) and the backward differentiates the first B only

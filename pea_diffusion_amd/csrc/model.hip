@@ -249,16 +249,16 @@ std::vector<CrossAttnInfo> enumerate_cross_attn(const PeaUnetCfg& c, bool includ
     if (c.down_cross[i])
       for (int j = 0; j < c.layers_per_block; ++j) {
         cur_heads = c.heads[i];
-        add("down_blocks." + std::to_string(i) + ".attentions." + std::to_string(j), c.block_out[i], c.depth[i]);
+        add("down_blocks." + std::to_string(i) + ".attentions." + std::to_string(j), c.block_out[i], c.depth_down[i][j]);
       }
   cur_heads = c.heads[n - 1];
-  add("mid_block.attentions.0", c.block_out[n - 1], c.depth[n - 1]);
+  if (c.depth_mid >= 0) add("mid_block.attentions.0", c.block_out[n - 1], c.depth_mid);
   for (int i = 0; i < n && include_up; ++i)
     if (c.up_cross[i])
       for (int j = 0; j < c.layers_per_block + 1; ++j) {
         cur_heads = c.heads[n - 1 - i];
         add("up_blocks." + std::to_string(i) + ".attentions." + std::to_string(j), c.block_out[n - 1 - i],
-            c.depth[n - 1 - i]);
+            c.depth_up[i][j]);
       }
   return r;
 }
@@ -270,14 +270,29 @@ std::vector<std::pair<std::string, int>> enumerate_resnets(const PeaUnetCfg& c, 
   for (int i = 0; i < n; ++i)
     for (int j = 0; j < c.layers_per_block; ++j)
       r.push_back({"down_blocks." + std::to_string(i) + ".resnets." + std::to_string(j), c.block_out[i]});
-  r.push_back({"mid_block.resnets.0", c.block_out[n - 1]});
-  r.push_back({"mid_block.resnets.1", c.block_out[n - 1]});
+  if (c.depth_mid >= 0) {
+    r.push_back({"mid_block.resnets.0", c.block_out[n - 1]});
+    r.push_back({"mid_block.resnets.1", c.block_out[n - 1]});
+  }
   for (int i = 0; i < n && include_up; ++i)
     for (int j = 0; j < c.layers_per_block + 1; ++j)
       r.push_back({"up_blocks." + std::to_string(i) + ".resnets." + std::to_string(j), c.block_out[n - 1 - i]});
   return r;
 }
 }  // namespace
+
+// uniform per-level depths (depth[]) -> the per-position tables every builder reads
+void normalize_depths(PeaUnetCfg& c) {
+  if (c.per_layer_depth) return;
+  const int n = c.n_levels;
+  for (int i = 0; i < 4; ++i)
+    for (int j = 0; j < 4; ++j) {
+      c.depth_down[i][j] = i < n ? c.depth[i] : 0;
+      c.depth_up[i][j] = i < n ? c.depth[n - 1 - i] : 0;
+    }
+  c.depth_mid = n >= 1 ? c.depth[n - 1] : 0;
+  c.per_layer_depth = 1;
+}
 
 int Tape::build_vae_encoder() {
   const PeaUnetCfg& c = cfg;
@@ -432,8 +447,11 @@ int Tape::build() {
   if (graph == 4) return build_text();
   if (graph == 1) return build_vae_encoder();
   if (graph == 3) return build_vae_decoder();
+  normalize_depths(cfg);
   const PeaUnetCfg& c = cfg;
   SHAPECHK(c.n_levels >= 2 && c.n_levels <= 4, "unet: n_levels=%d", c.n_levels);
+  SHAPECHK(c.layers_per_block >= 1 && c.layers_per_block <= 3, "unet: layers_per_block=%d", c.layers_per_block);
+  SHAPECHK(c.depth_mid >= 0 || graph == 0, "controlnet: a mid block is required");
   for (int i = 0; i < c.n_levels; ++i) {
     SHAPECHK(c.block_out[i] % 64 == 0, "unet: block_out_channels[%d]=%d must be a multiple of 64", i, c.block_out[i]);
     if (c.down_cross[i] || c.up_cross[c.n_levels - 1 - i] || i == c.n_levels - 1)
@@ -533,7 +551,7 @@ int Tape::build() {
     const std::string p = "down_blocks." + std::to_string(i);
     for (int j = 0; j < c.layers_per_block; ++j) {
       x = bd.resnet(x, p + ".resnets." + std::to_string(j), c.block_out[i]);
-      if (c.down_cross[i]) x = bd.transformer(x, p + ".attentions." + std::to_string(j), c.heads[i], c.depth[i]);
+      if (c.down_cross[i]) x = bd.transformer(x, p + ".attentions." + std::to_string(j), c.heads[i], c.depth_down[i][j]);
       skips.push_back(x);
     }
     if (i != n - 1) {
@@ -541,6 +559,7 @@ int Tape::build() {
       skips.push_back(x);
     }
     taps.push_back(x);
+    tap_names.push_back("d" + std::to_string(i));
   }
   auto add_external = [&](int t) {              // t + (externally supplied residual, zero until set)
     const Tn& a = tn[t];
@@ -557,10 +576,13 @@ int Tape::build() {
     SHAPECHK(!needs_grad, "unet: residual inputs are an inference feature (no backward through them)");
     for (int& sk : skips) sk = add_external(sk);
   }
-  x = bd.resnet(x, "mid_block.resnets.0", c.block_out[n - 1]);
-  x = bd.transformer(x, "mid_block.attentions.0", c.heads[n - 1], c.depth[n - 1]);
-  x = bd.resnet(x, "mid_block.resnets.1", c.block_out[n - 1]);
-  taps.push_back(x);
+  if (c.depth_mid >= 0) {                       // mid_block_type == null (SSD-1B-style pruned UNets): no mid block at all
+    x = bd.resnet(x, "mid_block.resnets.0", c.block_out[n - 1]);
+    x = bd.transformer(x, "mid_block.attentions.0", c.heads[n - 1], c.depth_mid);
+    x = bd.resnet(x, "mid_block.resnets.1", c.block_out[n - 1]);
+    taps.push_back(x);
+    tap_names.push_back("m");
+  }
   if (residual_inputs) x = add_external(x);     // mid_block_additional_residual (:535)
   if (graph == 2) {
     // zero-convs: one 1x1 conv per skip tensor and one for the mid block; their outputs ARE the residuals
@@ -578,10 +600,11 @@ int Tape::build() {
       skips.pop_back();
       x = bd.concat(x, sk);
       x = bd.resnet(x, p + ".resnets." + std::to_string(j), c.block_out[lvl]);
-      if (c.up_cross[i]) x = bd.transformer(x, p + ".attentions." + std::to_string(j), c.heads[lvl], c.depth[lvl]);
+      if (c.up_cross[i]) x = bd.transformer(x, p + ".attentions." + std::to_string(j), c.heads[lvl], c.depth_up[i][j]);
     }
     if (i != n - 1) x = bd.conv(x, p + ".upsamplers.0.conv", c.block_out[lvl], 1, 1);
     taps.push_back(x);
+    tap_names.push_back("u" + std::to_string(i));
   }
   SHAPECHK(skips.empty(), "unet: skip stack not consumed (%d left)", (int)skips.size());
   SHAPECHK(bd.kv_off == kvall_total, "unet: stacked K|V projection layout mismatch (%d vs %d)", bd.kv_off, kvall_total);
@@ -1322,10 +1345,25 @@ int Trainer::prepare() {
   Tape& Tt = *teacher;
   SHAPECHK(S.needs_grad, "trainer: student context needs gradient support");
   SHAPECHK(S.B == Tt.B && S.H == Tt.H && S.W == Tt.W, "trainer: student/teacher shapes differ");
-  SHAPECHK(S.taps.size() == Tt.taps.size(), "trainer: tap counts differ");
-  for (size_t k = 0; k < S.taps.size(); ++k)
-    SHAPECHK(S.tn[S.taps[k]].rows == Tt.tn[Tt.taps[k]].rows && S.tn[S.taps[k]].cols == Tt.tn[Tt.taps[k]].cols,
-             "trainer: tap %d shapes differ", (int)k);
+  // feature taps are paired by hook name (d0.., m, u0..: cast_hook, train_sdxl_zh.py:79-84).  A student without a mid
+  // block (SSD-1B-style, mid_block_type null) has no 'm' tap: that term leaves the feature loss (the reference's
+  // cast_hook would fail on `unet.mid_block is None`; every other tap must exist on both sides).
+  tap_pairs.clear();
+  for (size_t k = 0; k < S.taps.size(); ++k) {
+    int found = -1;
+    for (size_t j = 0; j < Tt.taps.size(); ++j)
+      if (Tt.tap_names[j] == S.tap_names[k]) found = (int)j;
+    SHAPECHK(found >= 0, "trainer: the teacher has no '%s' tap", S.tap_names[k].c_str());
+    SHAPECHK(S.tn[S.taps[k]].rows == Tt.tn[Tt.taps[found]].rows && S.tn[S.taps[k]].cols == Tt.tn[Tt.taps[found]].cols,
+             "trainer: tap '%s' shapes differ", S.tap_names[k].c_str());
+    tap_pairs.push_back({(int)k, found});
+  }
+  for (size_t j = 0; j < Tt.taps.size(); ++j) {
+    bool used = false;
+    for (auto& pr : tap_pairs) used = used || pr.second == (int)j;
+    SHAPECHK(used || Tt.tap_names[j] == "m", "trainer: the student has no '%s' tap", Tt.tap_names[j].c_str());
+  }
+  SHAPECHK(tap_pairs.size() <= 9, "trainer: %d taps", (int)tap_pairs.size());
   SHAPECHK(ad->B2 == 2 * S.B && ad->L == S.L, "trainer: adapter prepared for %d x %d, need %d x %d", ad->B2, ad->L,
            2 * S.B, S.L);
   const int tok_dim = ad->out1 ? ad->out1 : ad->out_dim;
@@ -1339,7 +1377,7 @@ int Trainer::prepare() {
   HIPCHK(hipMalloc((void**)&losses, 16));
   {
     std::vector<long long> per;
-    for (int tid_ : S.taps) per.push_back(S.tn[tid_].rows / S.B * S.tn[tid_].cols);
+    for (auto& pr : tap_pairs) per.push_back(S.tn[S.taps[pr.first]].rows / S.B * S.tn[S.taps[pr.first]].cols);
     HIPCHK(hipMalloc((void**)&kd_ws, kd_loss_workspace_bytes((int)per.size(), per.data(), (long long)S.cfg.in_channels * S.H * S.W, S.B)));
   }
   HIPCHK(hipMalloc((void**)&tehs_c, (size_t)Tt.B * Tt.L * Tt.cfg.cross_dim * 2));
@@ -1440,11 +1478,11 @@ int Trainer::step(const float* latents, const float* noise, const long long* tim
   // fused KD loss + seeds; :399-441
   KdLossP kp;
   memset(&kp, 0, sizeof(kp));
-  kp.ntaps = (int)S.taps.size();
+  kp.ntaps = (int)tap_pairs.size();
   S.begin_backward();
   for (int k = 0; k < kp.ntaps; ++k) {
-    Tn& ts = S.tn[S.taps[k]];
-    kp.fs[k] = ts.d; kp.ft[k] = Tt.tn[Tt.taps[k]].d; kp.dfs[k] = ts.g;
+    Tn& ts = S.tn[S.taps[tap_pairs[k].first]];
+    kp.fs[k] = ts.d; kp.ft[k] = Tt.tn[Tt.taps[tap_pairs[k].second]].d; kp.dfs[k] = ts.g;
     kp.per[k] = ts.rows / B * ts.cols;
     ts.gw = true;
   }

@@ -64,10 +64,17 @@ class HipUNet:
             check(lib().pea_unet_share_weights(self._h, share_weights_from._h))
             self._weights_owner = share_weights_from      # keep alive
         n = len(cfg.block_out_channels)
-        self.down_blocks = [_BlockShim(f"d{i}", i, True) for i in range(n)]
-        self.mid_block = _BlockShim("m", n, False)
-        self.up_blocks = [_BlockShim(f"u{i}", n + 1 + i, False) for i in range(n)]
         self.num_taps = lib().pea_unet_num_taps(self._h)
+        nm = ctypes.create_string_buffer(16)
+        self.tap_names = []
+        for k in range(self.num_taps):
+            check(lib().pea_unet_tap_name(self._h, k, nm, 16))
+            self.tap_names.append(nm.value.decode())
+        idx = {name: k for k, name in enumerate(self.tap_names)}
+        self.down_blocks = [_BlockShim(f"d{i}", idx[f"d{i}"], True) for i in range(n)]
+        # `mid_block_type: null` configs (SSD-1B) have no mid block: diffusers sets `unet.mid_block = None`
+        self.mid_block = _BlockShim("m", idx["m"], False) if "m" in idx else None
+        self.up_blocks = [_BlockShim(f"u{i}", idx[f"u{i}"], False) for i in range(n)]
 
     def __del__(self):
         try:

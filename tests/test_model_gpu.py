@@ -550,7 +550,7 @@ def test_sd15_shaped_step_tiny(gpu):
 def test_sd15_full_size_step_vs_oracle(gpu):
     """BASELINE configs[0]: SD1.5 512x512 (batch 2 so that both mask values occur) -- full 859.5 M-parameter UNet, the whole KD step on the MI355X
     against the fp32 CPU oracle (train_sd_zh.py path; head dims 40/80/160)"""
-    _sd15_step_check("sd15_config", B=2, L=77, hw=64, enc_dim=1024, hidden=2048, tol_fwd=3e-2, tol_grad=6e-2)
+    _sd15_step_check("sd15_config", B=2, L=77, hw=64, enc_dim=1024, hidden=2048, tol_fwd=2e-2, tol_grad=6e-3)   # measured grad 2.1e-3
 
 
 def _fast_fill_(module, seed=0):
@@ -624,7 +624,7 @@ def test_sdxl_full_model_step_vs_oracle_512(gpu):
     ref["loss"].backward()
     e_s, e_t = rel_l2(tr.export("eps_student"), ref["noise_pred"]), rel_l2(tr.export("eps_teacher"), ref["noise_pred_teacher"])
     print(f"[sdxl full model 512x512 step] eps_student rel_l2={e_s:.3e} eps_teacher rel_l2={e_t:.3e}")
-    assert e_s < 3e-2 and e_t < 3e-2
+    assert e_s < 1.5e-2 and e_t < 1.5e-2            # measured 7.0e-3
     total = abs(float(ref["loss"]))
     for k in tr.LOG_KEYS:
         h, r = float(out[k]), float(ref[k])
@@ -633,4 +633,4 @@ def test_sdxl_full_model_step_vs_oracle_512(gpu):
     g_ref = torch.cat([p.grad.reshape(-1) for p in ad_ref.parameters()])
     eg = rel_l2(ad.flat_grad, g_ref)
     print(f"   adapter grad rel_l2={eg:.3e} |ref|={g_ref.norm():.3e}")
-    assert eg < 6e-2
+    assert eg < 2e-2                                # measured 8.1e-3

@@ -153,3 +153,38 @@ def test_kd_loss_nan_guard_and_masks():
     _, _, _, l2g = kd_losses(a, b, c, fs, ft, zh, nan_guard=True)
     _, _, _, l2_first = kd_losses(a, b, c, fs[:1], ft[:1], zh)
     assert abs(float(l2g) - float(l2_first)) < 1e-7
+
+
+def test_ssd1b_layout_known_answers_and_config_json():
+    """BASELINE config 4 / tests/test_sdxl_zh.py:449-454 (SSD-1B as the downstream UNet): per-position transformer depths,
+    a reverse (up-path) list and no mid block.  Known answers: the model card's 1.3 B parameters; the diffusers rule for
+    the depth tables; the product's config reader agrees with the oracle's on the same `config.json` dictionary."""
+    from oracle.unet_ref import ssd1b_config, tap_names
+    from pea_diffusion_amd import config as pc
+    assert count_params_analytic(ssd1b_config()) == 1_300_195_844
+    assert tap_names(ssd1b_config()) == ["d0", "d1", "d2", "u0", "u1", "u2"]
+    js = {"block_out_channels": [320, 640, 1280], "down_block_types": ["DownBlock2D", "CrossAttnDownBlock2D", "CrossAttnDownBlock2D"],
+          "up_block_types": ["CrossAttnUpBlock2D", "CrossAttnUpBlock2D", "UpBlock2D"], "layers_per_block": 2,
+          "transformer_layers_per_block": [1, [2, 2], [4, 4]], "reverse_transformer_layers_per_block": [[4, 4, 10], [2, 1, 1], 1],
+          "mid_block_type": None, "attention_head_dim": [5, 10, 20], "cross_attention_dim": 2048, "use_linear_projection": True,
+          "addition_embed_type": "text_time", "addition_time_embed_dim": 256, "projection_class_embeddings_input_dim": 2816,
+          "sample_size": 128, "in_channels": 4, "out_channels": 4, "norm_num_groups": 32, "norm_eps": 1e-5}
+    c = pc.unet_config_from_diffusers(js)
+    assert pc.depth_tables(c) == ([[1, 1], [2, 2], [4, 4]], [[4, 4, 10], [2, 1, 1], [1, 1, 1]], -1)
+    assert pc.depth_tables(pc.ssd1b_config()) == pc.depth_tables(c)
+    cc = pc.to_c(c)
+    assert cc.per_layer_depth == 1 and cc.depth_mid == -1 and [cc.depth_up[0][j] for j in range(3)] == [4, 4, 10]
+    # uniform configs: ints broadcast, the up path mirrors the down path, the mid block takes the last entry
+    assert pc.depth_tables(pc.sdxl_config()) == ([[1, 1], [2, 2], [10, 10]], [[10, 10, 10], [2, 2, 2], [1, 1, 1]], 10)
+    sd = dict(js, transformer_layers_per_block=[1, 2, 10], reverse_transformer_layers_per_block=None,
+              mid_block_type="UNetMidBlock2DCrossAttn")
+    assert pc.depth_tables(pc.unet_config_from_diffusers(sd)) == pc.depth_tables(pc.sdxl_config())
+    with pytest.raises(ValueError):
+        pc.depth_tables(pc.unet_config_from_diffusers(dict(js, reverse_transformer_layers_per_block=None)))
+    # the oracle built from the same nested config has exactly the per-position stacks
+    with torch.device("meta"):
+        m = UNet2DConditionRef(ssd1b_config())
+    assert m.mid_block is None
+    assert [len(a.transformer_blocks) for a in m.up_blocks[0].attentions] == [4, 4, 10]
+    assert [len(a.transformer_blocks) for a in m.up_blocks[1].attentions] == [2, 1, 1]
+    assert [len(a.transformer_blocks) for a in m.down_blocks[2].attentions] == [4, 4]
