@@ -181,6 +181,11 @@ typedef struct pea_unet_config {
 #define PEA_UNET_RESIDUAL_INPUTS 2
 int pea_unet_create(const pea_unet_config* cfg, int B, int H, int W, int L, int flags, int own_weights,
                     void** out);
+/* Host-only planning pass of pea_unet_create (no device needed, nothing allocated): builds the op tape for the same
+ * arguments and reports its size -- ops, weight tensors, parameters (torch numel), and the bytes the weight / activation
+ * / gradient arenas will take in HBM.  Use it to size a configuration against 288 GB before creating it.   */
+int pea_unet_plan(const pea_unet_config* cfg, int B, int H, int W, int L, int flags, int* n_ops, int* n_weights,
+                  long long* n_params, long long* weight_bytes, long long* act_bytes, long long* grad_bytes);
 /* ControlNet extras of the UNet call (tests/test_sdxl_zh_controlnet.py:534-535): `down_block_additional_residuals`
  * (conv_in output, then every down-block resnet/attention output and downsampler output, in diffusers order) followed
  * by `mid_block_additional_residual` LAST.  ptrs: HOST array of n device pointers ([B,C,H,W]; NULL entry = zero);

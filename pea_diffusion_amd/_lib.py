@@ -79,6 +79,10 @@ def lib() -> ctypes.CDLL:
         if not os.path.exists(LIB_PATH):
             raise PeaError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                            "(there is no CPU fallback for the HIP path)")
+        # torch ships its own libamdhip64 / librccl: importing it FIRST makes libpea_hip.so bind to that one copy.  Loaded
+        # the other way round (ROCm's runtime first, torch's second) the process holds two HIP runtimes and the second to
+        # initialise sees no device.
+        import torch  # noqa: F401
         L = ctypes.CDLL(LIB_PATH)
         for name, (restype, argtypes) in parse_header().items():
             fn = getattr(L, name)          # AttributeError if the library lacks a declared symbol

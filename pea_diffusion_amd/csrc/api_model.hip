@@ -52,6 +52,26 @@ int pea_unet_create(const pea_unet_config* cfg, int B, int H, int W, int L, int 
   u->owns_weights = own_weights != 0;
   return finish_create(u, out);
 }
+int pea_unet_plan(const pea_unet_config* cfg, int B, int H, int W, int L, int flags, int* n_ops, int* n_weights,
+                  long long* n_params, long long* weight_bytes, long long* act_bytes, long long* grad_bytes) {
+  NOTNULL(cfg, "pea_unet_plan");
+  Tape u;
+  memcpy(&u.cfg, cfg, sizeof(PeaUnetCfg));
+  u.B = B; u.H = H; u.W = W; u.L = L; u.needs_grad = (flags & 1) != 0; u.residual_inputs = (flags & 2) != 0;
+  u.plan_only = true;
+  int rc = u.build();
+  if (rc == PEA_OK) rc = u.alloc();
+  if (rc != PEA_OK) return rc;
+  long long np = 0;
+  for (const WSlot& s : u.slots) np += s.numel;
+  if (n_ops) *n_ops = (int)u.ops.size();
+  if (n_weights) *n_weights = (int)u.slots.size();
+  if (n_params) *n_params = np;
+  if (weight_bytes) *weight_bytes = (long long)u.wbytes;
+  if (act_bytes) *act_bytes = (long long)u.abytes;
+  if (grad_bytes) *grad_bytes = (long long)u.gbytes;
+  return PEA_OK;
+}
 int pea_controlnet_create(const pea_unet_config* cfg, int B, int H, int W, int L, void** out) {
   NOTNULL(cfg, "pea_controlnet_create");
   NOTNULL(out, "pea_controlnet_create");

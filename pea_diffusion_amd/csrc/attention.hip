@@ -245,6 +245,7 @@ __global__ __launch_bounds__(256, (ND == 1 ? (MODE == 0 ? (TXT ? 3 : 4) : 2) : 1
       m_run = m_new;
     } else {
       // P^T = exp2(c S^T - lse2[q]);  dP^T = V . dO^T;  dS^T = P^T (dP^T - delta[q]) scale
+      const int skv_b = p.kv_len ? p.kv_len[b] : p.Skv;          // per-sample valid keys (padded contexts)
       f32x16 dpacc[2];
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb) {
@@ -264,7 +265,7 @@ __global__ __launch_bounds__(256, (ND == 1 ? (MODE == 0 ? (TXT ? 3 : 4) : 2) : 1
         for (int r = 0; r < 16; ++r) {
           const int key = kv0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
           float pr = fast_exp2(fmaf(sacc[kb][r], c, -lse2));
-          if (kv0 + 64 > p.Skv) pr = key < p.Skv ? pr : 0.f;      // uniform branch: only the last key tile masks
+          if (kv0 + 64 > skv_b) pr = key < skv_b ? pr : 0.f;      // uniform branch: only tiles holding masked keys
           sacc[kb][r] = pr * (dpacc[kb][r] - dlt) * p.scale;
         }
     }
@@ -356,8 +357,10 @@ __global__ __launch_bounds__(256, (ND == 1 ? 2 : 1)) void attn_dkv_kernel(const 
   const float* dltb = p.delta + ((long long)b * p.H + head) * p.Sq;
 
   int krow = k0 + frow;
-  const bool kvalid = krow < p.Skv;
-  krow = kvalid ? krow : p.Skv - 1;
+  const bool kstored = krow < p.Skv;          // the row exists in K / V / dK / dV
+  const int skv_b = p.kv_len ? p.kv_len[b] : p.Skv;   // keys >= skv_b are padding: P = 0, so their dK = dV = 0
+  const bool kvalid = krow < skv_b;
+  krow = kstored ? krow : p.Skv - 1;
   const bool wave_active = k0 < p.Skv;       // wave-uniform
   bf16x8 kf[ND][4], vf[ND][4];
 #pragma unroll
@@ -450,7 +453,7 @@ __global__ __launch_bounds__(256, (ND == 1 ? 2 : 1)) void attn_dkv_kernel(const 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
   }
-  if (!kvalid) return;
+  if (!kstored) return;
   const int D = 64 * ND;
   if (p.nsplit > 1) {
     float* pr = p.dkv_part + ((((long long)split * p.B + b) * p.H + head) * p.Skv + krow) * 2 * D + chunk * 64;

@@ -313,19 +313,24 @@ int launch_add_noise(const float* x0, const float* eps, const long long* t, cons
 }
 
 // ---- CFG-dropout row select and its backward (train_sdxl_zh.py:395)
+// ystride8 / dystride8: per-sample stride (in 8-element groups) of y / dy; >= per8 when the consumer's tensor holds more
+// tokens per sample than the adapter produced (merged passes with a shorter student context: the tail stays zero)
 __global__ void select_rows_kernel(const bf16* __restrict__ c, const bf16* __restrict__ u,
                                    const unsigned char* __restrict__ mask, bf16* __restrict__ y, int B,
-                                   long long per8) {
+                                   long long per8, long long ystride8) {
   EW_LOOP(i, (long long)B * per8) {
     const int b = (int)(i / per8);
-    *(bf16x8*)(y + i * 8) = mask[b] ? *(const bf16x8*)(u + i * 8) : *(const bf16x8*)(c + i * 8);
+    const long long o = (long long)b * ystride8 + (i - (long long)b * per8);
+    *(bf16x8*)(y + o * 8) = mask[b] ? *(const bf16x8*)(u + i * 8) : *(const bf16x8*)(c + i * 8);
   }
 }
 __global__ void select_rows_bwd_kernel(const bf16* __restrict__ dy, const unsigned char* __restrict__ mask,
-                                       bf16* __restrict__ dc, bf16* __restrict__ du, int B, long long per8) {
+                                       bf16* __restrict__ dc, bf16* __restrict__ du, int B, long long per8,
+                                       long long dystride8) {
   EW_LOOP(i, (long long)B * per8) {
     const int b = (int)(i / per8);
-    const bf16x8 v = *(const bf16x8*)(dy + i * 8);
+    const long long o = (long long)b * dystride8 + (i - (long long)b * per8);
+    const bf16x8 v = *(const bf16x8*)(dy + o * 8);
     bf16x8 z;
 #pragma unroll
     for (int j = 0; j < 8; ++j) z[j] = (bf16)0.f;
@@ -334,17 +339,19 @@ __global__ void select_rows_bwd_kernel(const bf16* __restrict__ dy, const unsign
   }
 }
 int launch_select_rows(const bf16* c, const bf16* u, const unsigned char* mask, bf16* y, int B, long long per,
-                       hipStream_t s) {
-  SHAPECHK(per % 8 == 0, "select: per %% 8");
-  hipLaunchKernelGGL(select_rows_kernel, dim3(EW_GRID(B * per / 8)), dim3(256), 0, s, c, u, mask, y, B, per / 8);
+                       hipStream_t s, long long ystride) {
+  if (ystride <= 0) ystride = per;
+  SHAPECHK(per % 8 == 0 && ystride % 8 == 0 && ystride >= per, "select: per %% 8");
+  hipLaunchKernelGGL(select_rows_kernel, dim3(EW_GRID(B * per / 8)), dim3(256), 0, s, c, u, mask, y, B, per / 8, ystride / 8);
   HIPCHK(hipGetLastError());
   return PEA_OK;
 }
 int launch_select_rows_bwd(const bf16* dy, const unsigned char* mask, bf16* dc, bf16* du, int B, long long per,
-                           hipStream_t s) {
-  SHAPECHK(per % 8 == 0, "select: per %% 8");
+                           hipStream_t s, long long dystride) {
+  if (dystride <= 0) dystride = per;
+  SHAPECHK(per % 8 == 0 && dystride % 8 == 0 && dystride >= per, "select: per %% 8");
   hipLaunchKernelGGL(select_rows_bwd_kernel, dim3(EW_GRID(B * per / 8)), dim3(256), 0, s, dy, mask, dc, du, B,
-                     per / 8);
+                     per / 8, dystride / 8);
   HIPCHK(hipGetLastError());
   return PEA_OK;
 }

@@ -135,6 +135,7 @@ struct Tape {
   bf16* geglu_tmp = nullptr;
   // arenas
   char* warena = nullptr; size_t wbytes = 0; bool owns_weights = true;
+  bool plan_only = false;          // alloc() computes the layout (wbytes / abytes / gbytes) without touching the device
   char* aarena = nullptr; size_t abytes = 0;
   char* garena = nullptr; size_t gbytes = 0;
   // scratch
@@ -154,6 +155,8 @@ struct Tape {
   int t_final = -1, t_pooled = -1;
   const long long* ids_in = nullptr;
   int* kvlen = nullptr;              // graph 4 (BERT): per-sample valid token count
+  int* cross_kvlen = nullptr;        // graph 0: per-sample valid context tokens of the cross-attention (merged passes with a shorter
+                                     // student context; rows beyond it in t_ehs are zero padding), null = all L
   int exec_ops(size_t begin, size_t end, bool skip_cached, hipStream_t s);
   int ensure_acts();                 // lazy allocation of the activation / gradient arenas and scratch
   int alloc();

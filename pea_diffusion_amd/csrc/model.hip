@@ -652,6 +652,7 @@ int Tape::alloc() {
       }
     }
     wbytes = off;
+    if (!plan_only) {
     HIPCHK(hipMalloc((void**)&warena, wbytes));
     for (FusedMat& f : fused) {
       f.w = (bf16*)(warena + f.off_w);
@@ -680,6 +681,7 @@ int Tape::alloc() {
     }
     tmp_f32_elems = max_numel;
     HIPCHK(hipMalloc((void**)&tmp_f32, tmp_f32_elems * 4));
+    }
   }
   // ---- activations (+ per-op aux), gradients
   size_t ao = 0, go = 0;
@@ -771,6 +773,7 @@ Tape::~Tape() {
   if (am_vt) hipFree(am_vt);
   if (vae_h) hipFree(vae_h);
   if (kvlen) hipFree(kvlen);
+  if (cross_kvlen) hipFree(cross_kvlen);
 }
 
 int Tape::load_weight(const char* name, const float* src, long long numel, hipStream_t s) {
@@ -1000,6 +1003,7 @@ int Tape::exec_ops(size_t begin, size_t end, bool skip_cached, hipStream_t s) {
         p.V = tn[o.c].d + o.ccol; p.ldv = tn[o.c].cols; p.O = tn[o.out].d; p.ldo = tn[o.out].cols; p.lse = o.aux;
         p.B = B; p.H = o.p0; p.Sq = o.p1; p.Skv = o.p2; p.scale = o.f0; p.nd = o.p3;
         p.causal = o.mask & 1; p.kv_len = (o.mask & 2) ? kvlen : nullptr;
+        if (cross_kvlen && o.b == t_kvall) p.kv_len = cross_kvlen;
         RC(launch_attention_fwd(p, s));
         break;
       }
@@ -1121,6 +1125,15 @@ int Tape::backward(const float* deps, hipStream_t s) {
       }
       case OP_CONCAT: {
         Tn &a = tn[o.a], &b = tn[o.b];
+        if (o.a == o.b) {                 // cat(x, x): a UNet without a mid block feeds the last down output to the first
+          if (a.rg) {                     // up resnet both as hidden state and as skip -> two ordered passes into one buffer
+            RC(materialize(a));
+            RC(launch_split2(out.g, a.cols, b.cols, a.g, a.gw, nullptr, false, rb(a), s));
+            RC(launch_split2(out.g, a.cols, b.cols, nullptr, false, a.g, true, rb(a), s));
+            a.gw = true;
+          }
+          break;
+        }
         if (a.rg) RC(materialize(a));
         if (b.rg) RC(materialize(b));
         RC(launch_split2(out.g, a.cols, b.cols, a.rg ? a.g : nullptr, a.gw, b.rg ? b.g : nullptr, b.gw, rb(a), s));
@@ -1179,6 +1192,7 @@ int Tape::backward(const float* deps, hipStream_t s) {
         p.O = out.d; p.ldo = out.cols; p.lse = o.aux; p.B = Bb; p.H = o.p0; p.Sq = o.p1; p.Skv = o.p2; p.scale = o.f0;
         p.nd = o.p3;
         p.dO = out.g; p.lddo = out.cols; p.delta = delta; p.dkv_part = attn_part;
+        if (cross_kvlen && o.b == t_kvall) p.kv_len = cross_kvlen;
         SHAPECHK(!q.gw && !q.gpend && !k.gpend && (!k.gw || o.b == t_kvall), "unet: attention operand gradient written twice");
         if (q.rg) { p.dQ = q.g + o.acol; p.lddq = q.cols; }
         if (k.rg) { p.dK = k.g + o.bcol; p.lddk = k.cols; p.dV = v.g + o.ccol; p.lddv = v.cols; }
@@ -1417,7 +1431,15 @@ int Trainer::step(const float* latents, const float* noise, const long long* tim
     // the same model_path) and both see the same context length
     // (merge_passes 1: only for per-GPU batches <= 4, where doubling the rows pays more than the two-stream overlap --
     // measured 32.4 vs 32.1 images/s at B = 4 and 34.7 vs 35.8 at B = 8; 2: always when eligible)
-    bool ok = (merge_passes >= 2 || B <= 4) && !Tt.owns_weights && Tt.slots.size() == S.slots.size() && S.L == Tt.L &&
+    // A student context shorter than the teacher's (the reference's default: Chinese-CLIP emits 52 tokens,
+    // utils/custom_dataset_sdxl.py:352-353, the teacher's CLIP towers 77) merges too: the merged context is Tt.L tokens
+    // long, the student rows carry S.L tokens + zero padding and a per-sample key count masks the padding in the
+    // cross-attention forward / backward kernels (head_dim 64 instances only).
+    bool all_nd1 = true;
+    for (const Op& o : S.ops)
+      if (o.kind == OP_ATTN && o.p3 != 1) all_nd1 = false;
+    bool ok = (merge_passes >= 2 || B <= 4) && !Tt.owns_weights && Tt.slots.size() == S.slots.size() &&
+              (S.L == Tt.L || (S.L < Tt.L && all_nd1)) &&
               S.graph == 0 && Tt.graph == 0 &&
               memcmp(&S.cfg, &Tt.cfg, sizeof(PeaUnetCfg)) == 0;
     for (size_t i = 0; ok && i < S.slots.size(); ++i)
@@ -1426,11 +1448,18 @@ int Trainer::step(const float* latents, const float* noise, const long long* tim
     if (ok) {
       merged = new Tape();
       merged->cfg = S.cfg;
-      merged->B = 2 * B; merged->H = S.H; merged->W = S.W; merged->L = S.L;
+      merged->B = 2 * B; merged->H = S.H; merged->W = S.W; merged->L = Tt.L;
       merged->needs_grad = true; merged->owns_weights = false; merged->bwd_batch = B;
       RC(merged->build());
       RC(merged->share_weights_from(S));
       RC(merged->alloc());
+      if (S.L != Tt.L) {
+        std::vector<int> kl(2 * B, Tt.L);
+        for (int i = 0; i < B; ++i) kl[i] = S.L;
+        HIPCHK(hipMalloc((void**)&merged->cross_kvlen, sizeof(int) * 2 * B));
+        HIPCHK(hipMemcpy(merged->cross_kvlen, kl.data(), sizeof(int) * 2 * B, hipMemcpyHostToDevice));
+        merged->tn[merged->t_ehs].zero_init = true;     // the padding rows of the student samples stay zero
+      }
       const size_t n = (size_t)B * S.cfg.in_channels * S.H * S.W;
       HIPCHK(hipMalloc((void**)&xt2, 2 * n * 4));
       HIPCHK(hipMalloc((void**)&eps2, 2 * n * 4));
@@ -1533,16 +1562,18 @@ int Trainer::step_merged(const float* latents, const float* noise, const long lo
     HIPCHK(hipMemcpyAsync(tid2, time_ids, (size_t)B * 6 * 4, hipMemcpyDeviceToDevice, s));
     HIPCHK(hipMemcpyAsync(tid2 + B * 6, time_ids, (size_t)B * 6 * 4, hipMemcpyDeviceToDevice, s));
   }
-  const long long per_tok = (long long)M.L * M.cfg.cross_dim;
+  const long long per_tok = (long long)M.L * M.cfg.cross_dim;               // merged context: the teacher's length
+  const long long per_stok = (long long)student->L * M.cfg.cross_dim;       // tokens the adapter emits per sample
   Tn& ehs = M.tn[M.t_ehs];
   // teacher rows: where(prompt_mask, negative, prompt) (:413)
   RC(launch_cast_f32_bf16(teacher_ehs, tehs_c, B * per_tok, s));
   RC(launch_cast_f32_bf16(teacher_neg, tehs_n, B * per_tok, s));
   RC(launch_select_rows(tehs_c, tehs_n, prompt_mask, ehs.d + B * per_tok, B, per_tok, s));
-  // student rows: adapter on (cond | uncond), CFG-dropout select (:383-395)
+  // student rows: adapter on (cond | uncond), CFG-dropout select (:383-395); a shorter student context leaves the
+  // sample's tail rows at their zero padding (masked by Tape::cross_kvlen)
   RC(A.forward(enc, enc_uncond, 0, s));
   const bf16* tokens = A.out1 ? A.tok : A.z2;
-  RC(launch_select_rows(tokens, tokens + B * per_tok, prompt_mask, ehs.d, B, per_tok, s));
+  RC(launch_select_rows(tokens, tokens + B * per_stok, prompt_mask, ehs.d, B, per_stok, s, per_tok));
   const void* text = nullptr;
   if (M.t_text >= 0) {
     Tn& q = M.tn[M.t_text];
@@ -1570,7 +1601,7 @@ int Trainer::step_merged(const float* latents, const float* noise, const long lo
   RC(M.backward(deps, s));
   SHAPECHK(ehs.gw, "trainer: no gradient reached encoder_hidden_states");
   bf16* dtokens = A.out1 ? A.dtok : A.dz2;
-  RC(launch_select_rows_bwd(ehs.g, prompt_mask, dtokens, dtokens + B * per_tok, B, per_tok, s));
+  RC(launch_select_rows_bwd(ehs.g, prompt_mask, dtokens, dtokens + B * per_stok, B, per_stok, s, per_tok));
   if (A.out1) {
     HIPCHK(hipMemsetAsync(A.dpool, 0, (size_t)A.B2 * A.out_dim * 2, s));
     if (M.t_text >= 0 && M.tn[M.t_text].gw)

@@ -82,7 +82,7 @@ struct AttnP {
   int nd;                          // padded head_dim / 64 (0 is read as 1)
   int xcd_remap;                   // set by the launchers: XCD-aware workgroup order
   int causal;                      // forward only: key index <= query index (text encoders)
-  const int* kv_len;               // forward only: per-sample number of valid keys (key padding mask), may be null
+  const int* kv_len;               // per-sample number of valid keys (key padding mask; forward and backward), may be null
 };
 int attention_bwd_nsplit(int B, int H, int Sq, int Skv);
 size_t attention_bwd_scratch_bytes(int B, int H, int Sq, int Skv, int nd = 1);
@@ -119,11 +119,12 @@ int launch_timestep_embed(const float* t, bf16* y, int n, int dim, hipStream_t s
 int launch_add_noise(const float* x0, const float* eps, const long long* t, const float* ac, float* xt, int B,
                      long long per, hipStream_t s);
 // y[b] = mask[b] ? u[b] : c[b]  rows of `per` bf16
+// (ystride: elements between consecutive samples of y, 0 = per; > per leaves each sample's tail untouched)
 int launch_select_rows(const bf16* c, const bf16* u, const unsigned char* mask, bf16* y, int B, long long per,
-                       hipStream_t s);
+                       hipStream_t s, long long ystride = 0);
 // backward of select: dc[b] = mask? 0 : dy[b]; du[b] = mask ? dy[b] : 0
 int launch_select_rows_bwd(const bf16* dy, const unsigned char* mask, bf16* dc, bf16* du, int B, long long per,
-                           hipStream_t s);
+                           hipStream_t s, long long dystride = 0);
 // mean over tokens: y[b][c] = mean_l x[b][l][c];  bwd: dx[b][l][c] (+)= dy[b][c]/L
 int launch_mean_tokens(const bf16* x, bf16* y, int B, int L, int C, hipStream_t s);
 int launch_mean_tokens_bwd(const bf16* dy, bf16* dx, int B, int L, int C, int accum, hipStream_t s);

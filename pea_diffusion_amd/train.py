@@ -96,6 +96,21 @@ class PEATrainer:
             torch.cuda.synchronize()
         return out
 
+    def attach_frontend(self, frontend):
+        """`PEAFrontEnd` (frozen VAE + teacher CLIP towers + student text tower) for training_step_from_batch"""
+        self.frontend = frontend
+
+    def training_step_from_batch(self, batch: Dict, batch_idx: int = 0, generator: Optional[torch.Generator] = None,
+                                 sync: bool = False):
+        """`training_step(self, batch, batch_idx)` on the dataloader's own dictionary (utils/custom_dataset_sdxl.py:397-407:
+        pixel_values, input_ids, input_ids_uncond, original_size, crops_coords_top_left, bucket_id, zh_or_not, texts_en):
+        VAE encode, the three text towers, add_time_ids from BUCKETS, the random draws, then the KD step
+        (train_sdxl_zh.py:305-449)."""
+        fe = getattr(self, "frontend", None)
+        if fe is None:
+            raise PeaError("training_step_from_batch: attach_frontend(PEAFrontEnd(...)) first")
+        return self.training_step(fe.prepare(batch, generator=generator), batch_idx, sync=sync)
+
     # ---- data parallel: ONE all-reduce over the flat adapter-grad buffer (24-46 MB), averaged
     def set_option(self, name: str, value: int):
         """`two_stream` (teacher pass on a side HIP stream), `merge_passes` (teacher == student checkpoint: both forwards

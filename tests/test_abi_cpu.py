@@ -42,3 +42,32 @@ def test_shape_errors_are_reported_without_gpu():
     # K not a multiple of 64 is rejected before any device work
     rc = L.pea_op_gemm(None, 8, None, 8, None, 8, 4, 4, 10, 1.0, None, None, 0, 1, 0, None, 0, None, 0, 0, 0, None)
     assert rc == -3 and b"K=10" in L.pea_last_error()
+
+
+def test_unet_plan_runs_without_a_device():
+    """pea_unet_plan: the host-side tape builder + memory planner needs no GPU (known answer: SDXL parameter total)"""
+    import ctypes as C
+    from pea_diffusion_amd import config as pc
+    L = _lib.lib()
+    c = pc.to_c(pc.sdxl_config())
+    n_ops, n_w, npar, wb, ab, gb = C.c_int(), C.c_int(), C.c_longlong(), C.c_longlong(), C.c_longlong(), C.c_longlong()
+    assert L.pea_unet_plan(C.byref(c), 4, 128, 128, 77, 1, C.byref(n_ops), C.byref(n_w), C.byref(npar), C.byref(wb),
+                           C.byref(ab), C.byref(gb)) == 0
+    assert npar.value == 2_567_463_684 and n_ops.value > 800 and ab.value > gb.value > 10e9
+    c2 = pc.to_c(pc.ssd1b_config())
+    assert L.pea_unet_plan(C.byref(c2), 4, 128, 128, 77, 1, None, None, C.byref(npar), None, None, None) == 0
+    assert npar.value == 1_300_195_844
+
+
+def test_host_runtime_under_asan():
+    """SURVEY 5 sanitizer row: the host half of every translation unit built with -fsanitize=address
+    (--offload-host-only; GPU ASAN is unavailable on this pool) and driven through the C ABI's error paths and the
+    tape builder / planner by tests/abi_asan_driver.c."""
+    import subprocess
+    r = subprocess.run(["make", "-C", _lib.CSRC, "-j8", "asan"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    exe = os.path.join(_lib.CSRC, "build_asan", "abi_asan_driver")
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300,
+                       env=dict(os.environ, ASAN_OPTIONS="detect_leaks=0:abort_on_error=0"))
+    assert r.returncode == 0 and "all host checks passed" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
+    assert "AddressSanitizer" not in r.stderr

@@ -314,8 +314,12 @@ def test_adamw_and_checkpoint_round_trip(gpu, tmp_path):
         assert torch.equal(sd[k], v.detach().cpu()), k
 
 
-def test_merged_passes_match_two_streams_and_oracle(gpu):
-    """Reference default: the teacher IS the student checkpoint (train_sdxl_zh.py:138,151 load the same model_path).  The
+@pytest.mark.parametrize("L,Lt", [(77, 77), (52, 77)])
+def test_merged_passes_match_two_streams_and_oracle(gpu, L, Lt):
+    """(L, Lt) = (52, 77) is the reference's actual default: Chinese-CLIP emits 52 tokens
+    (utils/custom_dataset_sdxl.py:352-353) while the teacher's CLIP towers emit 77 -- the merged context is then 77 tokens
+    long, the student rows are zero padded and a per-sample key count masks the padding in the cross-attention kernels.
+    Reference default: the teacher IS the student checkpoint (train_sdxl_zh.py:138,151 load the same model_path).  The
     trainer then runs both forwards as ONE pass over 2B samples and differentiates the first B; it must agree with the
     two-stream path and with the oracle."""
     import copy
@@ -325,7 +329,7 @@ def test_merged_passes_match_two_streams_and_oracle(gpu):
     from pea_diffusion_amd.adapter import PEAAdapter
     from pea_diffusion_amd.train import PEATrainer
     from pea_diffusion_amd.unet import HipUNet
-    B, L = 4, 77
+    B = 4
     cfg = tiny_config()
     torch.manual_seed(0)
     us = UNet2DConditionRef(cfg)
@@ -340,7 +344,7 @@ def test_merged_passes_match_two_streams_and_oracle(gpu):
     round_weights_bf16_(ad_ref)
     hs = HipUNet(pc.tiny_config(), B, 16, 16, L, needs_grad=True)
     hs.load_state_dict(us.state_dict())
-    ht = HipUNet(pc.tiny_config(), B, 16, 16, L, needs_grad=False, share_weights_from=hs)
+    ht = HipUNet(pc.tiny_config(), B, 16, 16, Lt, needs_grad=False, share_weights_from=hs)
     batch = synthetic_batch(cfg, B, L=L, enc_dim=128, seed=3)
     tr = PEATrainer(ad_hip, hs, ht)
     tr.set_option("merge_passes", 0)
