@@ -102,15 +102,14 @@ __device__ __forceinline__ void attn_block_coords(int remap, int& bx, int& by, i
 // K/V (Q/dO) tile is kept as ND sub-tiles of 64 x 64 so all LDS images stay 128-byte-row images.
 // MODE 0 produces all ND output chunks in one pass; MODE 1 produces ONE 64-wide chunk of dQ per workgroup
 // (blockIdx.x enumerates query blocks x ND chunks) so its register budget does not grow with ND.
-template <int MODE, bool USE_TR, int ND, bool TXT = false>
-__global__ __launch_bounds__(256, (ND == 1 ? (MODE == 0 ? (TXT ? 3 : 4) : 2) : 1)) void attn_q_kernel(const AttnP p) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 stages][K sub-tiles ND | V sub-tiles ND]
-  constexpr int STG = 2 * ND * TILE_BYTES;
+// WRITE_DELTA: the dQ pass also stores delta[q] for the dK/dV kernel launched behind it (two-launch form); the fused
+// backward launch gets delta from attn_delta_kernel instead (both roles run concurrently there)
+template <int MODE, bool USE_TR, int ND, bool TXT, bool WRITE_DELTA>
+__device__ __forceinline__ void attn_q_body(const AttnP& p, char* smem, int blk_x, int head, int b) {
+  constexpr int STG = 2 * ND * TILE_BYTES;                       // smem: [2 stages][K sub-tiles ND | V sub-tiles ND]
   constexpr int NO = MODE == 0 ? ND : 1;                         // output chunks held by this workgroup
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  int blk_x, head, b;
-  attn_block_coords(p.xcd_remap, blk_x, head, b);
   const int qblk = MODE == 0 ? blk_x : blk_x / ND;
   const int chunk = MODE == 0 ? 0 : blk_x % ND;                  // dQ output chunk
   const int q0 = qblk * 128 + wave * 32;
@@ -153,7 +152,7 @@ __global__ __launch_bounds__(256, (ND == 1 ? (MODE == 0 ? (TXT ? 3 : 4) : 2) : 1
       }
     dsum += __shfl_xor(dsum, 32, 64);
     dlt = dsum;
-    if (qvalid && fh == 0 && chunk == 0) p.delta[li] = dsum;
+    if (WRITE_DELTA && qvalid && fh == 0 && chunk == 0) p.delta[li] = dsum;
   }
 
   f32x16 oacc[2 * NO];
@@ -317,6 +316,14 @@ __global__ __launch_bounds__(256, (ND == 1 ? (MODE == 0 ? (TXT ? 3 : 4) : 2) : 1
       }
 }
 
+template <int MODE, bool USE_TR, int ND, bool TXT = false>
+__global__ __launch_bounds__(256, (ND == 1 ? (MODE == 0 ? (TXT ? 3 : 4) : 2) : 1)) void attn_q_kernel(const AttnP p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  int blk_x, head, b;
+  attn_block_coords(p.xcd_remap, blk_x, head, b);
+  attn_q_body<MODE, USE_TR, ND, TXT, true>(p, smem, blk_x, head, b);
+}
+
 // per-row constants of a 64-query tile (lse, delta) -> LDS, 4 bytes per lane, issued by wave 0 only
 __device__ __forceinline__ void stage_rowconst(const float* lse, const float* dlt, int r0, int rmax, char* dst,
                                                int wave, int lane) {
@@ -334,13 +341,10 @@ __device__ __forceinline__ void stage_rowconst(const float* lse, const float* dl
 // block writes fp32 partial dK/dV to p.dkv_part[split][b][h][key][2][64*ND]; attn_dkv_reduce_kernel adds the
 // splits in order (deterministic, no atomics).
 template <bool USE_TR, int ND>
-__global__ __launch_bounds__(256, (ND == 1 ? 2 : 1)) void attn_dkv_kernel(const AttnP p) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 stages][Q sub-tiles | dO sub-tiles | lse,delta]
-  constexpr int STG = 2 * ND * TILE_BYTES + 512;
+__device__ __forceinline__ void attn_dkv_body(const AttnP& p, char* smem, int blk_x, int head, int b) {
+  constexpr int STG = 2 * ND * TILE_BYTES + 512;                 // smem: [2 stages][Q sub-tiles | dO sub-tiles | lse,delta]
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  int blk_x, head, b;
-  attn_block_coords(p.xcd_remap, blk_x, head, b);
   const int nsplit = p.nsplit > 1 ? p.nsplit : 1;
   const int chunk = blk_x % ND;
   const int bx = blk_x / ND;
@@ -492,6 +496,37 @@ __global__ __launch_bounds__(256, (ND == 1 ? 2 : 1)) void attn_dkv_kernel(const 
     }
 }
 
+template <bool USE_TR, int ND>
+__global__ __launch_bounds__(256, (ND == 1 ? 2 : 1)) void attn_dkv_kernel(const AttnP p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  int blk_x, head, b;
+  attn_block_coords(p.xcd_remap, blk_x, head, b);
+  attn_dkv_body<USE_TR, ND>(p, smem, blk_x, head, b);
+}
+
+// ============================================================================= fused backward launch
+// dQ workgroups and dK/dV workgroups of ONE attention in ONE grid.  As two launches each pass ends on a partly filled
+// last round of workgroups (self-attention over 1024 tokens, B*H = 80: 640 workgroups on 512 slots = 1.25 rounds, i.e.
+// 62 % of the slots busy; 4096 tokens: 2.5 rounds, 83 %); together they are 2.5 / 5 rounds.  Both roles keep their own
+// code (the role is uniform per workgroup).  Task order: all workgroups of one (batch, head) are adjacent -- dQ blocks,
+// then dK/dV blocks -- and XCD x owns a contiguous range of heads, so a head's Q / K / V / dO are read into one L2 once
+// for both roles.  delta comes from attn_delta_kernel (the roles run concurrently, so the dQ role cannot hand it over).
+template <bool USE_TR, int ND>
+__global__ __launch_bounds__(256, (ND == 1 ? 2 : 1)) void attn_bwd_fused_kernel(const AttnP p, int n_dq, int n_dkv) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const unsigned total = gridDim.x;
+  unsigned lin = blockIdx.x;
+  if (p.xcd_remap) {
+    const unsigned q = total >> 3, r = total & 7, xcd = lin & 7, j = lin >> 3;
+    lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+  }
+  const int per_head = n_dq + n_dkv;
+  const int bh = (int)(lin / per_head), rem = (int)(lin - (unsigned)bh * per_head);
+  const int b = bh / p.H, head = bh - b * p.H;
+  if (rem < n_dkv) attn_dkv_body<USE_TR, ND>(p, smem, rem, head, b);          // heavier role (4 products) first
+  else attn_q_body<1, USE_TR, ND, false, false>(p, smem, rem - n_dkv, head, b);
+}
+
 // delta[b][h][q] = sum_d dO[q][h*D+d] * O[q][h*D+d]; 8 lanes per (row, head), each sums D/8 elements
 __global__ __launch_bounds__(256) void attn_delta_kernel(const AttnP p) {
   const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;   // one thread per (b, q, head, 8-lane slot)
@@ -614,10 +649,30 @@ static int attn_fwd_nd(const AttnP& p, hipStream_t s) {
   ATTN_DISPATCH((attn_q_kernel<0, true, ND>), (attn_q_kernel<0, false, ND>), grid, 2 * 2 * ND * TILE_BYTES);
   return PEA_OK;
 }
+static int g_attn_fused_bwd = getenv("PEA_ATTN_BWD_SPLIT") ? 0 : 1;      // PEA_ATTN_BWD_SPLIT=1: the two-launch form (A/B)
+extern "C" void pea_debug_set_attn_fused_bwd(int v) { g_attn_fused_bwd = v; }
 template <int ND>
 static int attn_bwd_nd(const AttnP& p, hipStream_t s) {
   int rc = attn_set_lds_attr<ND>();
   if (rc) return rc;
+  if (p.dQ && p.dK && p.dV && g_attn_fused_bwd) {
+    static bool attr = false;
+    constexpr int lds = 2 * (2 * ND * TILE_BYTES + 512);
+    if (!attr) {
+      HIPCHK(hipFuncSetAttribute((const void*)attn_bwd_fused_kernel<true, ND>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+      HIPCHK(hipFuncSetAttribute((const void*)attn_bwd_fused_kernel<false, ND>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+      attr = true;
+    }
+    const int n_dq = cdiv(p.Sq, 128) * ND, n_dkv = cdiv(p.Skv, 128) * (p.nsplit > 1 ? p.nsplit : 1) * ND;
+    const dim3 grid((unsigned)((n_dq + n_dkv) * p.H * p.B));
+    if (g_attn_use_tr) hipLaunchKernelGGL((attn_bwd_fused_kernel<true, ND>), grid, dim3(256), lds, s, p, n_dq, n_dkv);
+    else hipLaunchKernelGGL((attn_bwd_fused_kernel<false, ND>), grid, dim3(256), lds, s, p, n_dq, n_dkv);
+    if (p.nsplit > 1) {
+      const long long total = (long long)p.B * p.H * p.Skv * 2 * 16 * ND;
+      hipLaunchKernelGGL(attn_dkv_reduce_kernel, dim3((unsigned)cdivl(total, 256)), dim3(256), 0, s, p);
+    }
+    return PEA_OK;
+  }
   if (p.dQ) {
     const dim3 grid(cdiv(p.Sq, 128) * ND, p.H, p.B);
     ATTN_DISPATCH((attn_q_kernel<1, true, ND>), (attn_q_kernel<1, false, ND>), grid, 2 * 2 * ND * TILE_BYTES);
@@ -662,7 +717,10 @@ int launch_attention_bwd(const AttnP& p0, hipStream_t s) {
   // algorithmic: 5 products (S, dP, dV, dK, dQ) = 10*B*H*Sq*Skv*D flops (the two-kernel form recomputes S and dP)
   if (g_prof_on) { g_prof_tag[0] = p.B * p.H; g_prof_tag[1] = p.Sq; g_prof_tag[2] = p.Skv; g_prof_tag[3] = p.nd; }
   PROF_BEGIN(3, 10.0 * p.B * p.H * (double)p.Sq * p.Skv * 64 * p.nd, 2.0 * p.B * p.H * 64 * p.nd * (4.0 * p.Sq + 4.0 * p.Skv), s);
-  if (!p.dQ) hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)cdivl(total, 256)), dim3(256), 0, s, p);   // else: the dQ kernel computes it
+  // delta: its own (memory-bound) kernel for the fused launch and for dK/dV-only calls; the two-launch form computes it
+  // inside the dQ pass
+  if (!p.dQ || (p.dK && p.dV && g_attn_fused_bwd))
+    hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)cdivl(total, 256)), dim3(256), 0, s, p);
   rc = p.nd == 1 ? attn_bwd_nd<1>(p, s) : p.nd == 2 ? attn_bwd_nd<2>(p, s) : attn_bwd_nd<3>(p, s);
   PROF_END(s);
   if (rc) return rc;

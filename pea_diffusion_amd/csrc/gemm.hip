@@ -228,6 +228,145 @@ __device__ __forceinline__ void gemm_epilogue16(const GemmP& p, f32x4 (&acc)[NT]
   }
 }
 
+// Batched-load epilogue for the 16x16x32 accumulator layout (bf16 output; alpha, bias, per-sample row vector, residual,
+// fused GEGLU with its pre-activation stash).  The generic epilogue above walks the tile quad by quad -- load bias, load
+// residual, wait, convert, store -- and on this hardware vmcnt counts stores as well as loads, in issue order: every quad's
+// wait also waits for the store of the quad before it, so a tile's 20 quads per lane pay 20 dependent round trips while
+// both MFMA waves of the SIMD stand still (the tile transition measured 27-36 % of a K = 640..1280 launch,
+// profiles/r01_gemm_epi_probe.log).  Here every load of the wave tile is issued first (bias + row vector: NT quads,
+// residual: MT x NT quads), then the arithmetic runs and all stores leave back to back: one load latency per tile.
+// Preconditions (launch_gemm sets p.epi_fast): !out_f32, act == 0, no preact, ldc % 8 == 0, C 16-byte aligned,
+// N % 16 == 0, and for a row vector rows_per_batch % (rows of a wave tile) == 0 (one batch sample per wave tile).
+template <int MT, int NT>
+__device__ __forceinline__ void gemm_epilogue16_fast(const GemmP& p, f32x4 (&acc)[NT][MT], int m_base, int n_base, int r16,
+                                                     int q4) {
+  typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+  typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+  // ---- loads: bias (+ row vector) per n-tile
+  f32x4 bq[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) bq[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  if (p.bias) {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) bq[nt] = *(const f32x4*)(p.bias + min(n_base + nt * 16 + 4 * q4, p.N - 4));
+  }
+  bf16x4 rvq[NT];
+  if (p.rowvec) {
+    const int bidx = min(m_base, p.M - 1) / p.rows_per_batch;          // uniform over the wave tile (precondition)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+      rvq[nt] = *(const bf16x4*)(p.rowvec + (long long)bidx * p.ldrv + min(n_base + nt * 16 + 4 * q4, p.N - 4));
+  }
+  if (p.rowvec) {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) bq[nt][j] += (float)rvq[nt][j];
+  }
+  const bool has_res = p.res != nullptr;
+  const float alpha = p.alpha;
+  if (p.geglu_y) {
+    // v = (h_a, gate_a, h_b, gate_b) after bias: y = h * gelu(gate) -> geglu_y[m][n / 2]; the pre-activation goes to C
+    // for the rows that will be differentiated (stash_rows) -- none for a teacher / inference pass (C == null)
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const int m = m_base + mt * 16 + r16;
+      if (m >= p.M) continue;                                          // r16 only: swap partners leave together
+      const bool stash = p.C && !(p.stash_rows > 0 && m >= p.stash_rows);
+      bf16* yrow = p.geglu_y + (long long)m * p.ldy;
+      bf16* crow = (bf16*)p.C + (long long)m * p.ldc;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const bool paired = (nt & 1) == 0 && nt + 1 < NT && n_base + (nt + 2) * 16 <= p.N;
+        if ((nt & 1) == 1 && n_base + (nt + 1) * 16 <= p.N) continue;                 // done with its left neighbour
+        if (n_base + nt * 16 >= p.N) continue;
+        float v0[4], v1[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v0[j] = acc[nt][mt][j] * alpha + bq[nt][j];
+        union { bf16x2 h; unsigned u; } y0, y1;
+        y0.h[0] = (bf16)(v0[0] * gelu_erf(v0[1]));
+        y0.h[1] = (bf16)(v0[2] * gelu_erf(v0[3]));
+        if (paired) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v1[j] = acc[nt + 1][mt][j] * alpha + bq[nt + 1][j];
+          y1.h[0] = (bf16)(v1[0] * gelu_erf(v1[1]));
+          y1.h[1] = (bf16)(v1[2] * gelu_erf(v1[3]));
+          // lane row q4 receives the words of lane rows (q4 & ~1) and (q4 | 1) of n-tile nt + (q4 & 1): 8 contiguous bytes
+          const auto w = __builtin_amdgcn_permlane16_swap(y0.u, y1.u, false, false);
+          const u32x2 o = {w[0], w[1]};
+          *(u32x2*)(yrow + ((n_base + (nt + (q4 & 1)) * 16) >> 1) + 4 * (q4 >> 1)) = o;
+          if (stash) {
+            union { bf16x4 h; unsigned u[2]; } a, b;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { a.h[j] = (bf16)v0[j]; b.h[j] = (bf16)v1[j]; }
+            const auto lo = __builtin_amdgcn_permlane16_swap(a.u[0], b.u[0], false, false);
+            const auto hi = __builtin_amdgcn_permlane16_swap(a.u[1], b.u[1], false, false);
+            const u32x4 oc = {lo[0], hi[0], lo[1], hi[1]};
+            *(u32x4*)(crow + n_base + (nt + (q4 & 1)) * 16 + 8 * (q4 >> 1)) = oc;
+          }
+        } else {
+          *(bf16x2*)(yrow + ((n_base + nt * 16 + 4 * q4) >> 1)) = y0.h;
+          if (stash) {
+            bf16x4 oc;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) oc[j] = (bf16)v0[j];
+            *(bf16x4*)(crow + n_base + nt * 16 + 4 * q4) = oc;
+          }
+        }
+      }
+    }
+    return;
+  }
+  // residual quads one 16-row block ahead of the arithmetic (two buffers of NT quads): the loads of block mt + 1 are issued
+  // before the stores of block mt, so the wait for them leaves those stores in flight; holding the whole tile's quads
+  // (MT x NT x 8 bytes per lane) beside the accumulators would not fit the 168-register budget of three waves per SIMD.
+  // res may alias C: a block's quads are read before its own stores are issued and blocks do not overlap.
+  bf16x4 rq[2][NT];
+  auto load_res = [&](int buf, int mt) {
+    const long long mo = (long long)min(m_base + mt * 16 + r16, p.M - 1) * p.ldres;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) rq[buf][nt] = *(const bf16x4*)(p.res + mo + min(n_base + nt * 16 + 4 * q4, p.N - 4));
+  };
+  if (has_res) load_res(0, 0);
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    if (has_res && mt + 1 < MT) load_res((mt + 1) & 1, mt + 1);
+    __builtin_amdgcn_sched_barrier(0);
+    const int m = m_base + mt * 16 + r16;
+    if (m < p.M) {                                                     // r16 only: swap partners agree
+      bf16* crow = (bf16*)p.C + (long long)m * p.ldc;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const bool paired = (nt & 1) == 0 && nt + 1 < NT && n_base + (nt + 2) * 16 <= p.N;
+        if ((nt & 1) == 1 && n_base + (nt + 1) * 16 <= p.N) continue;                 // stored with its left neighbour
+        if (n_base + nt * 16 >= p.N) continue;
+        union { bf16x4 h; unsigned u[2]; } a, b;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          float v = acc[nt][mt][j] * alpha + bq[nt][j];
+          if (has_res) v += (float)rq[mt & 1][nt][j];
+          a.h[j] = (bf16)v;
+        }
+        if (paired) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            float v = acc[nt + 1][mt][j] * alpha + bq[nt + 1][j];
+            if (has_res) v += (float)rq[mt & 1][nt + 1][j];
+            b.h[j] = (bf16)v;
+          }
+          const auto lo = __builtin_amdgcn_permlane16_swap(a.u[0], b.u[0], false, false);
+          const auto hi = __builtin_amdgcn_permlane16_swap(a.u[1], b.u[1], false, false);
+          const u32x4 o = {lo[0], hi[0], lo[1], hi[1]};
+          *(u32x4*)(crow + n_base + (nt + (q4 & 1)) * 16 + 8 * (q4 >> 1)) = o;
+        } else {
+          *(bf16x4*)(crow + n_base + nt * 16 + 4 * q4) = a.h;
+        }
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
 // lean slice epilogue for the deferred form: alpha, optional bias, bf16 output (ldc % 8 == 0, C 16-byte aligned: the
 // launcher's rule); few live values, so it can sit inside the K-loop
 template <int MT, int NT, int M0, int M1>
@@ -445,6 +584,10 @@ __global__ __launch_bounds__((WM * WN + LW) * 64, MINW) void gemm_lc_kernel(cons
       }
       cur = nxt;
     }
+    if (p.epi_fast) {
+      gemm_epilogue16_fast<MT, NT>(p, acc, bm * BM + wr * (BM / WM), bn * BN + wc * (BN / WN), r16, q4);
+      return;
+    }
     GemmP q = p;
     if (p.ksplit > 1) q.C = (float*)p.C + (long long)blockIdx.y * p.split_stride;
     gemm_epilogue16<MT, NT, 0, MT, true>(q, acc, bm * BM + wr * (BM / WM), bn * BN + wc * (BN / WN), r16, q4);
@@ -550,7 +693,9 @@ static int launch_lc(const GemmP& p, hipStream_t stream) {
 // odd K-steps), so while one converts and stores a slice the other keeps the matrix pipe busy -- the tile
 // transition, 27-36 % of a K = 640..1280 launch when every wave stops for its epilogue at once
 // (scripts/gemm_epi_probe.py), disappears behind the main loop.
-template <int MODE, int BM, int BN, int WM, int WN, int LW, int S, int SW = 0, int DF = 0>
+// FASTONLY: only the batched-load epilogue is compiled in (the 256-row tiles: with both epilogues in one kernel the
+// register allocator spills around the tile transition); launch_gemm sends other epilogues to a 128-row variant.
+template <int MODE, int BM, int BN, int WM, int WN, int LW, int S, int SW = 0, int DF = 0, bool FASTONLY = false>
 __global__ __launch_bounds__((WM * WN + LW + SW) * 64) void gemm_lcp_kernel(const GemmP p) {
   constexpr int PITCH = BN * 2 + 16;                            // staging row pitch: conflict-free 8-byte writes
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -732,12 +877,16 @@ __global__ __launch_bounds__((WM * WN + LW + SW) * 64) void gemm_lcp_kernel(cons
   const int r16 = lane & 15, q4 = lane >> 4;
   const int a_row0 = wr * (BM / WM) + r16, w_row0 = wc * (BN / WN) + r16;
   bf16x8 af[2][MT], wf[2][NT];
+  // fragment addresses as (per-lane base) + (compile-time offset): rows 16 apart share the swizzle term ((row >> 1) & 7)
+  // and the two k32 halves differ by XOR 64 bytes, so FOUR per-lane offsets address all 2 x (MT + NT) fragments (the
+  // per-fragment form kept up to 18 loop-invariant address registers live beside 152 accumulator + fragment registers)
+  const int a_off[2] = {swz_off(a_row0, q4), swz_off(a_row0, 4 + q4)};
+  const int w_off[2] = {A_BYTES + swz_off(w_row0, q4), A_BYTES + swz_off(w_row0, 4 + q4)};
   auto load_frags = [&](int which, const char* tile, int s2) {
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) af[which][mt] = *(const bf16x8*)(tile + swz_off(a_row0 + mt * 16, 4 * s2 + q4));
+    for (int mt = 0; mt < MT; ++mt) af[which][mt] = *(const bf16x8*)(tile + a_off[s2] + mt * 2048);
 #pragma unroll
-    for (int nt_ = 0; nt_ < NT; ++nt_)
-      wf[which][nt_] = *(const bf16x8*)(tile + A_BYTES + swz_off(w_row0 + nt_ * 16, 4 * s2 + q4));
+    for (int nt_ = 0; nt_ < NT; ++nt_) wf[which][nt_] = *(const bf16x8*)(tile + w_off[s2] + nt_ * 2048);
   };
   __builtin_amdgcn_s_barrier();                                // prologue barrier
   load_frags(0, smem, 0);
@@ -846,8 +995,20 @@ __global__ __launch_bounds__((WM * WN + LW + SW) * 64) void gemm_lcp_kernel(cons
         for (int j = 0; j < MT; ++j) accp[i][j] = acc[i][j];
       pm = bm * BM + wr * (BM / WM); pn = bn * BN + wc * (BN / WN); pdone = 0;
     } else {
-      if (!(p.debug & 16)) gemm_epilogue16<MT, NT>(p, acc, bm * BM + wr * (BM / WM), bn * BN + wc * (BN / WN), r16, q4);
-      else if (acc[0][0][0] == 12345.678f) *(float*)p.C = 1.f;   // timing experiment: keep the accumulators alive
+      if (FASTONLY || p.epi_fast) {
+        // lane constants laundered through an empty asm: the epilogue's per-lane address arithmetic is then derived
+        // inside the epilogue instead of being hoisted to kernel entry and kept (spilled) across the whole tile loop
+        int r16e = r16, q4e = q4;
+        asm volatile("" : "+v"(r16e), "+v"(q4e));
+        gemm_epilogue16_fast<MT, NT>(p, acc, bm * BM + wr * (BM / WM), bn * BN + wc * (BN / WN), r16e, q4e);
+        // the next tile's first fragments were fetched at the last barrier already; fetching them AGAIN here makes that
+        // copy dead across the epilogue, so its 36 registers are free for the residual quads (the K-loop body itself
+        // stays as it was: a special-cased last K-step made the compiler peel the loop and spill fragments inside it)
+        load_frags(0, smem + cur * STAGE, 0);                  // unconditional (after the last tile: a harmless read of a stale slot)
+      } else if constexpr (!FASTONLY) {
+        if (!(p.debug & 16)) gemm_epilogue16<MT, NT>(p, acc, bm * BM + wr * (BM / WM), bn * BN + wc * (BN / WN), r16, q4);
+        else if (acc[0][0][0] == 12345.678f) *(float*)p.C = 1.f;   // timing experiment: keep the accumulators alive
+      }
     }
   }
   if constexpr (DF) {
@@ -860,13 +1021,13 @@ __global__ __launch_bounds__((WM * WN + LW + SW) * 64) void gemm_lcp_kernel(cons
 }
 
 static int g_num_cus = 0;
-template <int MODE, int BM, int BN, int WM, int WN, int LW, int S, int SW = 0, int DF = 0>
+template <int MODE, int BM, int BN, int WM, int WN, int LW, int S, int SW = 0, int DF = 0, bool FASTONLY = false>
 static int launch_lcp(const GemmP& p, hipStream_t stream) {
   constexpr int lds = S * (BM + BN) * 128 + (SW ? BM * (BN * 2 + 16) : 0);
   static_assert(lds <= 160 * 1024, "LDS budget");
   static bool attr_set = false;
   if (!attr_set) {
-    HIPCHK(hipFuncSetAttribute((const void*)gemm_lcp_kernel<MODE, BM, BN, WM, WN, LW, S, SW, DF>,
+    HIPCHK(hipFuncSetAttribute((const void*)gemm_lcp_kernel<MODE, BM, BN, WM, WN, LW, S, SW, DF, FASTONLY>,
                                hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     attr_set = true;
   }
@@ -878,8 +1039,9 @@ static int launch_lcp(const GemmP& p, hipStream_t stream) {
   SHAPECHK(p.ksplit <= 1, "gemm: the persistent kernel has no split-K path");
   const int tiles = cdiv(p.M, BM) * cdiv(p.N, BN);
   const int grid = tiles < g_num_cus ? tiles : g_num_cus;
-  hipLaunchKernelGGL((gemm_lcp_kernel<MODE, BM, BN, WM, WN, LW, S, SW, DF>), dim3(grid), dim3((WM * WN + LW + SW) * 64), lds,
-                     stream, p);
+  SHAPECHK(!FASTONLY || p.epi_fast, "gemm: variant needs the batched-load epilogue");
+  hipLaunchKernelGGL((gemm_lcp_kernel<MODE, BM, BN, WM, WN, LW, S, SW, DF, FASTONLY>), dim3(grid),
+                     dim3((WM * WN + LW + SW) * 64), lds, stream, p);
   return PEA_OK;
 }
 
@@ -896,12 +1058,12 @@ extern "C" void pea_debug_set_gemm_variant(int v) { g_gemm_variant = v; }
     case 23: rc = launch_lc<MODE, 128, 128, 2, 2, 4, 4, false, true>(p, stream); break; \
     case 24: rc = launch_lc<MODE, 256, 160, 4, 2, 4, 3, false, true>(p, stream); break; \
     case 25: rc = launch_lc<MODE, 128, 160, 4, 2, 4, 3, false, true>(p, stream); break; \
-    case 27: rc = launch_lcp<MODE, 256, 160, 4, 2, 4, 3>(p, stream); break; \
+    case 27: rc = launch_lcp<MODE, 256, 160, 4, 2, 4, 3, 0, 0, true>(p, stream); break; \
     case 28: rc = launch_lcp<MODE, 128, 160, 4, 2, 4, 3>(p, stream); break; \
     case 29: rc = launch_lcp<MODE, 128, 160, 2, 2, 4, 4>(p, stream); break; \
     case 30: rc = launch_lcp<MODE, 128, 128, 2, 2, 4, 4>(p, stream); break; \
     case 31: rc = launch_lcp<MODE, 64, 160, 2, 2, 4, 4>(p, stream); break; \
-    case 33: rc = launch_lcp<MODE, 256, 128, 4, 2, 4, 3>(p, stream); break; \
+    case 33: rc = launch_lcp<MODE, 256, 128, 4, 2, 4, 3, 0, 0, true>(p, stream); break; \
     case 34: rc = launch_lcp<MODE, 128, 160, 4, 2, 4, 3, 4>(p, stream); break; /* staged epilogue */ \
     case 35: rc = launch_lcp<MODE, 128, 160, 4, 2, 4, 3, 0, 1>(p, stream); break; /* deferred epilogue */ \
     default: rc = launch_lc<MODE, 128, 128, 2, 2, 4, 4, false, true>(p, stream); break; \
@@ -967,10 +1129,24 @@ int launch_gemm(const GemmP& p_in, hipStream_t stream) {
   GemmP p = p_in;
   p.debug = g_gemm_debug;
   int v = pick_variant(p);
+  {
+    // wave-tile rows of the 16x16x32 kernels are 32 or 64: a per-sample row vector must not change inside them
+    static const bool slow_epi = getenv("PEA_GEMM_SLOW_EPILOGUE") != nullptr;     // A/B switch
+    const bool rv_ok = !p.rowvec || (p.rows_per_batch % 64 == 0);
+    const bool gg_ok = !p.geglu_y || (p.ldy % 4 == 0 && (((unsigned long long)p.geglu_y & 7) == 0) && !p.res && !p.rowvec);
+    p.epi_fast = !slow_epi && !p.out_f32 && p.act == 0 && !p.preact && p.ksplit <= 1 && p.N % 16 == 0 && rv_ok && gg_ok &&
+                 (p.geglu_y ? (!p.C || (p.ldc % 8 == 0 && (((unsigned long long)p.C & 15) == 0)))
+                            : (p.ldc % 8 == 0 && (((unsigned long long)p.C & 15) == 0))) &&
+                 (!p.res || (p.ldres % 4 == 0 && (((unsigned long long)p.res & 7) == 0))) && !(g_gemm_debug & 16);
+  }
   if (p.ksplit > 1) {
     SHAPECHK(p.out_f32 && !p.accum_f32 && !p.bias && !p.res && !p.rowvec && !p.preact && p.act == 0 && p.mode == 0,
              "gemm: split-K writes plain fp32 partials");
     v = 18;                                         // loader/consumer 128x128 (the only kernel with the K-split path)
+  }
+  if (!p.epi_fast) {                                // the 256-row persistent kernels carry the batched-load epilogue only
+    if (v == 27) v = 28;
+    if (v == 33) v = 30;
   }
   int rc = PEA_OK;
   if (p.mode == 0) { GEMM_VARIANTS(0) } else { GEMM_VARIANTS(1) }

@@ -33,6 +33,7 @@ struct GemmP {
   bf16* geglu_y; int ldy;
   int stash_rows;                  // GEGLU with a stash: rows >= stash_rows (> 0) skip the C store (merged passes: teacher rows)
   int ksplit; long long split_stride;   // split-K: fp32 partial s is written at C + s*split_stride (then launch_splitk_reduce)
+  int epi_fast;                    // set by launch_gemm: the batched-load epilogue (gemm_epilogue16_fast) applies
 };
 int launch_splitk_reduce(const float* part, int nsplit, long long stride, bf16* out, int ldo, int M, int N, int accum,
                          hipStream_t s);

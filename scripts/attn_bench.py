@@ -22,6 +22,20 @@ for (B, H, Sq, Skv) in shapes:
     err = (o.float() - ref).abs().max().item()
     do = torch.randn_like(o)
     tf = timeit(lambda: ops.attention_fwd(q, k, v, H))
-    tb = timeit(lambda: ops.attention_bwd(q, k, v, o, do, lse, H))
+    from pea_diffusion_amd._lib import lib
     fl = 4.0 * B * H * Sq * Skv * 64
-    print(f"attn B{B} H{H} Sq{Sq} Skv{Skv}: fwd {tf*1e6:7.1f} us {fl/tf/1e12:6.1f} TF | bwd {tb*1e6:7.1f} us {2.5*fl/tb/1e12:6.1f} TF | max err {err:.3e}", flush=True)
+    res = {}
+    for rnd in range(3):                      # interleaved rounds in one process (fused launch vs two launches)
+        for mode in (1, 0):
+            lib().pea_debug_set_attn_fused_bwd(mode)
+            tb = timeit(lambda: ops.attention_bwd(q, k, v, o, do, lse, H))
+            res.setdefault(mode, []).append(tb)
+    lib().pea_debug_set_attn_fused_bwd(1)
+    g1 = ops.attention_bwd(q, k, v, o, do, lse, H)
+    lib().pea_debug_set_attn_fused_bwd(0)
+    g0 = ops.attention_bwd(q, k, v, o, do, lse, H)
+    lib().pea_debug_set_attn_fused_bwd(1)
+    same = all(torch.equal(a, b) for a, b in zip(g1, g0))
+    t1, t0 = min(res[1]), min(res[0])
+    print(f"attn B{B} H{H} Sq{Sq} Skv{Skv}: fwd {tf*1e6:7.1f} us {fl/tf/1e12:6.1f} TF | bwd fused {t1*1e6:7.1f} us {2.5*fl/t1/1e12:6.1f} TF, "
+          f"two launches {t0*1e6:7.1f} us {2.5*fl/t0/1e12:6.1f} TF (bit-identical: {same}) | max err {err:.3e}", flush=True)
