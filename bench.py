@@ -47,13 +47,15 @@ def synthetic_batch(cfg, B, L, enc_dim, hw, device, seed):
 
 
 def pmc_traffic():
-    """HBM-side bytes per GEMM launch from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this
-    same command (profiles/r01_pmc_traffic.json; gfx950 FETCH_SIZE x2 correction applied); None if absent."""
+    """HBM-side bytes per GEMM launch from the newest committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this
+    same command (profiles/rNN_pmc_traffic.json; gfx950 FETCH_SIZE x2 correction applied); (None, None) if absent."""
+    import glob
     try:
-        d = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
-        return round(d["gemm_family"]["traffic_MB_per_launch"] * 1e6)      # bytes per launch
+        f = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))[-1]
+        d = json.load(open(f))
+        return round(d["gemm_family"]["traffic_MB_per_launch"] * 1e6), os.path.basename(f)      # bytes per launch
     except Exception:
-        return None
+        return None, None
 
 
 def _fast_fill_(module):
@@ -413,9 +415,9 @@ def main():
         ach = g_fl / (g_ms * 1e-3) / 1e12 if g_ms > 0 else 0.0
         roof = {"bound": "mfma", "kernel": "gemm_lc_kernel / gemm_lcp_kernel (plain + implicit-GEMM conv3x3)",
                 "achieved": round(ach, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(ach / MFMA_PEAK_TFLOPS, 4), "traffic": pmc_traffic(),
+                "frac": round(ach / MFMA_PEAK_TFLOPS, 4), "traffic": pmc_traffic()[0],
                 "traffic_unit": "bytes per launch, TCC FETCH_SIZE x2 (gfx950) + WRITE_SIZE over the family's launches, from "
-                                "two separate rocprofv3 --pmc passes of this command (profiles/r01_pmc_traffic.json)",
+                                f"two separate rocprofv3 --pmc passes of this command (profiles/{pmc_traffic()[1]})",
                 "launches_per_step": g_n // nprof, "avg_launch_us": round(g_ms * 1e3 / max(g_n, 1), 2),
                 "gflop_per_launch": round(g_fl / max(g_n, 1) / 1e9, 3),
                 "ms_per_step_single_stream": round(g_ms / nprof, 2),

@@ -25,8 +25,16 @@
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 #define LOG2E 1.4426950408889634f
 
+// XOR term of a tile row: the bits of (row >> 1) & 7 rotated so that rows r and r + 2 differ in bit 2.  Any bijection of
+// (row >> 1) & 7 keeps the 16-byte row reads (ds_read_b128) conflict free; with this one the transposed reads
+// (ds_read_b64_tr_b16: 32 lanes = 4 rows x 4 chunks x 8-byte halves) are conflict free too -- with the plain term rows r and
+// r + 2 of such a read hit the same four chunks (2-way conflict: 25-32 % of the LDS cycles of these kernels were conflicts).
+__device__ __forceinline__ int swz_x(int row) {
+  const int x = (row >> 1) & 7;
+  return ((x & 1) << 2) | (x >> 1);
+}
 __device__ __forceinline__ int swz_rc(int row, int col) {   // byte offset of element (row, col) in a tile
-  return row * 128 + ((((col >> 3)) ^ ((row >> 1) & 7)) << 4) + (col & 7) * 2;
+  return row * 128 + ((((col >> 3)) ^ swz_x(row)) << 4) + (col & 7) * 2;
 }
 
 // stage a 64x64 tile: rows r0.. (clamped to rmax-1) of `src` (row stride ld elements) -> dst (LDS)
@@ -35,7 +43,7 @@ __device__ __forceinline__ void stage_tile(const bf16* src, int ld, int r0, int 
   for (int j = 0; j < 2; ++j) {
     const int piece = wave * 2 + j;
     const int r = piece * 8 + (lane >> 3);
-    const int chunk = (lane & 7) ^ ((r >> 1) & 7);
+    const int chunk = (lane & 7) ^ swz_x(r);
     int gr = r0 + r;
     gr = gr < rmax ? gr : rmax - 1;
     __builtin_amdgcn_global_load_lds(PEA_GLB(src + (long long)gr * ld + chunk * 8), PEA_LDS(dst + piece * 1024), 16,
@@ -74,8 +82,22 @@ __device__ __forceinline__ bf16x8 read_transposed_frag(const char* tile, int kba
   return out;
 }
 
+// the same fragment from precomputed per-lane byte offsets of its two 8-row halves (see attn_q_body)
+__device__ __forceinline__ bf16x8 read_transposed_frag_at(const char* lo_addr, const char* hi_addr) {
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)PEA_LDS(lo_addr));
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)PEA_LDS(hi_addr));
+  bf16x8 out;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    short a = lo[j], b = hi[j];
+    out[j] = *(bf16*)&a;
+    out[4 + j] = *(bf16*)&b;
+  }
+  return out;
+}
+
 __device__ __forceinline__ bf16x8 read_row_frag(const char* tile, int row, int s, int h) {
-  return *(const bf16x8*)(tile + row * 128 + ((((2 * s + h)) ^ ((row >> 1) & 7)) << 4));
+  return *(const bf16x8*)(tile + row * 128 + ((((2 * s + h)) ^ swz_x(row)) << 4));
 }
 
 // XCD-aware workgroup order.  Workgroups are handed to the 8 XCDs round-robin in dispatch order (x fastest), so the
@@ -174,25 +196,59 @@ __device__ __forceinline__ void attn_q_body(const AttnP& p, char* smem, int blk_
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
+  // Per-lane LDS byte offsets, computed once.  The swizzle term of a row is unchanged by +16 / +32 rows, so every fragment
+  // address in the loop is (stage base) + (one of these eight per-lane constants) + (a compile-time offset): eight integer
+  // adds per key tile instead of one address computation per ds_read (45 of the ~200 VALU instructions of a tile of the
+  // VALU-bound forward loop were address arithmetic).
+  int rf_off[4], tr_off[2][2];
+#pragma unroll
+  for (int s4 = 0; s4 < 4; ++s4) rf_off[s4] = frow * 128 + (((2 * s4 + fh) ^ swz_x(frow)) << 4);
+  {
+    const int i16 = lane & 15, rr = 4 * fh + (i16 >> 2), cc = 16 * ((lane >> 4) & 1) + 4 * (i16 & 3);
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+      for (int hl = 0; hl < 2; ++hl) tr_off[db][hl] = swz_rc(rr + 8 * hl, db * 32 + cc);
+  }
+
   for (int t = 0; t < nt; ++t) {
     const int cur = t & 1;
     if (t + 1 < nt) stage_kv(smem + (cur ^ 1) * STG, (t + 1) * 64);
     const char* Ks = smem + cur * STG;
     const char* Vs = Ks + ND * TILE_BYTES;
+    int rfc[4], trc[2][2];
+    {
+      const int sb = cur * STG;
+      const int tb = sb + (MODE == 0 ? ND * TILE_BYTES : chunk * TILE_BYTES);   // fwd: V sub-tiles; dQ: this chunk's K sub-tile
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) rfc[s4] = rf_off[s4] + sb;
+#pragma unroll
+      for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int hl = 0; hl < 2; ++hl) trc[db][hl] = tr_off[db][hl] + tb;
+    }
 
-    // S^T[key][q] = K . Q^T  (sum over the ND sub-tiles of the head dimension)
+    // S^T[key][q] = K . Q^T  (sum over the ND sub-tiles of the head dimension).  All K fragments of a sub-tile are requested
+    // before the first MFMA: read-wait-MFMA per fragment (what the compiler emits for the fused loop under a 128-register
+    // budget) exposes one LDS latency per MFMA, i.e. the matrix pipe runs at a quarter of its rate in this phase.
     f32x16 sacc[2];
 #pragma unroll
-    for (int kb = 0; kb < 2; ++kb) {
+    for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
       for (int r = 0; r < 16; ++r) sacc[kb][r] = 0.f;
 #pragma unroll
-      for (int nd = 0; nd < ND; ++nd)
+    for (int nd = 0; nd < ND; ++nd) {
+      bf16x8 kfr[2][4];
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-          const bf16x8 kf = read_row_frag(Ks + nd * TILE_BYTES, kb * 32 + frow, s, fh);
-          sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[nd][s], sacc[kb], 0, 0, 0);
-        }
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) kfr[kb][s] = *(const bf16x8*)(smem + rfc[s] + (nd * TILE_BYTES + kb * 4096));
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+          sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr[kb][s], qf[nd][s], sacc[kb], 0, 0, 0);
     }
     const int kv0 = t * 64;
     bf16x8 pf[4];   // P^T (fwd) or dS^T (dQ) as B-operand fragments, k-permuted
@@ -247,16 +303,22 @@ __device__ __forceinline__ void attn_q_body(const AttnP& p, char* smem, int blk_
       const int skv_b = p.kv_len ? p.kv_len[b] : p.Skv;          // per-sample valid keys (padded contexts)
       f32x16 dpacc[2];
 #pragma unroll
-      for (int kb = 0; kb < 2; ++kb) {
+      for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
         for (int r = 0; r < 16; ++r) dpacc[kb][r] = 0.f;
 #pragma unroll
-        for (int nd = 0; nd < ND; ++nd)
+      for (int nd = 0; nd < ND; ++nd) {
+        bf16x8 vfr[2][4];
 #pragma unroll
-          for (int s = 0; s < 4; ++s) {
-            const bf16x8 vf = read_row_frag(Vs + nd * TILE_BYTES, kb * 32 + frow, s, fh);
-            dpacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, dof[MODE == 1 ? nd : 0][s], dpacc[kb], 0, 0, 0);
-          }
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+          for (int s = 0; s < 4; ++s) vfr[kb][s] = *(const bf16x8*)(smem + rfc[s] + ((ND + nd) * TILE_BYTES + kb * 4096));
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+          for (int kb = 0; kb < 2; ++kb)
+            dpacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfr[kb][s], dof[MODE == 1 ? nd : 0][s], dpacc[kb], 0, 0, 0);
       }
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb)
@@ -277,13 +339,22 @@ __device__ __forceinline__ void attn_q_body(const AttnP& p, char* smem, int blk_
 #pragma unroll
     for (int no = 0; no < NO; ++no) {
       const char* Ts = MODE == 0 ? Vs + no * TILE_BYTES : Ks + chunk * TILE_BYTES;
+      bf16x8 tfr[4][2];                        // all eight transposed fragments first (the score registers are free by now)
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
         for (int db = 0; db < 2; ++db) {
-          const bf16x8 tf = read_transposed_frag<USE_TR>(Ts, ks * 16, db * 32, lane);
-          oacc[2 * no + db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tf, pf[ks], oacc[2 * no + db], 0, 0, 0);
+          if constexpr (USE_TR)
+            tfr[ks][db] = read_transposed_frag_at(smem + trc[db][0] + (no * TILE_BYTES + ks * 2048),
+                                                  smem + trc[db][1] + (no * TILE_BYTES + ks * 2048));
+          else tfr[ks][db] = read_transposed_frag<false>(Ts, ks * 16, db * 32, lane);
         }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+          oacc[2 * no + db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tfr[ks][db], pf[ks], oacc[2 * no + db], 0, 0, 0);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -317,7 +388,7 @@ __device__ __forceinline__ void attn_q_body(const AttnP& p, char* smem, int blk_
 }
 
 template <int MODE, bool USE_TR, int ND, bool TXT = false>
-__global__ __launch_bounds__(256, (ND == 1 ? (MODE == 0 ? (TXT ? 3 : 4) : 2) : 1)) void attn_q_kernel(const AttnP p) {
+__global__ __launch_bounds__(256, (ND == 1 ? (MODE == 0 ? 3 : 2) : 1)) void attn_q_kernel(const AttnP p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   int blk_x, head, b;
   attn_block_coords(p.xcd_remap, blk_x, head, b);
@@ -444,15 +515,26 @@ __device__ __forceinline__ void attn_dkv_body(const AttnP& p, char* smem, int bl
           }
         }
       // dV^T[d][key] += dO^T[d][q] P[q][key] ;  dK^T[d][key] += Q^T[d][q] dS[q][key]   (d in this block's chunk)
+      // two k-slices (8 transposed fragments = 32 registers, the score registers are free by now) per batch of 8 MFMAs
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks)
+      for (int k2 = 0; k2 < 4; k2 += 2) {
+        bf16x8 dot[2][2], qt[2][2];
 #pragma unroll
-        for (int db = 0; db < 2; ++db) {
-          const bf16x8 dot = read_transposed_frag<USE_TR>(dOs + chunk * TILE_BYTES, ks * 16, db * 32, lane);
-          dv[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dot, pfr[ks], dv[db], 0, 0, 0);
-          const bf16x8 qt = read_transposed_frag<USE_TR>(Qs + chunk * TILE_BYTES, ks * 16, db * 32, lane);
-          dk[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qt, dsfr[ks], dk[db], 0, 0, 0);
-        }
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+          for (int db = 0; db < 2; ++db) {
+            dot[kk][db] = read_transposed_frag<USE_TR>(dOs + chunk * TILE_BYTES, (k2 + kk) * 16, db * 32, lane);
+            qt[kk][db] = read_transposed_frag<USE_TR>(Qs + chunk * TILE_BYTES, (k2 + kk) * 16, db * 32, lane);
+          }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+          for (int db = 0; db < 2; ++db) {
+            dv[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dot[kk][db], pfr[k2 + kk], dv[db], 0, 0, 0);
+            dk[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qt[kk][db], dsfr[k2 + kk], dk[db], 0, 0, 0);
+          }
+      }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();

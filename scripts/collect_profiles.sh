@@ -15,7 +15,8 @@ python3 $R/scripts/pmc_traffic.py /tmp/prof_fetch /tmp/prof_write > $O/pmc_traff
 python3 $R/scripts/pmc_hbm.py /tmp/prof_fetch /tmp/prof_write > $O/pmc_hbm.json 2>> $O/pmc_err.txt
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace -d /tmp/prof_mfma -o r --output-format csv -- python3 $R/bench.py --single-stream --steps 2 --warmup 1 --no-cpu-baseline --no-roofline > /dev/null 2>&1
 python3 $R/scripts/pmc_mfma.py /tmp/prof_mfma > $O/pmc_mfma.json 2>> $O/pmc_err.txt
-python3 $R/scripts/gemm_bench.py 24,27,25,28,29,23,31 > $O/gemm_variants.log 2>&1
-python3 $R/scripts/gemm_ksweep.py 25,28,24,27,31 >> $O/gemm_variants.log 2>&1
+python3 $R/scripts/gemm_bench.py 24,25,27,28,29 > $O/gemm_variants.log 2>&1
+python3 $R/scripts/gemm_bench.py 24,25,27,28,29 merged > $O/gemm_variants_merged.log 2>&1
+python3 $R/scripts/attn_bench.py > $O/attn_bench.log 2>&1
 tail -1 $O/bench_line.json | cut -c1-300
 cat $O/pmc_traffic.json $O/pmc_mfma.json
