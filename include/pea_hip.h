@@ -47,6 +47,16 @@ int pea_op_gemm(const void* A, int lda, const void* W, int ldw, void* C, int ldc
                 const float* bias, const void* rowvec, int ldrv, int rows_per_batch, int act, void* preact,
                 int ldpre, const void* res, int ldres, int out_f32, int accum_f32, void* stream);
 
+/* LayerNorm folded into the Linear that consumes it (UNet transformer blocks: norm1 -> to_q|k|v, norm2 -> attn2.to_q,
+ * norm3 -> ff.net.0.proj):  y = LN(x; gamma, beta, eps) . W^T + bias  computed as  rstd (x . W'^T - mean s) + t  with
+ * W' = W . gamma, s[n] = sum_k W'[n][k], t[n] = sum_k beta[k] W[n][k] + bias[n] -- one statistics pass over x and one
+ * GEMM on the un-normalised rows.  x bf16 [M][K]; W bf16 [N][K]; y bf16 [M][N]; geglu_y (optional) bf16 [M][N/2] =
+ * h * gelu(gate) for interleaved (h_i, gate_i) weight rows (y then receives the pre-activation, may be NULL).
+ * Caller-provided scratch: Wf bf16 [N][K], svec / tvec fp32 [N], stats fp32 [M][2].                      */
+int pea_op_ln_linear(const void* x, const float* gamma, const float* beta, const void* W, const float* bias, void* y,
+                     void* geglu_y, int M, int N, int K, float eps, void* Wf, float* svec, float* tvec, float* stats,
+                     void* stream);
+
 /* 3x3 convolution, padding 1, as implicit GEMM over an NHWC bf16 tensor x[B][Hs][Ws][Cin] with
  * packed weights w[Cout][(ky,kx,ci)] (see pea_op_pack_conv).  (ResnetBlock2D conv1/conv2,
  * Downsample2D, Upsample2D of the UNet called at train_sdxl_zh.py:397,415.)

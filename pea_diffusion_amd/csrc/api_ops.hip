@@ -47,6 +47,23 @@ int pea_op_gemm(const void* A, int lda, const void* W, int ldw, void* C, int ldc
   return launch_gemm(p, (hipStream_t)stream);
 }
 
+int pea_op_ln_linear(const void* x, const float* gamma, const float* beta, const void* W, const float* bias, void* y,
+                     void* geglu_y, int M, int N, int K, float eps, void* Wf, float* svec, float* tvec, float* stats,
+                     void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  int rc = launch_layernorm_stats((const bf16*)x, stats, M, K, eps, st);
+  if (rc) return rc;
+  rc = launch_ln_fold((const bf16*)W, K, gamma, beta, bias, (bf16*)Wf, svec, tvec, N, K, st);
+  if (rc) return rc;
+  GemmP p;
+  memset(&p, 0, sizeof(p));
+  p.A = (const bf16*)x; p.lda = K; p.W = (const bf16*)Wf; p.ldw = K; p.M = M; p.N = N; p.K = K; p.alpha = 1.f;
+  p.bias = tvec; p.rows_per_batch = 1; p.ln_stats = stats; p.ln_s = svec;
+  if (geglu_y) { p.geglu_y = (bf16*)geglu_y; p.ldy = N / 2; p.C = y; p.ldc = N; }
+  else { p.C = y; p.ldc = N; }
+  return launch_gemm(p, st);
+}
+
 int pea_op_conv3x3(const void* x, const void* w, void* y, int B, int Hs, int Ws, int Cin, int Cout, int stride,
                    int upsample2x, int transposed2, const float* bias, const void* rowvec, int ldrv,
                    const void* res, void* stream) {

@@ -237,7 +237,11 @@ __device__ __forceinline__ void gemm_epilogue16(const GemmP& p, f32x4 (&acc)[NT]
 // residual: MT x NT quads), then the arithmetic runs and all stores leave back to back: one load latency per tile.
 // Preconditions (launch_gemm sets p.epi_fast): !out_f32, act == 0, no preact, ldc % 8 == 0, C 16-byte aligned,
 // N % 16 == 0, and for a row vector rows_per_batch % (rows of a wave tile) == 0 (one batch sample per wave tile).
-template <int MT, int NT>
+// LNF (own kernel instantiations, so the common kernels keep their register allocation): the A operand is the
+// UN-normalised input of a LayerNorm folded into this GEMM -- W holds W' = W . gamma, p.bias holds t, and
+//   value = rstd[m] * (acc - mean[m] * s[n]) + t[n]        (p.ln_stats = [M][2] (mean, rstd), p.ln_s = s[N]);
+// such GEMMs have no residual and no row vector (QKV, attn2.to_q, FF projection with GEGLU).
+template <int MT, int NT, bool LNF = false>
 __device__ __forceinline__ void gemm_epilogue16_fast(const GemmP& p, f32x4 (&acc)[NT][MT], int m_base, int n_base, int r16,
                                                      int q4) {
   typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
@@ -251,20 +255,34 @@ __device__ __forceinline__ void gemm_epilogue16_fast(const GemmP& p, f32x4 (&acc
     for (int nt = 0; nt < NT; ++nt) bq[nt] = *(const f32x4*)(p.bias + min(n_base + nt * 16 + 4 * q4, p.N - 4));
   }
   bf16x4 rvq[NT];
-  if (p.rowvec) {
+  if (!LNF && p.rowvec) {
     const int bidx = min(m_base, p.M - 1) / p.rows_per_batch;          // uniform over the wave tile (precondition)
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
       rvq[nt] = *(const bf16x4*)(p.rowvec + (long long)bidx * p.ldrv + min(n_base + nt * 16 + 4 * q4, p.N - 4));
   }
-  if (p.rowvec) {
+  if (!LNF && p.rowvec) {
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
       for (int j = 0; j < 4; ++j) bq[nt][j] += (float)rvq[nt][j];
   }
-  const bool has_res = p.res != nullptr;
+  const bool has_res = !LNF && p.res != nullptr;
   const float alpha = p.alpha;
+  // folded LayerNorm: per row (c1, c2) = (rstd, -rstd * mean); v = c1 * acc + (c2 * s[n] + t[n])
+  f32x4 sq[LNF ? NT : 1];
+  float2 st[LNF ? MT : 1];
+  if constexpr (LNF) {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) sq[nt] = *(const f32x4*)(p.ln_s + min(n_base + nt * 16 + 4 * q4, p.N - 4));
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) st[mt] = *(const float2*)(p.ln_stats + 2 * (long long)min(m_base + mt * 16 + r16, p.M - 1));
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  auto val = [&](int nt, int mt, int j) -> float {
+    if constexpr (LNF) return st[mt].y * (acc[nt][mt][j] - st[mt].x * sq[nt][j]) + bq[nt][j];
+    else return acc[nt][mt][j] * alpha + bq[nt][j];
+  };
   if (p.geglu_y) {
     // v = (h_a, gate_a, h_b, gate_b) after bias: y = h * gelu(gate) -> geglu_y[m][n / 2]; the pre-activation goes to C
     // for the rows that will be differentiated (stash_rows) -- none for a teacher / inference pass (C == null)
@@ -282,13 +300,13 @@ __device__ __forceinline__ void gemm_epilogue16_fast(const GemmP& p, f32x4 (&acc
         if (n_base + nt * 16 >= p.N) continue;
         float v0[4], v1[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) v0[j] = acc[nt][mt][j] * alpha + bq[nt][j];
+        for (int j = 0; j < 4; ++j) v0[j] = val(nt, mt, j);
         union { bf16x2 h; unsigned u; } y0, y1;
         y0.h[0] = (bf16)(v0[0] * gelu_erf(v0[1]));
         y0.h[1] = (bf16)(v0[2] * gelu_erf(v0[3]));
         if (paired) {
 #pragma unroll
-          for (int j = 0; j < 4; ++j) v1[j] = acc[nt + 1][mt][j] * alpha + bq[nt + 1][j];
+          for (int j = 0; j < 4; ++j) v1[j] = val(nt + 1, mt, j);
           y1.h[0] = (bf16)(v1[0] * gelu_erf(v1[1]));
           y1.h[1] = (bf16)(v1[2] * gelu_erf(v1[3]));
           // lane row q4 receives the words of lane rows (q4 & ~1) and (q4 | 1) of n-tile nt + (q4 & 1): 8 contiguous bytes
@@ -343,14 +361,14 @@ __device__ __forceinline__ void gemm_epilogue16_fast(const GemmP& p, f32x4 (&acc
         union { bf16x4 h; unsigned u[2]; } a, b;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          float v = acc[nt][mt][j] * alpha + bq[nt][j];
+          float v = val(nt, mt, j);
           if (has_res) v += (float)rq[mt & 1][nt][j];
           a.h[j] = (bf16)v;
         }
         if (paired) {
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
-            float v = acc[nt + 1][mt][j] * alpha + bq[nt + 1][j];
+            float v = val(nt + 1, mt, j);
             if (has_res) v += (float)rq[mt & 1][nt + 1][j];
             b.h[j] = (bf16)v;
           }
@@ -416,7 +434,8 @@ __device__ __forceinline__ void gemm_epilogue16_lean(const GemmP& p, f32x4 (&acc
 //   consumer t: sub-steps 0..2 of tile t, lgkmcnt(0) -> barrier_t -> prefetch (t+1, 0), sub-step 3 of tile t
 // After barrier_t every consumer has issued and retired all reads of tile t's LDS slot, so the ring runs S
 // tiles ahead (all S slots in flight).
-template <int MODE, int BM, int BN, int WM, int WN, int LW, int S, bool PROBE16 = false, bool M16 = false, int MINW = 1>
+template <int MODE, int BM, int BN, int WM, int WN, int LW, int S, bool PROBE16 = false, bool M16 = false, int MINW = 1,
+          bool LNF = false>
 __global__ __launch_bounds__((WM * WN + LW) * 64, MINW) void gemm_lc_kernel(const GemmP p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int NWC = WM * WN;
@@ -584,6 +603,10 @@ __global__ __launch_bounds__((WM * WN + LW) * 64, MINW) void gemm_lc_kernel(cons
       }
       cur = nxt;
     }
+    if constexpr (LNF) {
+      gemm_epilogue16_fast<MT, NT, true>(p, acc, bm * BM + wr * (BM / WM), bn * BN + wc * (BN / WN), r16, q4);
+      return;
+    }
     if (p.epi_fast) {
       gemm_epilogue16_fast<MT, NT>(p, acc, bm * BM + wr * (BM / WM), bn * BN + wc * (BN / WN), r16, q4);
       return;
@@ -659,19 +682,20 @@ __global__ __launch_bounds__((WM * WN + LW) * 64, MINW) void gemm_lc_kernel(cons
   gemm_epilogue<MI, NI>(p, acc, bm * BM + wr * (BM / WM), bn * BN + wc * (BN / WN), frow, fh);
 }
 
-template <int MODE, int BM, int BN, int WM, int WN, int LW, int S, bool PROBE16 = false, bool M16 = false, int MINW = 1>
+template <int MODE, int BM, int BN, int WM, int WN, int LW, int S, bool PROBE16 = false, bool M16 = false, int MINW = 1,
+          bool LNF = false>
 static int launch_lc(const GemmP& p, hipStream_t stream) {
   constexpr int lds = S * (BM + BN) * 128;
   static_assert(lds <= 160 * 1024, "LDS budget");
   static bool attr_set = false;
   if (!attr_set) {
-    HIPCHK(hipFuncSetAttribute((const void*)gemm_lc_kernel<MODE, BM, BN, WM, WN, LW, S, PROBE16, M16, MINW>,
+    HIPCHK(hipFuncSetAttribute((const void*)gemm_lc_kernel<MODE, BM, BN, WM, WN, LW, S, PROBE16, M16, MINW, LNF>,
                                hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     attr_set = true;
   }
   const int grid = cdiv(p.M, BM) * cdiv(p.N, BN);
-  hipLaunchKernelGGL((gemm_lc_kernel<MODE, BM, BN, WM, WN, LW, S, PROBE16, M16, MINW>), dim3(grid, p.ksplit > 1 ? p.ksplit : 1),
-                     dim3((WM * WN + LW) * 64), lds, stream, p);
+  hipLaunchKernelGGL((gemm_lc_kernel<MODE, BM, BN, WM, WN, LW, S, PROBE16, M16, MINW, LNF>),
+                     dim3(grid, p.ksplit > 1 ? p.ksplit : 1), dim3((WM * WN + LW) * 64), lds, stream, p);
   return PEA_OK;
 }
 
@@ -695,8 +719,9 @@ static int launch_lc(const GemmP& p, hipStream_t stream) {
 // (scripts/gemm_epi_probe.py), disappears behind the main loop.
 // FASTONLY: only the batched-load epilogue is compiled in (the 256-row tiles: with both epilogues in one kernel the
 // register allocator spills around the tile transition); launch_gemm sends other epilogues to a 128-row variant.
-template <int MODE, int BM, int BN, int WM, int WN, int LW, int S, int SW = 0, int DF = 0, bool FASTONLY = false>
+template <int MODE, int BM, int BN, int WM, int WN, int LW, int S, int SW = 0, int DF = 0, int EPI = 0>
 __global__ __launch_bounds__((WM * WN + LW + SW) * 64) void gemm_lcp_kernel(const GemmP p) {
+  constexpr bool FASTONLY = EPI != 0;     // EPI 1: batched-load epilogue only; 2: the same with the folded LayerNorm
   constexpr int PITCH = BN * 2 + 16;                            // staging row pitch: conflict-free 8-byte writes
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int NWC = WM * WN;
@@ -1000,7 +1025,7 @@ __global__ __launch_bounds__((WM * WN + LW + SW) * 64) void gemm_lcp_kernel(cons
         // inside the epilogue instead of being hoisted to kernel entry and kept (spilled) across the whole tile loop
         int r16e = r16, q4e = q4;
         asm volatile("" : "+v"(r16e), "+v"(q4e));
-        gemm_epilogue16_fast<MT, NT>(p, acc, bm * BM + wr * (BM / WM), bn * BN + wc * (BN / WN), r16e, q4e);
+        gemm_epilogue16_fast<MT, NT, EPI == 2>(p, acc, bm * BM + wr * (BM / WM), bn * BN + wc * (BN / WN), r16e, q4e);
         // the next tile's first fragments were fetched at the last barrier already; fetching them AGAIN here makes that
         // copy dead across the epilogue, so its 36 registers are free for the residual quads (the K-loop body itself
         // stays as it was: a special-cased last K-step made the compiler peel the loop and spill fragments inside it)
@@ -1021,13 +1046,13 @@ __global__ __launch_bounds__((WM * WN + LW + SW) * 64) void gemm_lcp_kernel(cons
 }
 
 static int g_num_cus = 0;
-template <int MODE, int BM, int BN, int WM, int WN, int LW, int S, int SW = 0, int DF = 0, bool FASTONLY = false>
+template <int MODE, int BM, int BN, int WM, int WN, int LW, int S, int SW = 0, int DF = 0, int EPI = 0>
 static int launch_lcp(const GemmP& p, hipStream_t stream) {
   constexpr int lds = S * (BM + BN) * 128 + (SW ? BM * (BN * 2 + 16) : 0);
   static_assert(lds <= 160 * 1024, "LDS budget");
   static bool attr_set = false;
   if (!attr_set) {
-    HIPCHK(hipFuncSetAttribute((const void*)gemm_lcp_kernel<MODE, BM, BN, WM, WN, LW, S, SW, DF, FASTONLY>,
+    HIPCHK(hipFuncSetAttribute((const void*)gemm_lcp_kernel<MODE, BM, BN, WM, WN, LW, S, SW, DF, EPI>,
                                hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     attr_set = true;
   }
@@ -1039,8 +1064,8 @@ static int launch_lcp(const GemmP& p, hipStream_t stream) {
   SHAPECHK(p.ksplit <= 1, "gemm: the persistent kernel has no split-K path");
   const int tiles = cdiv(p.M, BM) * cdiv(p.N, BN);
   const int grid = tiles < g_num_cus ? tiles : g_num_cus;
-  SHAPECHK(!FASTONLY || p.epi_fast, "gemm: variant needs the batched-load epilogue");
-  hipLaunchKernelGGL((gemm_lcp_kernel<MODE, BM, BN, WM, WN, LW, S, SW, DF, FASTONLY>), dim3(grid),
+  SHAPECHK(EPI == 0 || p.epi_fast, "gemm: variant needs the batched-load epilogue");
+  hipLaunchKernelGGL((gemm_lcp_kernel<MODE, BM, BN, WM, WN, LW, S, SW, DF, EPI>), dim3(grid),
                      dim3((WM * WN + LW + SW) * 64), lds, stream, p);
   return PEA_OK;
 }
@@ -1058,12 +1083,12 @@ extern "C" void pea_debug_set_gemm_variant(int v) { g_gemm_variant = v; }
     case 23: rc = launch_lc<MODE, 128, 128, 2, 2, 4, 4, false, true>(p, stream); break; \
     case 24: rc = launch_lc<MODE, 256, 160, 4, 2, 4, 3, false, true>(p, stream); break; \
     case 25: rc = launch_lc<MODE, 128, 160, 4, 2, 4, 3, false, true>(p, stream); break; \
-    case 27: rc = launch_lcp<MODE, 256, 160, 4, 2, 4, 3, 0, 0, true>(p, stream); break; \
+    case 27: rc = launch_lcp<MODE, 256, 160, 4, 2, 4, 3, 0, 0, 1>(p, stream); break; \
     case 28: rc = launch_lcp<MODE, 128, 160, 4, 2, 4, 3>(p, stream); break; \
     case 29: rc = launch_lcp<MODE, 128, 160, 2, 2, 4, 4>(p, stream); break; \
     case 30: rc = launch_lcp<MODE, 128, 128, 2, 2, 4, 4>(p, stream); break; \
     case 31: rc = launch_lcp<MODE, 64, 160, 2, 2, 4, 4>(p, stream); break; \
-    case 33: rc = launch_lcp<MODE, 256, 128, 4, 2, 4, 3, 0, 0, true>(p, stream); break; \
+    case 33: rc = launch_lcp<MODE, 256, 128, 4, 2, 4, 3, 0, 0, 1>(p, stream); break; \
     case 34: rc = launch_lcp<MODE, 128, 160, 4, 2, 4, 3, 4>(p, stream); break; /* staged epilogue */ \
     case 35: rc = launch_lcp<MODE, 128, 160, 4, 2, 4, 3, 0, 1>(p, stream); break; /* deferred epilogue */ \
     default: rc = launch_lc<MODE, 128, 128, 2, 2, 4, 4, false, true>(p, stream); break; \
@@ -1149,6 +1174,22 @@ int launch_gemm(const GemmP& p_in, hipStream_t stream) {
     if (v == 33) v = 30;
   }
   int rc = PEA_OK;
+  if (p.ln_stats) {
+    // folded-LayerNorm instantiations of the five tile forms the shape rule can pick for a plain GEMM
+    SHAPECHK(p.epi_fast && p.ln_s && p.alpha == 1.f && p.mode == 0 && !p.res && !p.rowvec,
+             "gemm: the folded-LayerNorm epilogue needs the batched-load epilogue (bf16 output, no activation / residual)");
+    switch (v) {
+      case 27: rc = launch_lcp<0, 256, 160, 4, 2, 4, 3, 0, 0, 2>(p, stream); break;
+      case 24: rc = launch_lc<0, 256, 160, 4, 2, 4, 3, false, true, 1, true>(p, stream); break;
+      case 28: case 35: rc = launch_lcp<0, 128, 160, 4, 2, 4, 3, 0, 0, 2>(p, stream); break;
+      case 31: rc = launch_lcp<0, 64, 160, 2, 2, 4, 4, 0, 0, 2>(p, stream); break;
+      default: rc = launch_lc<0, 128, 160, 4, 2, 4, 3, false, true, 1, true>(p, stream); break;   // 25 and the rest
+    }
+    PROF_END(stream);
+    if (rc != PEA_OK) return rc;
+    HIPCHK(hipGetLastError());
+    return PEA_OK;
+  }
   if (p.mode == 0) { GEMM_VARIANTS(0) } else { GEMM_VARIANTS(1) }
   PROF_END(stream);
   if (rc != PEA_OK) return rc;

@@ -72,6 +72,21 @@ struct FusedMat {            // several Linear weights stacked along N sharing o
   bool need_wt = false, has_bias = false;
 };
 
+// A LayerNorm whose only consumer is a Linear is folded into it (UNet / ControlNet transformer blocks: norm1 -> fused QKV,
+// norm2 -> attn2.to_q, norm3 -> FF projection):  LN(x) . W^T + b = rstd (x . W'^T - mean s) + t  with W' = W . gamma,
+// s[n] = sum_k W'[n][k], t[n] = sum_k beta[k] W[n][k] + b[n].  Forward: a statistics-only pass over x and the GEMM on the
+// un-normalised rows (the normalised tensor is never written); backward: unchanged (dgrad with the original W^T, then the
+// LayerNorm backward from x and the statistics).
+struct LnFold {
+  int ln_op = -1, lin_op = -1;
+  int gamma = -1, beta = -1;         // LayerNorm weight slots
+  int w_slot = -1, fused = -1;       // the Linear's weight: a slot or a fused matrix
+  int bias_slot = -1;
+  int N = 0, K = 0;
+  bf16* wf = nullptr; float* s = nullptr; float* t = nullptr;
+  size_t off_wf = 0, off_s = 0, off_t = 0;
+};
+
 struct Tn {
   long long rows = 0; int cols = 0;
   int B = 0, H = 0, W = 0;
@@ -101,6 +116,7 @@ struct Op {
   float* aux = nullptr; size_t aux_off = 0, aux_bytes = 0;   // GN/LN stats, attention lse
   int src = 0;                    // OP_TEMB: 0 = timesteps, 1 = time_ids
   int mask = 0;                   // OP_ATTN: 1 causal, 2 per-sample key count (text encoders)
+  int fold = -1;                  // OP_LN / OP_LINEAR: index into Tape::folds (LayerNorm folded into the consuming Linear)
 };
 
 // The static op tape: tensors, weight slots and ops of ONE graph, built once per (config, batch, size).  graph selects the
@@ -127,6 +143,10 @@ struct Tape {
   std::deque<FusedMat> fused;
   std::vector<Tn> tn;
   std::vector<Op> ops;
+  std::vector<LnFold> folds;      // LayerNorm -> Linear folds; their W' / s / t live in the weight arena of the owner
+  bool fold_dirty = true;         // a weight was (re)loaded since the folds were last computed (owner only)
+  Tape* weights_owner = nullptr;  // set by share_weights_from
+  int ensure_folded(hipStream_t s);
   std::vector<int> taps;          // tensor ids: d0.., m, u0..
   std::vector<std::string> tap_names;   // "d0".., "m" (absent without a mid block), "u0"..
   int t_ehs = -1, t_text = -1, t_tproj = -1, t_out_in = -1, t_kvall = -1;

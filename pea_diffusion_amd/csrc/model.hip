@@ -171,6 +171,26 @@ struct Builder {
     return out;
   }
 
+  // fold the LayerNorm pushed as op `ln_idx` into the Linear pushed as op `lin_idx` (see LnFold).  Opt-in (PEA_LN_FOLD=1):
+  // measured in the SDXL step (B = 4, same box, profiles/r02_ln_fold_ab.txt) the LayerNorm family drops 6.22 -> 5.28 ms but
+  // the three consuming GEMMs per block pay 2.8 ms more for the heavier tile transition (s[n] quads + row statistics + one
+  // more FMA per element while the matrix pipes wait), so the separate kernel stays the default.
+  void fold_ln(int ln_idx, int lin_idx) {
+    static const bool off = !(getenv("PEA_LN_FOLD") && atoi(getenv("PEA_LN_FOLD")) == 1);
+    if (off || !(u.graph == 0 || u.graph == 2)) return;
+    Op& l = u.ops[ln_idx];
+    Op& g = u.ops[lin_idx];
+    if (l.kind != OP_LN || g.kind != OP_LINEAR || g.a != l.out || g.res >= 0) return;
+    LnFold f;
+    f.ln_op = ln_idx; f.lin_op = lin_idx; f.gamma = l.w; f.beta = l.bias;
+    f.K = u.tn[l.a].cols;
+    if (g.fused >= 0) { f.fused = g.fused; f.N = u.fused[g.fused].N; }
+    else { f.w_slot = g.w; f.bias_slot = g.bias; f.N = u.slots[g.w].st_n ? u.slots[g.w].st_n : u.slots[g.w].d0; }
+    if (f.N % 16 != 0 || f.K % 64 != 0) return;
+    u.folds.push_back(f);
+    l.fold = g.fold = (int)u.folds.size() - 1;
+  }
+
   int tproj_off = 0, kv_off = 0;
   int resnet(int x, const std::string& pfx, int cout) {
     const int cin = u.tn[x].cols;
@@ -195,8 +215,10 @@ struct Builder {
     for (int i = 0; i < depth; ++i) {
       const std::string bp = pfx + ".transformer_blocks." + std::to_string(i);
       int n1 = ln(h, bp + ".norm1");
+      const int ln1_idx = (int)u.ops.size() - 1;
       int qkv = fused_linear(n1, {bp + ".attn1.to_q", bp + ".attn1.to_k", bp + ".attn1.to_v"}, {Cp, Cp, Cp}, false, &vd3,
                              &vdp3);
+      fold_ln(ln1_idx, (int)u.ops.size() - 1);
       int a1 = T(t0.rows, Cp, t0.B, t0.H, t0.W);
       {
         Op& o = push(OP_ATTN);
@@ -206,7 +228,9 @@ struct Builder {
       }
       h = linear(a1, bp + ".attn1.to_out.0", C, true, h, padded ? 2 : 0, d, dp);
       int n2 = ln(h, bp + ".norm2");
+      const int ln2_idx = (int)u.ops.size() - 1;
       int q2 = linear(n2, bp + ".attn2.to_q", Cp, false, -1, padded ? 1 : 0, d, dp);
+      fold_ln(ln2_idx, (int)u.ops.size() - 1);
       // K|V of every cross-attention layer come from ONE GEMM over encoder_hidden_states (u.t_kvall)
       const int kv = u.t_kvall, kvo = kv_off;
       kv_off += 2 * Cp;
@@ -219,6 +243,7 @@ struct Builder {
       }
       h = linear(a2, bp + ".attn2.to_out.0", C, true, h, padded ? 2 : 0, d, dp);
       int n3 = ln(h, bp + ".norm3");
+      const int ln3_idx = (int)u.ops.size() - 1;
       // FF projection with GEGLU fused into the GEMM epilogue: weight rows interleaved (h_i, gate_i) at load time;
       // `g` = h * gelu(gate); the [rows][8C] pre-activation (op.c) is kept only when a backward pass will need it
       int g = T(t0.rows, 4 * C, t0.B, t0.H, t0.W);
@@ -230,6 +255,7 @@ struct Builder {
         Op& o = push(OP_LINEAR);
         o.a = n3; o.w = w; o.bias = bsl; o.out = g; o.c = hg; o.p3 = 3;
       }
+      fold_ln(ln3_idx, (int)u.ops.size() - 1);
       h = linear(g, bp + ".ff.net.2", C, true, h);
     }
     return linear(h, pfx + ".proj_out", C, true, x);
@@ -651,6 +677,11 @@ int Tape::alloc() {
         if (s.need_wt) { s.off_wt = off; off += al256(st * 2); }
       }
     }
+    for (LnFold& f : folds) {
+      f.off_wf = off; off += al256((size_t)f.N * f.K * 2);
+      f.off_s = off; off += al256((size_t)f.N * 4);
+      f.off_t = off; off += al256((size_t)f.N * 4);
+    }
     wbytes = off;
     if (!plan_only) {
     HIPCHK(hipMalloc((void**)&warena, wbytes));
@@ -678,6 +709,9 @@ int Tape::alloc() {
         s.wt = (bf16*)(warena + s.off_wt);
         s.ldwt = s.kind == W_CONV3 ? 9 * s.d0 : s.st_n;
       }
+    }
+    for (LnFold& f : folds) {
+      f.wf = (bf16*)(warena + f.off_wf); f.s = (float*)(warena + f.off_s); f.t = (float*)(warena + f.off_t);
     }
     tmp_f32_elems = max_numel;
     HIPCHK(hipMalloc((void**)&tmp_f32, tmp_f32_elems * 4));
@@ -809,6 +843,23 @@ int Tape::load_weight(const char* name, const float* src, long long numel, hipSt
       break;
   }
   w.loaded = true;
+  fold_dirty = true;
+  return PEA_OK;
+}
+
+// (re)compute W' / s / t of every folded LayerNorm from the current weights; blocks until they are in place, because
+// contexts that share these weights may read them from other streams
+int Tape::ensure_folded(hipStream_t s) {
+  if (weights_owner) return weights_owner->ensure_folded(s);
+  if (!fold_dirty || folds.empty()) { fold_dirty = false; return PEA_OK; }
+  for (LnFold& f : folds) {
+    const bf16* W; int ldw; const float* bias = nullptr;
+    if (f.fused >= 0) { W = fused[f.fused].w; ldw = fused[f.fused].K; if (fused[f.fused].has_bias) bias = fused[f.fused].bias; }
+    else { W = slots[f.w_slot].w; ldw = slots[f.w_slot].ldw; if (f.bias_slot >= 0) bias = slots[f.bias_slot].f32; }
+    RC(launch_ln_fold(W, ldw, slots[f.gamma].f32, slots[f.beta].f32, bias, f.wf, f.s, f.t, f.N, f.K, s));
+  }
+  HIPCHK(hipStreamSynchronize(s));
+  fold_dirty = false;
   return PEA_OK;
 }
 
@@ -845,6 +896,9 @@ int Tape::share_weights_from(const Tape& src) {
   for (size_t i = 0; i < fused.size(); ++i) {
     fused[i].w = src.fused[i].w; fused[i].wt = src.fused[i].wt; fused[i].bias = src.fused[i].bias;
   }
+  SHAPECHK(src.folds.size() == folds.size(), "unet: LayerNorm folds differ");
+  for (size_t i = 0; i < folds.size(); ++i) { folds[i].wf = src.folds[i].wf; folds[i].s = src.folds[i].s; folds[i].t = src.folds[i].t; }
+  weights_owner = src.weights_owner ? src.weights_owner : const_cast<Tape*>(&src);
   return PEA_OK;
 }
 
@@ -868,6 +922,7 @@ int Tape::forward(const float* x, const float* t, const void* ehs, int ehs_dtype
     return PEA_E_STATE;
   }
   RC(ensure_acts());
+  RC(ensure_folded(s));
   x_in = x; t_in = t; tid_in = time_ids; eps_out = eps;
   if (graph == 0 || graph == 2) {
     Tn& e = tn[t_ehs];
@@ -917,8 +972,13 @@ int Tape::exec_ops(size_t begin, size_t end, bool skip_cached, hipStream_t s) {
           if (bwd_batch > 0) p.stash_rows = (int)(out.rows / B * bwd_batch);   // only the differentiated samples are stashed
         }
         if (o.res >= 0) { p.res = tn[o.res].d; p.ldres = tn[o.res].cols; }
+        if (o.fold >= 0) {                // folded LayerNorm: the GEMM reads the un-normalised rows
+          const LnFold& f = folds[o.fold];
+          p.A = tn[ops[f.ln_op].a].d; p.W = f.wf; p.ldw = f.K; p.bias = f.t;
+          p.ln_stats = ops[f.ln_op].aux; p.ln_s = f.s;
+        }
         static const bool geglu_unfused = getenv("PEA_GEGLU_UNFUSED") != nullptr;   // A/B switch for experiments
-        if (o.p3 == 3 && geglu_unfused && o.c >= 0) {
+        if (o.p3 == 3 && geglu_unfused && o.c >= 0 && o.fold < 0) {
           p.geglu_y = nullptr; p.stash_rows = 0;
           RC(launch_gemm(p, s));
           RC(launch_geglu_fwd_il(tn[o.c].d, out.d, out.rows, out.cols, s));
@@ -993,6 +1053,10 @@ int Tape::exec_ops(size_t begin, size_t end, bool skip_cached, hipStream_t s) {
       }
       case OP_LN: {
         Tn& a = tn[o.a];
+        if (o.fold >= 0) {                // folded into its consumer: statistics only
+          RC(launch_layernorm_stats(a.d, o.aux, (int)a.rows, a.cols, o.f0, s));
+          break;
+        }
         RC(launch_layernorm_fwd(a.d, slots[o.w].f32, slots[o.bias].f32, tn[o.out].d, o.aux, (int)a.rows, a.cols, o.f0,
                                 s));
         break;

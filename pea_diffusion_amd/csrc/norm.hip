@@ -279,7 +279,9 @@ int launch_groupnorm_bwd(const bf16* x, const bf16* dy, const float* gamma, cons
 // wave (the kernels are latency-bound: 16 waves x 3 KB per CU did not cover the HBM latency), gamma / beta read
 // once per wave as 16-byte vectors.
 #define LN_NR 2
-template <int NCH>
+// STATS_ONLY: only (mean, rstd) per row -- the LayerNorms whose affine part is folded into the consuming GEMM
+// (Tape::fold_ln: the normalised tensor is never written)
+template <int NCH, bool STATS_ONLY = false>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const bf16* __restrict__ x, const float* __restrict__ gamma,
                                                      const float* __restrict__ beta, bf16* __restrict__ y,
                                                      float* __restrict__ stats, int R, int C, float eps) {
@@ -322,6 +324,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const bf16* __restrict__ x,
       stats[2 * (long long)(row0 + r) + 1] = rstd[r];
     }
   }
+  if constexpr (STATS_ONLY) return;
 #pragma unroll
   for (int i = 0; i < NCH; ++i) {
     const int ck = lane + 64 * i;
@@ -418,6 +421,56 @@ int launch_layernorm_fwd(const bf16* x, const float* gamma, const float* beta, b
   if (nch <= 1) LN_FWD(1); else if (nch == 2) LN_FWD(2); else if (nch == 3) LN_FWD(3); else if (nch == 4) LN_FWD(4); else LN_FWD(8);
 #undef LN_FWD
   PROF_END(s);
+  HIPCHK(hipGetLastError());
+  return PEA_OK;
+}
+
+int launch_layernorm_stats(const bf16* x, float* stats, int R, int C, float eps, hipStream_t s) {
+  SHAPECHK(C % 8 == 0 && C <= 64 * 8 * LN_MAXCH, "layernorm: C=%d unsupported", C);
+  PROF_BEGIN(5, 0.0, 2.0 * R * (double)C, s);
+  const int nch = cdiv(C / 8, 64);
+#define LN_ST(N) hipLaunchKernelGGL((ln_fwd_kernel<N, true>), dim3(cdiv(R, 4 * LN_NR)), dim3(256), 0, s, x, nullptr, nullptr, nullptr, stats, R, C, eps)
+  if (nch <= 1) LN_ST(1); else if (nch == 2) LN_ST(2); else if (nch == 3) LN_ST(3); else if (nch == 4) LN_ST(4); else LN_ST(8);
+#undef LN_ST
+  PROF_END(s);
+  HIPCHK(hipGetLastError());
+  return PEA_OK;
+}
+
+// LayerNorm folded into the Linear that consumes it:  LN(x) . W^T + b  =  rstd (x . W'^T - mean s) + t  with
+//   W'[n][k] = W[n][k] gamma[k] (bf16),   s[n] = sum_k W'[n][k],   t[n] = sum_k beta[k] W[n][k] + b[n].
+// One wave per output row n; s is summed over the ROUNDED W' (what the MFMA multiplies).
+__global__ __launch_bounds__(256) void ln_fold_kernel(const bf16* __restrict__ W, int ldw, const float* __restrict__ gamma,
+                                                      const float* __restrict__ beta, const float* __restrict__ bias,
+                                                      bf16* __restrict__ Wf, float* __restrict__ svec,
+                                                      float* __restrict__ tvec, int N, int K) {
+  const int lane = threadIdx.x & 63;
+  const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (n >= N) return;
+  float sa = 0.f, ta = 0.f;
+  for (int k = lane * 8; k < K; k += 512) {
+    const bf16x8 w = *(const bf16x8*)(W + (long long)n * ldw + k);
+    bf16x8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float wv = (float)w[j];
+      o[j] = (bf16)(wv * gamma[k + j]);
+      sa += (float)o[j];
+      ta += beta[k + j] * wv;
+    }
+    *(bf16x8*)(Wf + (long long)n * K + k) = o;
+  }
+  sa = wave_sum(sa);
+  ta = wave_sum(ta);
+  if (lane == 0) {
+    svec[n] = sa;
+    tvec[n] = ta + (bias ? bias[n] : 0.f);
+  }
+}
+int launch_ln_fold(const bf16* W, int ldw, const float* gamma, const float* beta, const float* bias, bf16* Wf, float* svec,
+                   float* tvec, int N, int K, hipStream_t s) {
+  SHAPECHK(K % 8 == 0 && ldw % 8 == 0, "ln fold: K=%d ldw=%d", K, ldw);
+  hipLaunchKernelGGL(ln_fold_kernel, dim3(cdiv(N, 4)), dim3(256), 0, s, W, ldw, gamma, beta, bias, Wf, svec, tvec, N, K);
   HIPCHK(hipGetLastError());
   return PEA_OK;
 }

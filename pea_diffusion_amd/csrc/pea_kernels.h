@@ -34,6 +34,9 @@ struct GemmP {
   int stash_rows;                  // GEGLU with a stash: rows >= stash_rows (> 0) skip the C store (merged passes: teacher rows)
   int ksplit; long long split_stride;   // split-K: fp32 partial s is written at C + s*split_stride (then launch_splitk_reduce)
   int epi_fast;                    // set by launch_gemm: the batched-load epilogue (gemm_epilogue16_fast) applies
+  // folded LayerNorm on the A operand (A = the UN-normalised rows, W = W' = W.gamma, bias = t):
+  //   value = rstd[m] * (acc - mean[m] * ln_s[n]) + bias[n];  ln_stats = [M][2] (mean, rstd).  Needs epi_fast.
+  const float* ln_stats; const float* ln_s;
 };
 int launch_splitk_reduce(const float* part, int nsplit, long long stride, bf16* out, int ldo, int M, int N, int accum,
                          hipStream_t s);
@@ -61,6 +64,10 @@ int launch_groupnorm_bwd(const bf16* x, const bf16* dy, const float* gamma, cons
 // LayerNorm over rows [R][C] (C % 8 == 0, C <= 4096); stats fp32 [R][2] = (mean, rstd)
 int launch_layernorm_fwd(const bf16* x, const float* gamma, const float* beta, bf16* y, float* stats, int R, int C,
                          float eps, hipStream_t s);
+// (mean, rstd) per row only; and the LayerNorm -> Linear fold (norm.hip: ln_fold_kernel)
+int launch_layernorm_stats(const bf16* x, float* stats, int R, int C, float eps, hipStream_t s);
+int launch_ln_fold(const bf16* W, int ldw, const float* gamma, const float* beta, const float* bias, bf16* Wf, float* svec,
+                   float* tvec, int N, int K, hipStream_t s);
 int launch_layernorm_bwd(const bf16* x, const bf16* dy, const float* gamma, const float* stats, bf16* dx,
                          float* dgamma, float* dbeta, int R, int C, const bf16* add, hipStream_t s);   // add: optional addend (may be dx)
 

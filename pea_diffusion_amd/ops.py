@@ -34,6 +34,22 @@ def gemm(a, w, bias=None, rowvec=None, rows_per_batch=1, act=0, res=None, want_p
     return (out, pre) if want_preact else out
 
 
+def ln_linear(x, gamma, beta, w, bias=None, eps=1e-5, geglu=False):
+    """LayerNorm folded into its consuming Linear (pea_op_ln_linear): x [M,K] bf16, w [N,K] bf16 -> LN(x) @ w.T + bias.
+    geglu=True: w rows interleaved (h_i, gate_i); returns (h * gelu(gate) [M,N/2], pre-activation [M,N])."""
+    M, K = x.shape
+    N = w.shape[0]
+    y = torch.empty(M, N, device=x.device, dtype=BF)
+    gy = torch.empty(M, N // 2, device=x.device, dtype=BF) if geglu else None
+    wf = torch.empty(N, K, device=x.device, dtype=BF)
+    sv = torch.empty(N, device=x.device, dtype=torch.float32)
+    tv = torch.empty(N, device=x.device, dtype=torch.float32)
+    st = torch.empty(M, 2, device=x.device, dtype=torch.float32)
+    check(lib().pea_op_ln_linear(ptr(x), ptr(gamma), ptr(beta), ptr(w), ptr(bias), ptr(y), ptr(gy), M, N, K, eps, ptr(wf),
+                                 ptr(sv), ptr(tv), ptr(st), stream_ptr()))
+    return (gy, y) if geglu else y
+
+
 def pack_conv(w_fp32, dgrad=False):
     Co, Ci = w_fp32.shape[:2]
     out = torch.empty((Ci, 9 * Co) if dgrad else (Co, 9 * Ci), device=w_fp32.device, dtype=BF)

@@ -61,6 +61,30 @@ def test_gemm_plain(ops, M, N, K):
     close_bf16(f"gemm {M}x{N}x{K}", out, a.float() @ w.float().T)
 
 
+@pytest.mark.parametrize("M,N,K,shift", [(8192, 3840, 1280, 0.0), (4096, 1280, 1280, 4.0), (1000, 640, 320, -2.5),
+                                          (77, 160, 64, 1.0)])
+def test_ln_linear_folded(ops, M, N, K, shift):
+    """LayerNorm folded into the consuming Linear (W' = W . gamma, s, t; statistics applied in the GEMM epilogue) against
+    LayerNorm -> Linear in fp32 on the same bf16 inputs; `shift` moves the row mean away from 0 (the folded form subtracts
+    mean * s[n] from the accumulator: cancellation must stay harmless).  Includes the fused GEGLU epilogue."""
+    g = torch.Generator().manual_seed(11)
+    x = (torch.randn(M, K, generator=g) * 1.3 + shift).to(BF)
+    w = bfr(N, K, seed=2, scale=K ** -0.5)
+    gamma = 1.0 + 0.2 * torch.randn(K, generator=g)
+    beta = 0.3 * torch.randn(K, generator=g)
+    bias = torch.randn(N, generator=g)
+    ln = F.layer_norm(x.float(), (K,), gamma, beta, 1e-5)
+    ref = ln @ w.float().T + bias
+    out = ops.ln_linear(x.cuda(), gamma.cuda(), beta.cuda(), w.cuda(), bias.cuda())
+    close_bf16(f"ln_linear {M}x{N}x{K} shift {shift}", out, ref, ulps=2.0)
+    out_nb = ops.ln_linear(x.cuda(), gamma.cuda(), beta.cuda(), w.cuda(), None)
+    close_bf16(f"ln_linear no-bias {M}x{N}x{K}", out_nb, ln @ w.float().T, ulps=2.0)
+    gy, pre = ops.ln_linear(x.cuda(), gamma.cuda(), beta.cuda(), w.cuda(), bias.cuda(), geglu=True)
+    close_bf16(f"ln_linear geglu preact {M}x{N}x{K}", pre, ref, ulps=2.0)
+    # y = h * gelu(gate): the rounding of BOTH factors enters (W. gamma is rounded to bf16 once more than in the unfolded form)
+    close_bf16(f"ln_linear geglu y {M}x{N}x{K}", gy, ref[:, 0::2] * F.gelu(ref[:, 1::2]), ulps=3.0)
+
+
 def test_gemm_epilogues(ops):
     M, N, K, rpb = 192, 256, 128, 48
     a, w = bfr(M, K, seed=1), bfr(N, K, seed=2, scale=K ** -0.5)
