@@ -223,3 +223,17 @@ def test_ssd1b_1024_properties(gpu):
     tr = PEATrainer(ad, student, teacher)
     _properties(tr, ad, B, hw, L, same_weights=False)
     assert lib_merge_state(tr) == -1
+
+
+def test_layernorm_fold_opt_in_matches_oracle(gpu):
+    """PEA_LN_FOLD=1 (read once per process, so this runs the tiny forward / training-step parity tests in a child
+    process): LayerNorm folded into the consuming Linear -- statistics pass + W.gamma / s / t -- must meet the same
+    oracle tolerances as the default path."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_model_gpu.py"), "-m", "gpu", "-x", "-q",
+                        "-k", "unet_forward_tiny or unet_backward_tiny or training_step_vs_oracle or merged_passes"],
+                       capture_output=True, text=True, timeout=900, env=dict(os.environ, PEA_LN_FOLD="1"), cwd=root)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout and "failed" not in r.stdout
