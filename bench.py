@@ -456,7 +456,8 @@ def main():
                        "parallelism": f"dp{world}",
                        "per_gpu_batch_rule": "4 at N=1 (BASELINE configs[1]); 8 at N>1 (configs[2]: global 64 = 8 x 8)",
                        "weights": ("random init (teacher == student checkpoint)" if args.student == "same" else
-                                   "random init, SSD-1B-shaped student (transformer depths 1/2/4) under the SDXL teacher"),
+                                   "random init, SSD-1B student (per-position depths [2,2],[4,4] down / [4,4,10],[2,1,1] up, no mid "
+                                   "block; 1 300 195 844 parameters) under the SDXL teacher"),
                        "loss": round(loss, 6),
                        **({"vae_encode": f"next batch's {hw * 8}x{hw * 8} VAE encode on a side HIP stream inside every step"}
                           if args.with_vae else {})},
