@@ -231,18 +231,29 @@ int pea_controlnet_export_nchw(void* cn, int i, float* dst, void* stream);   /* 
  * Chinese-CLIP text tower (train_sdxl_zh.py:103-107; `self.text_encoder.encode_text(batch["input_ids"])` :327-329 returns
  * the per-token states): post-LN, right-padding mask from pad id `eos_id`.  head_dim must be 64 (true for all three).
  * forward: ids int64 [B,L] device; hidden_index -1 = last state (CLIP: after the final LayerNorm), -2 = hidden_states[-2],
- * k >= 0 = hidden_states[k]; hidden_out fp32 [B,L,width] and / or pooled_out fp32 [B,proj_dim] (CLIP only). */
+ * k >= 0 = hidden_states[k]; hidden_out fp32 [B,L,width] and / or pooled_out fp32 [B,proj_dim] (CLIP only).
+ * flavor 2 = T5 encoder stack -- the mT5 student option (`T5EncoderModel.from_pretrained('mt5-xl')`, train_sdxl_zh.py:108-112;
+ * `self.text_encoder.encoder(ids, attention_mask=ids.ne(pad))[0]` :337-345; HF keys `shared.weight`, `encoder.block.N.*`,
+ * `encoder.final_layer_norm.weight`): token embedding only, pre-RMSNorm blocks, scores = q.k (unscaled) + bucketed
+ * relative-position bias of block 0, right-padding mask from pad id `eos_id`, gated FF wo(gelu_new(wi_0 x) * wi_1 x);
+ * `intermediate` = d_ff; inner attention width = heads * 64 (d_kv must be 64).  hidden_index -1 = after the final RMSNorm. */
 typedef struct pea_text_config {
   int vocab, max_pos, width, heads, layers, intermediate;
   int act;          /* 1 GELU(erf), 3 quick-GELU */
-  int flavor;       /* 0 CLIP, 1 BERT */
+  int flavor;       /* 0 CLIP, 1 BERT, 2 T5 encoder (mT5: RMSNorm, relative position bias, unscaled scores, gated gelu_new FF) */
   int proj_dim;     /* CLIP text_projection width, 0 = none */
   float eps;
   int pos_offset;   /* position row = token index + pos_offset: 2 for RoBERTa / XLM-R towers (mul_clip, alt_clip), else 0 */
-  long long eos_id; /* CLIP: EOS id (< 0: argmax of the ids); BERT: pad id */
+  long long eos_id; /* CLIP: EOS id (< 0: argmax of the ids); BERT / T5: pad id */
+  int rel_buckets;  /* T5: relative_attention_num_buckets (32) */
+  int rel_max_dist; /* T5: relative_attention_max_distance (128) */
 } pea_text_config;
 int pea_text_create(const pea_text_config* cfg, int B, int L, void** out);
 int pea_text_forward(void* enc, const long long* ids, int hidden_index, float* hidden_out, float* pooled_out, void* stream);
+/* T5 flavour only: the additive attention bias the encoder uses, bias_out fp32 [heads][L][L] =
+ * relative_attention_bias[bucket(k - q)][h] * log2(e) (HF T5Attention.compute_bias; the attention kernels work in the
+ * log2 domain).  Diagnostic read-back for the bucket parity test. */
+int pea_text_rel_bias(void* enc, float* bias_out, void* stream);
 
 /* VAE encoder (AutoencoderKL.encode, train_sdxl_zh.py:306-309; train_sd_zh.py:188-189) on the same op tape: cfg uses
  * in_channels (3), out_channels (2 * latent channels = 8), n_levels, block_out, layers_per_block, groups, eps.

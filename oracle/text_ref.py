@@ -127,3 +127,93 @@ class BertTextRef(nn.Module):
             x = lyr(x, mask)
             hs.append(x)
         return {"hidden_states": hs, "last_hidden_state": x}
+
+
+class _T5Norm(nn.Module):
+    """T5LayerNorm: x * rsqrt(mean(x^2) + eps) * weight (no mean subtraction, no bias)"""
+
+    def __init__(self, w, eps):
+        super().__init__()
+        self.weight = nn.Parameter(torch.ones(w))
+        self.eps = eps
+
+    def forward(self, x):
+        return self.weight * (x * torch.rsqrt(x.pow(2).mean(-1, keepdim=True) + self.eps))
+
+
+def t5_relative_bucket(rel, num_buckets, max_distance):
+    """bidirectional bucket of rel = key_pos - query_pos (T5Attention._relative_position_bucket, encoder form): half the
+    buckets per sign; within a sign the first half are exact offsets, the rest log-spaced up to max_distance"""
+    nb = num_buckets // 2
+    out = (rel > 0).long() * nb
+    n = rel.abs()
+    max_exact = nb // 2
+    large = max_exact + (torch.log(n.float() / max_exact) / math.log(max_distance / max_exact) * (nb - max_exact)).long()
+    large = torch.min(large, torch.full_like(large, nb - 1))
+    return out + torch.where(n < max_exact, n, large)
+
+
+class _T5Block(nn.Module):
+    def __init__(self, w, heads, d_kv, d_ff, eps, buckets):
+        super().__init__()
+        inner = heads * d_kv
+        att = nn.Module()
+        att.SelfAttention = nn.Module()
+        for n in ("q", "k", "v"):
+            setattr(att.SelfAttention, n, nn.Linear(w, inner, bias=False))
+        att.SelfAttention.o = nn.Linear(inner, w, bias=False)
+        if buckets:
+            att.SelfAttention.relative_attention_bias = nn.Embedding(buckets, heads)
+        att.layer_norm = _T5Norm(w, eps)
+        ff = nn.Module()
+        ff.DenseReluDense = nn.Module()
+        ff.DenseReluDense.wi_0, ff.DenseReluDense.wi_1 = nn.Linear(w, d_ff, bias=False), nn.Linear(w, d_ff, bias=False)
+        ff.DenseReluDense.wo = nn.Linear(d_ff, w, bias=False)
+        ff.layer_norm = _T5Norm(w, eps)
+        self.layer = nn.ModuleList([att, ff])
+        self.heads, self.d_kv = heads, d_kv
+
+    def forward(self, x, bias):
+        B, L, _ = x.shape
+        a, f = self.layer[0], self.layer[1]
+        n = a.layer_norm(x)
+        sp = lambda t: t.view(B, L, self.heads, self.d_kv).transpose(1, 2)
+        q, k, v = sp(a.SelfAttention.q(n)), sp(a.SelfAttention.k(n)), sp(a.SelfAttention.v(n))
+        s = q @ k.transpose(-1, -2) + bias                          # no 1/sqrt(d): folded into T5's initialisation
+        o = (torch.softmax(s, -1) @ v).transpose(1, 2).reshape(B, L, self.heads * self.d_kv)
+        x = x + a.SelfAttention.o(o)
+        n = f.layer_norm(x)
+        g = F.gelu(f.DenseReluDense.wi_0(n), approximate="tanh") * f.DenseReluDense.wi_1(n)     # gated gelu_new
+        return x + f.DenseReluDense.wo(g)
+
+
+class T5EncoderRef(nn.Module):
+    """the encoder stack of HF `T5EncoderModel` in its T5 v1.1 / mT5 form (gated-gelu FF), the student text tower of
+    `--text_encoder mt5` (train_sdxl_zh.py:108-112; call site :331-345 -- `encoder(ids, attention_mask=ids.ne(pad))[0]`).
+    keys: shared.weight, encoder.block.N.layer.{0,1}.*, encoder.final_layer_norm.weight (d_kv = 64)"""
+
+    def __init__(self, cfg, d_kv=64):
+        super().__init__()
+        self.cfg = cfg
+        w = cfg.hidden_size
+        self.shared = nn.Embedding(cfg.vocab_size, w)
+        self.encoder = nn.Module()
+        self.encoder.block = nn.ModuleList([
+            _T5Block(w, cfg.num_attention_heads, d_kv, cfg.intermediate_size, cfg.layer_norm_eps,
+                     cfg.relative_attention_num_buckets if i == 0 else 0) for i in range(cfg.num_hidden_layers)])
+        self.encoder.final_layer_norm = _T5Norm(w, cfg.layer_norm_eps)
+
+    def forward(self, ids):
+        B, L = ids.shape
+        c = self.cfg
+        x = self.shared(ids)
+        pos = torch.arange(L)
+        bucket = t5_relative_bucket(pos[None, :] - pos[:, None], c.relative_attention_num_buckets, c.relative_attention_max_distance)
+        bias = self.encoder.block[0].layer[0].SelfAttention.relative_attention_bias(bucket).permute(2, 0, 1)[None]   # [1,H,L,L]
+        valid = ids != c.eos_token_id                              # pad id; right padding
+        bias = bias + torch.zeros(B, 1, 1, L).masked_fill(~valid[:, None, None, :], float("-inf"))
+        hs = [x]
+        for blk in self.encoder.block:
+            x = blk(x, bias)
+            hs.append(x)
+        return {"hidden_states": hs, "last_hidden_state": self.encoder.final_layer_norm(x)}

@@ -256,11 +256,13 @@ class TextConfig:
     num_hidden_layers: int = 12
     intermediate_size: int = 3072
     hidden_act: str = "quick_gelu"          # "quick_gelu" | "gelu"
-    flavor: str = "clip"                    # "clip" (pre-LN, causal, EOS pooling) | "bert" (post-LN, padding mask)
+    flavor: str = "clip"                    # "clip" (pre-LN, causal, EOS pooling) | "bert" (post-LN, padding mask) | "t5" (encoder stack)
     projection_dim: int = 0
     layer_norm_eps: float = 1e-5
     eos_token_id: int = -1                  # clip: EOS id (-1: argmax of the ids, the original CLIP vocabulary); bert: pad id
     position_offset: int = 0                # RoBERTa / XLM-R: 2 (position = padding_idx + 1 + index)
+    relative_attention_num_buckets: int = 32    # t5 only
+    relative_attention_max_distance: int = 128  # t5 only
     name: str = "clip_l"
 
 
@@ -291,6 +293,20 @@ def tiny_xlmr_config() -> TextConfig:
                       eos_token_id=1, position_offset=2, name="tiny_xlmr")
 
 
+def mt5_xl_config() -> TextConfig:
+    """google/mt5-xl encoder (`T5EncoderModel.from_pretrained('mt5-xl')`, train_sdxl_zh.py:108-112): d_model 2048,
+    32 heads x d_kv 64, d_ff 5120, 24 blocks, gated gelu_new, pad id 0; the trainer tokenises to 77 tokens (:333-339)"""
+    return TextConfig(vocab_size=250112, max_position_embeddings=77, hidden_size=2048, num_attention_heads=32,
+                      num_hidden_layers=24, intermediate_size=5120, hidden_act="gelu_new", flavor="t5", layer_norm_eps=1e-6,
+                      eos_token_id=0, name="mt5_xl")
+
+
+def tiny_t5_config() -> TextConfig:
+    return TextConfig(vocab_size=1000, max_position_embeddings=40, hidden_size=128, num_attention_heads=3,
+                      num_hidden_layers=2, intermediate_size=256, hidden_act="gelu_new", flavor="t5", layer_norm_eps=1e-6,
+                      eos_token_id=0, relative_attention_num_buckets=8, relative_attention_max_distance=20, name="tiny_t5")
+
+
 def tiny_clip_config() -> TextConfig:
     return TextConfig(vocab_size=1000, max_position_embeddings=77, hidden_size=128, num_attention_heads=2,
                       num_hidden_layers=3, intermediate_size=512, projection_dim=64, eos_token_id=999, name="tiny_clip")
@@ -305,15 +321,18 @@ def tiny_bert_config() -> TextConfig:
 class CTextConfig(ctypes.Structure):
     _fields_ = [("vocab", ctypes.c_int), ("max_pos", ctypes.c_int), ("width", ctypes.c_int), ("heads", ctypes.c_int),
                 ("layers", ctypes.c_int), ("intermediate", ctypes.c_int), ("act", ctypes.c_int), ("flavor", ctypes.c_int),
-                ("proj_dim", ctypes.c_int), ("eps", ctypes.c_float), ("pos_offset", ctypes.c_int), ("eos_id", ctypes.c_longlong)]
+                ("proj_dim", ctypes.c_int), ("eps", ctypes.c_float), ("pos_offset", ctypes.c_int), ("eos_id", ctypes.c_longlong),
+                ("rel_buckets", ctypes.c_int), ("rel_max_dist", ctypes.c_int)]
 
 
 def text_to_c(cfg) -> CTextConfig:
     c = CTextConfig()
     c.vocab, c.max_pos, c.width = cfg.vocab_size, cfg.max_position_embeddings, cfg.hidden_size
     c.heads, c.layers, c.intermediate = cfg.num_attention_heads, cfg.num_hidden_layers, cfg.intermediate_size
-    c.act = {"quick_gelu": 3, "gelu": 1}[cfg.hidden_act]
-    c.flavor = {"clip": 0, "bert": 1}[cfg.flavor]
+    c.act = {"quick_gelu": 3, "gelu": 1, "gelu_new": 1}[cfg.hidden_act]      # t5: the gate's gelu_new is fixed by the flavor
+    c.flavor = {"clip": 0, "bert": 1, "t5": 2}[cfg.flavor]
+    c.rel_buckets = getattr(cfg, "relative_attention_num_buckets", 32)
+    c.rel_max_dist = getattr(cfg, "relative_attention_max_distance", 128)
     c.proj_dim, c.eps, c.eos_id = cfg.projection_dim, cfg.layer_norm_eps, cfg.eos_token_id
     c.pos_offset = getattr(cfg, "position_offset", 0)
     return c

@@ -220,8 +220,13 @@ int pea_text_forward(void* h, const long long* ids, int hidden_index, float* hid
   }
   { int rc0 = u->ensure_acts(); if (rc0 != PEA_OK) return rc0; }
   u->ids_in = ids;
-  if (u->tcfg.flavor == 1) {
+  if (u->tcfg.flavor >= 1) {
     int rc = launch_kv_len(ids, u->kvlen, u->B, u->L, u->tcfg.eos_id, s);
+    if (rc != PEA_OK) return rc;
+  }
+  if (u->tcfg.flavor == 2) {          // block 0's bucket table -> [heads][L][pitch] additive score bias (cheap; weights may have changed)
+    int rc = launch_t5_rel_bias(u->slots[u->w_rel].f32, u->rel_bucket, u->rel_bias, u->tcfg.heads, u->L, ((u->L + 63) >> 6) << 6,
+                                u->tcfg.rel_buckets / 2, s);
     if (rc != PEA_OK) return rc;
   }
   int rc = u->exec_ops(0, u->ops.size(), false, s);
@@ -243,6 +248,21 @@ int pea_text_forward(void* h, const long long* ids, int hidden_index, float* hid
     rc = launch_cast_bf16_f32(t.d, pooled_out, t.rows * t.cols, s);
     if (rc != PEA_OK) return rc;
   }
+  return PEA_OK;
+}
+int pea_text_rel_bias(void* h, float* bias_out, void* stream) {
+  NOTNULL(h, "pea_text_rel_bias");
+  NOTNULL(bias_out, "pea_text_rel_bias");
+  Tape* u = (Tape*)h;
+  if (u->graph != 4 || u->tcfg.flavor != 2) { pea_set_error("pea_text_rel_bias: not a T5 encoder handle"); return PEA_E_INVALID; }
+  if (!u->slots[u->w_rel].loaded) { pea_set_error("pea_text_rel_bias: the bias table was never loaded"); return PEA_E_STATE; }
+  hipStream_t s = (hipStream_t)stream;
+  { int rc0 = u->ensure_acts(); if (rc0 != PEA_OK) return rc0; }
+  const int L = u->L, pitch = ((L + 63) >> 6) << 6;
+  int rc = launch_t5_rel_bias(u->slots[u->w_rel].f32, u->rel_bucket, u->rel_bias, u->tcfg.heads, L, pitch, u->tcfg.rel_buckets / 2, s);
+  if (rc != PEA_OK) return rc;
+  HIPCHK(hipMemcpy2DAsync(bias_out, sizeof(float) * L, u->rel_bias, sizeof(float) * pitch, sizeof(float) * L,
+                          (size_t)u->tcfg.heads * L, hipMemcpyDeviceToDevice, s));
   return PEA_OK;
 }
 int pea_unet_destroy(void* h) {

@@ -260,6 +260,24 @@ __device__ __forceinline__ void attn_q_body(const AttnP& p, char* smem, int blk_
       // so the UNet's kernel keeps its register budget
       int skv_b = p.Skv;
       if constexpr (TXT) skv_b = p.kv_len ? p.kv_len[b] : p.Skv;
+      float cc = c;                     // factor between the values in sacc and the log2 domain
+      if constexpr (TXT) {
+        if (p.bias) {
+          // additive score bias (T5 relative positions), given in the log2 domain with a row pitch of 64 * ceil(Skv / 64):
+          // scores move to the log2 domain here (t = c s + bias), the softmax below then runs with a factor of 1
+          const int pitch = ((p.Skv + 63) >> 6) << 6;
+          const float* brow = p.bias + ((long long)head * p.Sq + qrow) * pitch + kv0 + 4 * fh;
+#pragma unroll
+          for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+              const f32x4 bv = *(const f32x4*)(brow + kb * 32 + 8 * g);
+#pragma unroll
+              for (int j = 0; j < 4; ++j) sacc[kb][4 * g + j] = fmaf(sacc[kb][4 * g + j], c, bv[j]);
+            }
+          cc = 1.0f;
+        }
+      }
       const bool boundary = (TXT && p.causal) || kv0 + 64 > skv_b;   // wave-uniform
       if (boundary) {
         int kmax = skv_b;
@@ -278,18 +296,18 @@ __device__ __forceinline__ void attn_q_body(const AttnP& p, char* smem, int blk_
       mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
       const float m_new = fmaxf(m_run, mx);
       const bool moved = m_new != m_run;
-      const float mc = m_new * c;
+      const float mc = m_new * cc;
       float ls = 0.f;
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const float e = fast_exp2(fmaf(sacc[kb][r], c, -mc));
+          const float e = fast_exp2(fmaf(sacc[kb][r], cc, -mc));
           sacc[kb][r] = e;
           ls += e;
         }
       if (__any(moved)) {
-        const float alpha = fast_exp2((m_run - m_new) * c);   // m_run = -inf on the first tile -> 0
+        const float alpha = fast_exp2((m_run - m_new) * cc);   // m_run = -inf on the first tile -> 0
         l_run *= alpha;
 #pragma unroll
         for (int i = 0; i < 2 * NO; ++i)
@@ -715,7 +733,7 @@ static int attn_fwd_nd(const AttnP& p, hipStream_t s) {
   int rc = attn_set_lds_attr<ND>();
   if (rc) return rc;
   const dim3 grid(cdiv(p.Sq, 128), p.H, p.B);
-  if (p.causal || p.kv_len) {                 // text-encoder masks: separate instance (head_dim 64 only)
+  if (p.causal || p.kv_len || p.bias) {       // text-encoder masks / score bias: separate instance (head_dim 64 only)
     SHAPECHK(ND == 1, "attention: causal / key-length masks need head_dim 64");
     if constexpr (ND == 1) {
       static bool attr = false;

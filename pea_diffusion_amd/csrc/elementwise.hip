@@ -675,6 +675,10 @@ __global__ void embed_tokens_kernel(const long long* __restrict__ ids, const bf1
     long long id = ids[r];
     id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
     const bf16x8 t = *(const bf16x8*)(tok + id * width + c * 8);
+    if (!pos) {                                  // T5: token embedding only (positions enter as an attention bias)
+      *(bf16x8*)(out + r * width + c * 8) = t;
+      continue;
+    }
     const bf16x8 p = *(const bf16x8*)(pos + (long long)l * width + c * 8);
     bf16x8 o;
     if (type0) {
@@ -693,6 +697,27 @@ int launch_embed_tokens(const long long* ids, const bf16* tok, const bf16* pos, 
   SHAPECHK(width % 8 == 0, "embed: width %% 8");
   hipLaunchKernelGGL(embed_tokens_kernel, dim3(EW_GRID((long long)B * L * width / 8)), dim3(256), 0, s, ids, tok, pos,
                      type0, out, B, L, width, vocab);
+  HIPCHK(hipGetLastError());
+  return PEA_OK;
+}
+// T5 relative position bias (HF T5Attention.compute_bias / _relative_position_bucket, bidirectional): bias[h][q][k] =
+// rel[bucket(k - q)][h] * log2(e)  (the attention kernel works in the log2 domain); rel: fp32 [num_buckets][H];
+// bucket(d) = (d > 0 ? num_buckets/2 : 0) + dist_bucket[|d|], the |d| -> sub-bucket table is computed on the host
+// (Tape::alloc) so that the log-spaced bucket edges round exactly as the CPU reference's fp32 arithmetic does
+__global__ void t5_rel_bias_kernel(const float* __restrict__ rel, const int* __restrict__ dist_bucket,
+                                   float* __restrict__ bias, int H, int L, int pitch, int half_buckets) {
+  const long long total = (long long)H * L * L;
+  EW_LOOP(i, total) {
+    const int k = (int)(i % L), q = (int)((i / L) % L), h = (int)(i / ((long long)L * L));
+    const int rp = k - q;
+    const int bucket = (rp > 0 ? half_buckets : 0) + dist_bucket[rp < 0 ? -rp : rp];
+    bias[((long long)h * L + q) * pitch + k] = rel[(long long)bucket * H + h] * 1.4426950408889634f;
+  }
+}
+int launch_t5_rel_bias(const float* rel, const int* dist_bucket, float* bias, int H, int L, int pitch, int half_buckets,
+                       hipStream_t s) {
+  hipLaunchKernelGGL(t5_rel_bias_kernel, dim3(EW_GRID((long long)H * L * L)), dim3(256), 0, s, rel, dist_bucket, bias, H, L,
+                     pitch, half_buckets);
   HIPCHK(hipGetLastError());
   return PEA_OK;
 }

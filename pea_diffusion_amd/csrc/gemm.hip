@@ -66,8 +66,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x16 (&acc)[NI][
         }
         if (p.geglu_y) {            // v = (h_a, gate_a, h_b, gate_b) after bias
           bf16x2 y;
-          y[0] = (bf16)(v[0] * gelu_erf(v[1]));
-          y[1] = (bf16)(v[2] * gelu_erf(v[3]));
+          y[0] = (bf16)(v[0] * (p.geglu_tanh ? gelu_tanh(v[1]) : gelu_erf(v[1])));
+          y[1] = (bf16)(v[2] * (p.geglu_tanh ? gelu_tanh(v[3]) : gelu_erf(v[3])));
           *(bf16x2*)(p.geglu_y + (long long)m * p.ldy + (n >> 1)) = y;
           if (!p.C || (p.stash_rows > 0 && m >= p.stash_rows)) continue;
         }
@@ -151,8 +151,8 @@ __device__ __forceinline__ void gemm_epilogue16(const GemmP& p, f32x4 (&acc)[NT]
     }
     if (p.geglu_y) {            // v = (h_a, gate_a, h_b, gate_b) after bias
       bf16x2 y;
-      y[0] = (bf16)(v[0] * gelu_erf(v[1]));
-      y[1] = (bf16)(v[2] * gelu_erf(v[3]));
+      y[0] = (bf16)(v[0] * (p.geglu_tanh ? gelu_tanh(v[1]) : gelu_erf(v[1])));
+      y[1] = (bf16)(v[2] * (p.geglu_tanh ? gelu_tanh(v[3]) : gelu_erf(v[3])));
       *(bf16x2*)(p.geglu_y + (long long)m * p.ldy + (n >> 1)) = y;
       if (!p.C || (p.stash_rows > 0 && m >= p.stash_rows)) return false;
     }
@@ -1168,7 +1168,7 @@ int launch_gemm(const GemmP& p_in, hipStream_t stream) {
     // wave-tile rows of the 16x16x32 kernels are 32 or 64: a per-sample row vector must not change inside them
     static const bool slow_epi = getenv("PEA_GEMM_SLOW_EPILOGUE") != nullptr;     // A/B switch
     const bool rv_ok = !p.rowvec || (p.rows_per_batch % 64 == 0);
-    const bool gg_ok = !p.geglu_y || (p.ldy % 4 == 0 && (((unsigned long long)p.geglu_y & 7) == 0) && !p.res && !p.rowvec);
+    const bool gg_ok = !p.geglu_y || (p.ldy % 4 == 0 && (((unsigned long long)p.geglu_y & 7) == 0) && !p.res && !p.rowvec && !p.geglu_tanh);
     p.epi_fast = !slow_epi && !p.out_f32 && p.act == 0 && !p.preact && p.ksplit <= 1 && p.N % 16 == 0 && rv_ok && gg_ok &&
                  (p.geglu_y ? (!p.C || (p.ldc % 8 == 0 && (((unsigned long long)p.C & 15) == 0)))
                             : (p.ldc % 8 == 0 && (((unsigned long long)p.C & 15) == 0))) &&

@@ -36,11 +36,13 @@ void normalize_depths(PeaUnetCfg& c);
 struct PeaTextCfg {          // mirrors `pea_text_config` of include/pea_hip.h
   int vocab, max_pos, width, heads, layers, intermediate;
   int act;                   // GEMM epilogue activation of the MLP: 1 GELU(erf), 3 quick-GELU
-  int flavor;                // 0: CLIP text model (pre-LN, causal, final LN, EOS pooling), 1: BERT (post-LN, key padding)
+  int flavor;                // 0: CLIP text model (pre-LN, causal, final LN, EOS pooling), 1: BERT (post-LN, key padding), 2: T5 encoder
   int proj_dim;              // CLIP text_projection width (0: none)
   float eps;
   int pos_offset;            // position row = token index + pos_offset (RoBERTa / XLM-R: 2, else 0)
-  long long eos_id;          // CLIP: EOS token id (< 0: argmax of the ids);  BERT: pad token id
+  long long eos_id;          // CLIP: EOS token id (< 0: argmax of the ids);  BERT / T5: pad token id
+  int rel_buckets;           // T5: relative_attention_num_buckets
+  int rel_max_dist;          // T5: relative_attention_max_distance
 };
 
 enum WKind { W_VEC, W_LINEAR, W_CONV3, W_CONV_IN, W_CONV_OUT };
@@ -60,6 +62,7 @@ struct WSlot {
   size_t off_f32 = (size_t)-1, off_w = (size_t)-1, off_wt = (size_t)-1;
   int fused_parent = -1;     // index of the fused matrix this slot is a row block of
   int row_off = 0;
+  int row_step = 1;          // > 1: this slot's rows are interleaved with its siblings' (T5 gated FF: wi_1 even, wi_0 odd)
   // head padding (heads whose width d is not a multiple of 64 are stored dp = 64*ceil(d/64) wide, zero filled)
   int pad_mode = 0, pad_d = 0, pad_dp = 0;   // 1: rows (to_q/k/v), 2: columns (to_out), 3: GEGLU (h_i, gate_i) row interleave
   int st_n = 0, st_k = 0;    // stored (padded) dims of a LINEAR weight
@@ -115,7 +118,7 @@ struct Op {
   float f0 = 0.f;
   float* aux = nullptr; size_t aux_off = 0, aux_bytes = 0;   // GN/LN stats, attention lse
   int src = 0;                    // OP_TEMB: 0 = timesteps, 1 = time_ids
-  int mask = 0;                   // OP_ATTN: 1 causal, 2 per-sample key count (text encoders)
+  int mask = 0;                   // OP_ATTN: 1 causal, 2 per-sample key count (text encoders), 4 additive T5 position bias
   int fold = -1;                  // OP_LN / OP_LINEAR: index into Tape::folds (LayerNorm folded into the consuming Linear)
 };
 
@@ -170,11 +173,15 @@ struct Tape {
   int build_vae_encoder();
   int build_vae_decoder();
   int build_text();
+  int build_text_t5();
   PeaTextCfg tcfg{};                 // graph 4: text encoder
   std::vector<int> hidden;           // graph 4: hidden_states[0..layers] tensor ids; t_final = final LN output, t_pooled
   int t_final = -1, t_pooled = -1;
   const long long* ids_in = nullptr;
   int* kvlen = nullptr;              // graph 4 (BERT): per-sample valid token count
+  float* rel_bias = nullptr;         // graph 4 (T5): [heads][L][64*ceil(L/64)] relative-position bias in the log2 domain
+  int* rel_bucket = nullptr;         // ... |key - query| -> sub-bucket table [L]
+  int w_rel = -1;                    // ... its [buckets][heads] weight slot
   int* cross_kvlen = nullptr;        // graph 0: per-sample valid context tokens of the cross-attention (merged passes with a shorter
                                      // student context; rows beyond it in t_ehs are zero padding), null = all L
   int exec_ops(size_t begin, size_t end, bool skip_cached, hipStream_t s);

@@ -108,6 +108,13 @@ struct Builder {
     o.f0 = eps; o.aux_bytes = sizeof(float) * 2 * u.tn[x].rows;
     return out;
   }
+  int rms(int x, const std::string& name, float eps) {        // T5LayerNorm: scale only, no mean subtraction
+    const int C = u.tn[x].cols;
+    const int out = T(u.tn[x].rows, C, u.tn[x].B, u.tn[x].H, u.tn[x].W);
+    Op& o = push(OP_LN);
+    o.a = x; o.out = out; o.w = vec(name, C); o.p0 = 1; o.f0 = eps;
+    return out;
+  }
   int silu(int x) {
     const int out = T(u.tn[x].rows, u.tn[x].cols, u.tn[x].B, u.tn[x].H, u.tn[x].W);
     Op& o = push(OP_SILU);
@@ -413,6 +420,7 @@ int Tape::build_vae_decoder() {
 int Tape::build_text() {
   const PeaTextCfg& c = tcfg;
   SHAPECHK(!needs_grad, "text encoder: inference graph only");
+  if (c.flavor == 2) return build_text_t5();
   SHAPECHK(c.width % 64 == 0 && c.heads > 0 && c.width / c.heads == 64 && c.width % c.heads == 0,
            "text encoder: width %d / heads %d (head_dim must be 64)", c.width, c.heads);
   SHAPECHK(c.intermediate % 64 == 0 && c.layers >= 1 && L + c.pos_offset <= c.max_pos && c.pos_offset >= 0 && c.proj_dim % 4 == 0,
@@ -466,6 +474,60 @@ int Tape::build_text() {
     { Op& o = bd.push(OP_GATHER_EOS); o.a = t_final; o.out = eos; }
     t_pooled = c.proj_dim ? bd.linear(eos, "text_projection", c.proj_dim, false) : eos;
   }
+  return PEA_OK;
+}
+
+// flavor 2: the T5 v1.1 encoder stack (the mT5 student option, train_sdxl_zh.py:108-112,331-345; HF transformers
+// T5EncoderModel keys `shared.weight`, `encoder.block.N.layer.0.{SelfAttention.{q,k,v,o},layer_norm}`,
+// `encoder.block.N.layer.1.{DenseReluDense.{wi_0,wi_1,wo},layer_norm}`, `encoder.final_layer_norm.weight`):
+//   x = shared[ids];  per block:  x += o(attn(q, k, v of rms(x)))  with scores = q.k + bias[h][i][j] (no 1/sqrt(d)),
+//   x += wo(gelu_new(wi_0 n) * wi_1 n), n = rms(x);  output = rms_final(x).
+// The position bias comes from block 0's `relative_attention_bias` table ([buckets][heads]) through T5's bidirectional
+// log-spaced buckets and is shared by all blocks; padded keys (ids == pad, right padding) are masked through kv_len.
+// The gated FF runs as ONE GEMM over (wi_1_i, wi_0_i) row-interleaved weights with the h * gelu(gate) epilogue.
+int Tape::build_text_t5() {
+  const PeaTextCfg& c = tcfg;
+  const int W = c.width, I = c.heads * 64, F = c.intermediate;
+  SHAPECHK(W % 64 == 0 && c.heads > 0 && F % 64 == 0 && c.layers >= 1 && c.rel_buckets >= 2 && c.rel_buckets % 2 == 0 &&
+           c.rel_max_dist > c.rel_buckets / 2, "t5 encoder: dims");
+  Builder bd(*this);
+  int x = bd.T((long long)B * L, W, B, 1, L);
+  {
+    Op& o = bd.push(OP_EMBED);
+    o.out = x;
+    o.w = bd.lin("shared.weight", c.vocab, W);
+  }
+  hidden.push_back(x);
+  w_rel = bd.vec("encoder.block.0.layer.0.SelfAttention.relative_attention_bias.weight", c.rel_buckets * c.heads);
+  for (int i = 0; i < c.layers; ++i) {
+    const std::string p = "encoder.block." + std::to_string(i) + ".layer.";
+    const int n1 = bd.rms(x, p + "0.layer_norm.weight", c.eps);
+    const int qkv = bd.fused_linear(n1, {p + "0.SelfAttention.q", p + "0.SelfAttention.k", p + "0.SelfAttention.v"}, {I, I, I}, false);
+    const int att = bd.T((long long)B * L, I, B, 1, L);
+    {
+      Op& o = bd.push(OP_ATTN);
+      o.a = qkv; o.acol = 0; o.b = qkv; o.bcol = I; o.c = qkv; o.ccol = 2 * I; o.out = att;
+      o.p0 = c.heads; o.p1 = L; o.p2 = L; o.p3 = 1; o.f0 = 1.0f; o.mask = 2 | 4;
+    }
+    x = bd.linear(att, p + "0.SelfAttention.o", W, false, x);
+    const int n2 = bd.rms(x, p + "1.layer_norm.weight", c.eps);
+    const int g = bd.T((long long)B * L, F, B, 1, L);
+    {
+      FusedMat f;
+      f.K = W; f.N = 2 * F; f.has_bias = false;
+      fused.push_back(f);
+      const int fi = (int)fused.size() - 1;
+      const int wh = bd.lin(p + "1.DenseReluDense.wi_1.weight", F, W);      // linear half -> even rows
+      const int wg = bd.lin(p + "1.DenseReluDense.wi_0.weight", F, W);      // gated half  -> odd rows
+      slots[wh].fused_parent = fi; slots[wh].row_off = 0; slots[wh].row_step = 2;
+      slots[wg].fused_parent = fi; slots[wg].row_off = 1; slots[wg].row_step = 2;
+      Op& o = bd.push(OP_LINEAR);
+      o.a = n2; o.fused = fi; o.out = g; o.p3 = 3; o.p1 = 1;                // p1: gelu_new (tanh form) in the gate
+    }
+    x = bd.linear(g, p + "1.DenseReluDense.wo", W, false, x);
+    hidden.push_back(x);
+  }
+  t_final = bd.rms(x, "encoder.final_layer_norm.weight", c.eps);
   return PEA_OK;
 }
 
@@ -695,7 +757,7 @@ int Tape::alloc() {
         FusedMat& f = fused[s.fused_parent];
         if (s.kind == W_VEC) s.f32 = f.bias + s.row_off;
         else {
-          s.w = f.w + (size_t)s.row_off * f.K; s.ldw = f.K;
+          s.w = f.w + (size_t)s.row_off * f.K; s.ldw = f.K * s.row_step;
           if (f.need_wt) { s.wt = f.wt + s.row_off; s.ldwt = f.N; s.need_wt = true; }
         }
         continue;
@@ -785,6 +847,22 @@ int Tape::ensure_acts() {
     HIPCHK(hipMalloc((void**)&vae_h, sizeof(float) * (size_t)B * cfg.out_channels * t.H * t.W));
   }
   if (graph == 4) HIPCHK(hipMalloc((void**)&kvlen, sizeof(int) * B));
+  if (graph == 4 && tcfg.flavor == 2) {
+    const size_t n = (size_t)tcfg.heads * L * (((L + 63) >> 6) << 6);
+    HIPCHK(hipMalloc((void**)&rel_bias, n * sizeof(float)));
+    HIPCHK(hipMemset(rel_bias, 0, n * sizeof(float)));
+    // |key - query| -> sub-bucket (T5Attention._relative_position_bucket): exact below nb/2, then log-spaced up to
+    // max_distance; fp32 arithmetic in the order the reference evaluates it
+    const int nb = tcfg.rel_buckets / 2, max_exact = nb / 2;
+    std::vector<int> tab(L);
+    for (int d = 0; d < L; ++d) {
+      if (d < max_exact) { tab[d] = d; continue; }
+      const float lg = logf((float)d / (float)max_exact) / (float)log((double)tcfg.rel_max_dist / (double)max_exact) * (float)(nb - max_exact);
+      tab[d] = std::min(max_exact + (int)lg, nb - 1);
+    }
+    HIPCHK(hipMalloc((void**)&rel_bucket, sizeof(int) * L));
+    HIPCHK(hipMemcpy(rel_bucket, tab.data(), sizeof(int) * L, hipMemcpyHostToDevice));
+  }
   if (graph == 3) HIPCHK(hipMalloc((void**)&vae_h, sizeof(float) * (size_t)B * cfg.in_channels * H * W));   // post_quant_conv(z / s)
   RC(pea_zero_page(&zeros));
   return PEA_OK;
@@ -807,6 +885,8 @@ Tape::~Tape() {
   if (am_vt) hipFree(am_vt);
   if (vae_h) hipFree(vae_h);
   if (kvlen) hipFree(kvlen);
+  if (rel_bias) hipFree(rel_bias);
+  if (rel_bucket) hipFree(rel_bucket);
   if (cross_kvlen) hipFree(cross_kvlen);
 }
 
@@ -832,6 +912,8 @@ int Tape::load_weight(const char* name, const float* src, long long numel, hipSt
     case W_LINEAR:
       if (w.pad_mode) {
         RC(launch_pad_gather(src, w.d0, w.d1, w.pad_mode, w.pad_d, w.pad_dp, w.w, w.ldw, w.wt, w.ldwt, w.st_n, w.st_k, s));
+      } else if (w.row_step > 1) {      // row-interleaved member of a fused matrix (T5 gated FF)
+        RC(launch_pad_gather(src, w.d0, w.d1, 0, 0, 0, w.w, w.ldw, nullptr, 0, w.d0, w.d1, s));
       } else {
         RC(launch_cast_f32_bf16(src, w.w, numel, s));
         if (w.wt) RC(launch_transpose_f32_bf16(src, w.wt, w.d0, w.d1, w.ldwt, s));
@@ -967,7 +1049,7 @@ int Tape::exec_ops(size_t begin, size_t end, bool skip_cached, hipStream_t s) {
         else { WSlot& w = slots[o.w]; p.W = w.w; p.ldw = w.ldw; p.bias = o.bias >= 0 ? slots[o.bias].f32 : nullptr; }
         p.C = out.d; p.ldc = out.cols; p.act = o.p2;
         if (o.p3 == 3) {                  // fused GEGLU: N = 8C interleaved, y -> out, pre-activation -> op.c (student only)
-          p.N = 2 * out.cols; p.geglu_y = out.d; p.ldy = out.cols;
+          p.N = 2 * out.cols; p.geglu_y = out.d; p.ldy = out.cols; p.geglu_tanh = o.p1;
           p.C = o.c >= 0 ? tn[o.c].d : nullptr; p.ldc = 2 * out.cols;
           if (bwd_batch > 0) p.stash_rows = (int)(out.rows / B * bwd_batch);   // only the differentiated samples are stashed
         }
@@ -1006,7 +1088,8 @@ int Tape::exec_ops(size_t begin, size_t end, bool skip_cached, hipStream_t s) {
       case OP_EMBED: {
         SHAPECHK(ids_in != nullptr, "text encoder: no input ids");
         Tn& out = tn[o.out];
-        RC(launch_embed_tokens(ids_in, slots[o.w].w, slots[o.bias].w + (long long)tcfg.pos_offset * out.cols,
+        RC(launch_embed_tokens(ids_in, slots[o.w].w,
+                               o.bias >= 0 ? slots[o.bias].w + (long long)tcfg.pos_offset * out.cols : nullptr,
                                o.c >= 0 ? slots[o.c].w : nullptr, out.d, B, L, out.cols, tcfg.vocab, s));
         break;
       }
@@ -1057,6 +1140,10 @@ int Tape::exec_ops(size_t begin, size_t end, bool skip_cached, hipStream_t s) {
           RC(launch_layernorm_stats(a.d, o.aux, (int)a.rows, a.cols, o.f0, s));
           break;
         }
+        if (o.p0 == 1) {                  // T5LayerNorm
+          RC(launch_rmsnorm_fwd(a.d, slots[o.w].f32, tn[o.out].d, (int)a.rows, a.cols, o.f0, s));
+          break;
+        }
         RC(launch_layernorm_fwd(a.d, slots[o.w].f32, slots[o.bias].f32, tn[o.out].d, o.aux, (int)a.rows, a.cols, o.f0,
                                 s));
         break;
@@ -1067,6 +1154,7 @@ int Tape::exec_ops(size_t begin, size_t end, bool skip_cached, hipStream_t s) {
         p.V = tn[o.c].d + o.ccol; p.ldv = tn[o.c].cols; p.O = tn[o.out].d; p.ldo = tn[o.out].cols; p.lse = o.aux;
         p.B = B; p.H = o.p0; p.Sq = o.p1; p.Skv = o.p2; p.scale = o.f0; p.nd = o.p3;
         p.causal = o.mask & 1; p.kv_len = (o.mask & 2) ? kvlen : nullptr;
+        if (o.mask & 4) p.bias = rel_bias;
         if (cross_kvlen && o.b == t_kvall) p.kv_len = cross_kvlen;
         RC(launch_attention_fwd(p, s));
         break;

@@ -425,6 +425,67 @@ int launch_layernorm_fwd(const bf16* x, const float* gamma, const float* beta, b
   return PEA_OK;
 }
 
+// T5LayerNorm (mT5 student text tower, train_sdxl_zh.py:108-112): y = x * rsqrt(mean(x^2) + eps) * w -- no mean
+// subtraction, no bias.  One wave per LN_NR rows, the rows live in registers (as ln_fwd_kernel).
+template <int NCH>
+__global__ __launch_bounds__(256) void rms_fwd_kernel(const bf16* __restrict__ x, const float* __restrict__ gamma,
+                                                      bf16* __restrict__ y, int R, int C, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * LN_NR;
+  if (row0 >= R) return;
+  const int nchunk = C / 8;
+  bf16x8 v[LN_NR][NCH];
+#pragma unroll
+  for (int r = 0; r < LN_NR; ++r) {
+    const int row = min(row0 + r, R - 1);
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int ck = lane + 64 * i;
+      if (ck < nchunk) v[r][i] = *(const bf16x8*)(x + (long long)row * C + ck * 8);
+    }
+  }
+  float rinv[LN_NR];
+#pragma unroll
+  for (int r = 0; r < LN_NR; ++r) {
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i)
+      if (lane + 64 * i < nchunk)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) q += (float)v[r][i][j] * (float)v[r][i][j];
+    rinv[r] = rsqrtf(wave_sum(q) / (float)C + eps);
+  }
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int ck = lane + 64 * i;
+    if (ck < nchunk) {
+      const f32x4 g0 = *(const f32x4*)(gamma + ck * 8), g1 = *(const f32x4*)(gamma + ck * 8 + 4);
+#pragma unroll
+      for (int r = 0; r < LN_NR; ++r) {
+        if (row0 + r >= R) break;
+        bf16x8 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          o[j] = (bf16)((float)v[r][i][j] * rinv[r] * g0[j]);
+          o[4 + j] = (bf16)((float)v[r][i][4 + j] * rinv[r] * g1[j]);
+        }
+        *(bf16x8*)(y + (long long)(row0 + r) * C + ck * 8) = o;
+      }
+    }
+  }
+}
+int launch_rmsnorm_fwd(const bf16* x, const float* gamma, bf16* y, int R, int C, float eps, hipStream_t s) {
+  SHAPECHK(C % 8 == 0 && C <= 64 * 8 * LN_MAXCH, "rmsnorm: C=%d unsupported", C);
+  PROF_BEGIN(5, 0.0, 4.0 * R * (double)C, s);
+  const int nch = cdiv(C / 8, 64);
+#define RMS_FWD(N) hipLaunchKernelGGL(rms_fwd_kernel<N>, dim3(cdiv(R, 4 * LN_NR)), dim3(256), 0, s, x, gamma, y, R, C, eps)
+  if (nch <= 1) RMS_FWD(1); else if (nch == 2) RMS_FWD(2); else if (nch == 3) RMS_FWD(3); else if (nch == 4) RMS_FWD(4); else RMS_FWD(8);
+#undef RMS_FWD
+  PROF_END(s);
+  HIPCHK(hipGetLastError());
+  return PEA_OK;
+}
+
 int launch_layernorm_stats(const bf16* x, float* stats, int R, int C, float eps, hipStream_t s) {
   SHAPECHK(C % 8 == 0 && C <= 64 * 8 * LN_MAXCH, "layernorm: C=%d unsupported", C);
   PROF_BEGIN(5, 0.0, 2.0 * R * (double)C, s);

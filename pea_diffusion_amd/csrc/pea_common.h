@@ -59,6 +59,13 @@ __device__ __forceinline__ float erf_fast(float x, float* exp_mx2 = nullptr) {
   return copysignf(fmaf(-p, e, 1.0f), x);
 }
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erf_fast(x * 0.70710678118654752f)); }
+// gelu_new (HF NewGELUActivation, T5 v1.1 / mT5): 0.5 x (1 + tanh(sqrt(2/pi) (x + 0.044715 x^3))); tanh(u) = 1 - 2 / (exp(2u) + 1)
+__device__ __forceinline__ float gelu_tanh(float x) {
+  const float u = 0.7978845608028654f * fmaf(0.044715f * x * x, x, x);
+  const float e = __builtin_amdgcn_exp2f(2.8853900817779268f * u);          // exp(2u)
+  const float th = 1.0f - 2.0f * __builtin_amdgcn_rcpf(e + 1.0f);
+  return 0.5f * x * (1.0f + th);
+}
 __device__ __forceinline__ float gelu_erf_grad(float x) {
   // d/dx [x * Phi(x)] = Phi(x) + x * phi(x);  phi(x) = exp(-x^2/2)/sqrt(2 pi) shares the exponential with erf(x/sqrt2)
   float e;

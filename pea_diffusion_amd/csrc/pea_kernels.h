@@ -31,6 +31,7 @@ struct GemmP {
   // fused GEGLU: the weight rows are interleaved (h_i, gate_i) so a lane's 4 consecutive columns are two pairs;
   // geglu_y[m][n/2] = h * gelu(gate).  C may be null then (no pre-activation stash: teacher / inference).
   bf16* geglu_y; int ldy;
+  int geglu_tanh;                  // GEGLU gate activation: 0 = GELU(erf) (diffusers GEGLU), 1 = gelu_new / tanh form (T5 v1.1 gated-gelu)
   int stash_rows;                  // GEGLU with a stash: rows >= stash_rows (> 0) skip the C store (merged passes: teacher rows)
   int ksplit; long long split_stride;   // split-K: fp32 partial s is written at C + s*split_stride (then launch_splitk_reduce)
   int epi_fast;                    // set by launch_gemm: the batched-load epilogue (gemm_epilogue16_fast) applies
@@ -65,6 +66,7 @@ int launch_groupnorm_bwd(const bf16* x, const bf16* dy, const float* gamma, cons
 int launch_layernorm_fwd(const bf16* x, const float* gamma, const float* beta, bf16* y, float* stats, int R, int C,
                          float eps, hipStream_t s);
 // (mean, rstd) per row only; and the LayerNorm -> Linear fold (norm.hip: ln_fold_kernel)
+int launch_rmsnorm_fwd(const bf16* x, const float* gamma, bf16* y, int R, int C, float eps, hipStream_t s);
 int launch_layernorm_stats(const bf16* x, float* stats, int R, int C, float eps, hipStream_t s);
 int launch_ln_fold(const bf16* W, int ldw, const float* gamma, const float* beta, const float* bias, bf16* Wf, float* svec,
                    float* tvec, int N, int K, hipStream_t s);
@@ -91,6 +93,7 @@ struct AttnP {
   int xcd_remap;                   // set by the launchers: XCD-aware workgroup order
   int causal;                      // forward only: key index <= query index (text encoders)
   const int* kv_len;               // per-sample number of valid keys (key padding mask; forward and backward), may be null
+  const float* bias;               // forward, masked instance only: additive score bias [H][Sq][Skv] in the LOG2 domain (T5 relative positions), may be null
 };
 int attention_bwd_nsplit(int B, int H, int Sq, int Skv);
 size_t attention_bwd_scratch_bytes(int B, int H, int Sq, int Skv, int nd = 1);
@@ -203,5 +206,6 @@ int launch_vae_post_quant(const float* z, const float* w, const float* b, float*
                           float inv_scaling, hipStream_t s);
 int launch_embed_tokens(const long long* ids, const bf16* tok, const bf16* pos, const bf16* type0, bf16* out, int B, int L,
                         int width, int vocab, hipStream_t s);
+int launch_t5_rel_bias(const float* rel, const int* dist_bucket, float* bias, int H, int L, int pitch, int half_buckets, hipStream_t s);
 int launch_gather_eos(const long long* ids, const bf16* x, bf16* out, int B, int L, int width, long long eos_id, hipStream_t s);
 int launch_kv_len(const long long* ids, int* len, int B, int L, long long pad_id, hipStream_t s);

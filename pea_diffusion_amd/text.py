@@ -3,7 +3,10 @@ tape.  CLIP flavour = the teacher's two encoders as diffusers' `encode_prompt` c
 (`out = text_encoder(ids, output_hidden_states=True); pooled = out[0]; prompt_embeds = out.hidden_states[-2]`,
 train_sdxl_zh.py:170-285) -- CLIP-L and OpenCLIP-bigG, HF `CLIPTextModel[WithProjection]` state-dict keys.  BERT flavour =
 the Chinese-CLIP text tower whose per-token states feed the adapter (`encode_text(batch["input_ids"])`,
-train_sdxl_zh.py:327-329; HF `BertModel` keys, an optional `bert.` prefix is stripped).  Tokenisation stays on the host."""
+train_sdxl_zh.py:327-329; HF `BertModel` keys, an optional `bert.` prefix is stripped).  T5 flavour = the mT5 student
+option (`self.text_encoder.encoder(ids, attention_mask=ids.ne(pad), output_hidden_states=True)[0]`, train_sdxl_zh.py:108-112,
+331-345; HF `T5EncoderModel` keys; the padding mask is derived from the ids on the device, right padding with the pad id).
+Tokenisation stays on the host."""
 from __future__ import annotations
 
 import ctypes
@@ -52,11 +55,20 @@ class HipTextEncoder:
     weight_table = HipUNet.weight_table
     memory = HipUNet.memory
 
+    @property
+    def encoder(self):
+        """`T5EncoderModel.encoder` -- the reference calls the stack directly (train_sdxl_zh.py:341)"""
+        return self
+
     def load_state_dict(self, sd: Dict[str, torch.Tensor], strict: bool = True):
         table = self.weight_table()
         fixed = {}
         for k, v in sd.items():
             k2 = k[5:] if k.startswith("bert.") else k
+            if k2 == "encoder.embed_tokens.weight":       # T5: tied to `shared.weight`
+                if "shared.weight" in sd:
+                    continue
+                k2 = "shared.weight"
             if k2 in table:
                 fixed[k2] = v[: table[k2][0]] if (k2.endswith("position_embeddings.weight") or k2.endswith("token_type_embeddings.weight")) and v.shape[0] > table[k2][0] else v
         return HipUNet.load_state_dict(self, fixed, strict)
@@ -83,5 +95,6 @@ class HipTextEncoder:
         return _Output(self, input_ids, last, pooled)
 
     def encode_text(self, input_ids):
-        """Chinese-CLIP's (privately modified) `encode_text`: per-token states first (train_sdxl_zh.py:327-329)"""
+        """Chinese-CLIP's (privately modified) `encode_text`: per-token states first (train_sdxl_zh.py:327-329); for the T5
+        flavour the same call returns `encoder(ids, attention_mask=ids.ne(pad))[0]`"""
         return self.encode(input_ids, hidden_index=-1)[0], None
