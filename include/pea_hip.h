@@ -299,6 +299,9 @@ int pea_unet_backward(void* unet, const float* deps, unsigned tap_seed_mask, voi
 int pea_unet_input_grads(void* unet, void** d_ehs, void** d_text);
 /* resident bytes: weights; activations and gradients (allocated on the first forward / backward, 0 before) */
 int pea_unet_memory(void* unet, long long* weight_bytes, long long* act_bytes, long long* grad_bytes, int* n_ops);
+/* Free the activation / gradient arenas and scratch of a context (weights stay); the next forward allocates them again.
+ * Pointers handed out by pea_unet_tap_info / pea_unet_input_grads become invalid.  Synchronises the device. */
+int pea_unet_release_activations(void* unet);
 
 /* The PEA adapter `MLP(in_dim, out_dim, hidden_dim, out_dim1, use_residual)` (train_sdxl_zh.py:43-67);
  * out_dim1 = 0 selects the SD1.5 variant (train_sd_zh.py:41-56).  Parameters live in ONE flat fp32
@@ -336,6 +339,11 @@ int pea_train_step(void* tr, const float* latents, const float* noise, const lon
  * first B; otherwise the two-stream path is used) */
 int pea_trainer_set_option(void* tr, const char* name, int value);
 int pea_trainer_get_option(void* trainer, const char* name);   /* also "merge_state": 0 undecided, 1 merged, -1 n/a */
+/* pea_unet_release_activations on the trainer's student, teacher and merged-pass contexts.  The reference trains over
+ * nine aspect-ratio buckets (utils/custom_dataset_sdxl.py:30, one bucket per batch): a caller keeps one trainer per
+ * bucket -- all sharing one set of weights and one adapter -- and releases the least recently used when HBM runs short
+ * (pea_diffusion_amd/train.py: BucketedTrainer). */
+int pea_trainer_release_activations(void* trainer);
 /* intermediate results of the last step (fp32 NCHW [B][4][H][W]): which 0 = x_t, 1 = eps_student, 2 = eps_teacher */
 int pea_trainer_export(void* tr, int which, float* out, void* stream);
 

@@ -127,13 +127,14 @@ def rescale_noise_cfg_ref(noise_cfg, noise_pred_text, guidance_rescale=0.0):
 
 
 def synthetic_batch(cfg, B: int, L: int = 77, enc_dim: int = 1024, seed: int = 0,
-                    latent_hw: Optional[int] = None, force_mask: bool = True) -> Dict[str, torch.Tensor]:
+                    latent_hw=None, force_mask: bool = True) -> Dict[str, torch.Tensor]:
     """Seeded synthetic post-encoder batch; identical tensors feed the
     oracle and the device path."""
     g = lambda s: torch.Generator().manual_seed(seed * 100 + s)
     hw = latent_hw or cfg.sample_size
-    lat = torch.randn(B, 4, hw, hw, generator=g(0))
-    noise = torch.randn(B, 4, hw, hw, generator=g(1))
+    lh, lw = (hw, hw) if isinstance(hw, int) else hw           # (height, width): the reference's aspect-ratio buckets
+    lat = torch.randn(B, 4, lh, lw, generator=g(0))
+    noise = torch.randn(B, 4, lh, lw, generator=g(1))
     if cfg.addition_embed_type == "text_time":                         # SDXL: noise_offset 0.5 (universal.py:31)
         noise = noise + 0.5 * torch.randn(B, 4, 1, 1, generator=g(11))
     t = torch.randint(0, 1000, (B,), generator=g(2))
@@ -155,7 +156,6 @@ def synthetic_batch(cfg, B: int, L: int = 77, enc_dim: int = 1024, seed: int = 0
     out = dict(latents=lat, noise=noise, timesteps=t, enc=enc, enc_uncond=enc_u, prompt_mask=pm,
                zh_or_not=zh, teacher_ehs=te, teacher_neg=tn)
     if cfg.addition_embed_type == "text_time":
-        px = hw * 8
         out["teacher_pooled"] = torch.randn(B, cfg.pooled_dim, generator=g(7))
-        out["time_ids"] = torch.tensor([[px, px, 0, 0, px, px]] * B, dtype=torch.int64)
+        out["time_ids"] = torch.tensor([[lh * 8, lw * 8, 0, 0, lh * 8, lw * 8]] * B, dtype=torch.int64)
     return out

@@ -389,7 +389,8 @@ int pea_unet_tap_export_nchw(void* h, int k, int grad, float* out, void* stream)
   const Tn& t = u->tn[u->taps[k]];
   const bf16* src = grad ? t.g : t.d;
   NOTNULL(src, "pea_unet_tap_export_nchw(grad)");
-  return launch_nhwc_to_nchw_f32(src, out, t.B, t.H * t.W, t.cols, (hipStream_t)stream);
+  const int nb = (grad && u->bwd_batch > 0) ? u->bwd_batch : t.B;    // gradients exist for the differentiated samples only
+  return launch_nhwc_to_nchw_f32(src, out, nb, t.H * t.W, t.cols, (hipStream_t)stream);
 }
 int pea_unet_backward(void* h, const float* deps, unsigned tap_seed_mask, void* stream) {
   NOTNULL(h, "pea_unet_backward");
@@ -415,6 +416,11 @@ int pea_unet_memory(void* h, long long* weight_bytes, long long* act_bytes, long
   if (grad_bytes) *grad_bytes = u->garena ? (long long)u->gbytes : 0;
   if (n_ops) *n_ops = (int)u->ops.size();
   return PEA_OK;
+}
+
+int pea_unet_release_activations(void* h) {
+  NOTNULL(h, "pea_unet_release_activations");
+  return ((Tape*)h)->release_acts();
 }
 
 // ------------------------------------------------------------------------------ adapter
@@ -519,6 +525,14 @@ int pea_trainer_set_option(void* h, const char* name, int value) {
     pea_set_error("pea_trainer_set_option: unknown option '%s'", name);
     return PEA_E_INVALID;
   }
+  return PEA_OK;
+}
+int pea_trainer_release_activations(void* h) {
+  NOTNULL(h, "pea_trainer_release_activations");
+  Trainer* t = (Trainer*)h;
+  RCX(t->student->release_acts());
+  RCX(t->teacher->release_acts());
+  if (t->merged) RCX(t->merged->release_acts());
   return PEA_OK;
 }
 int pea_trainer_get_option(void* h, const char* name) {

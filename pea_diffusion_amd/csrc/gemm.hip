@@ -728,8 +728,10 @@ static int launch_lc(const GemmP& p, hipStream_t stream) {
 // (scripts/gemm_epi_probe.py), disappears behind the main loop.
 // FASTONLY: only the batched-load epilogue is compiled in (the 256-row tiles: with both epilogues in one kernel the
 // register allocator spills around the tile transition); launch_gemm sends other epilogues to a 128-row variant.
-template <int MODE, int BM, int BN, int WM, int WN, int LW, int S, int SW = 0, int DF = 0, int EPI = 0>
-__global__ __launch_bounds__((WM * WN + LW + SW) * 64) void gemm_lcp_kernel(const GemmP p) {
+// OCC = 2: TWO workgroups per CU (each with its own ring in at most half of the LDS, registers capped for three waves
+// per SIMD): the two run out of phase, so one's tile transition / DMA wait is the other's main loop.
+template <int MODE, int BM, int BN, int WM, int WN, int LW, int S, int SW = 0, int DF = 0, int EPI = 0, int OCC = 1>
+__global__ __launch_bounds__((WM * WN + LW + SW) * 64, (OCC == 2 ? 3 : 1)) void gemm_lcp_kernel(const GemmP p) {
   constexpr bool FASTONLY = EPI != 0;     // EPI 1: batched-load epilogue only; 2: the same with the folded LayerNorm
   constexpr int PITCH = BN * 2 + 16;                            // staging row pitch: conflict-free 8-byte writes
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1056,13 +1058,14 @@ __global__ __launch_bounds__((WM * WN + LW + SW) * 64) void gemm_lcp_kernel(cons
 }
 
 static int g_num_cus = 0;
-template <int MODE, int BM, int BN, int WM, int WN, int LW, int S, int SW = 0, int DF = 0, int EPI = 0>
+template <int MODE, int BM, int BN, int WM, int WN, int LW, int S, int SW = 0, int DF = 0, int EPI = 0, int OCC = 1>
 static int launch_lcp(const GemmP& p, hipStream_t stream) {
   constexpr int lds = S * (BM + BN) * 128 + (SW ? BM * (BN * 2 + 16) : 0);
-  static_assert(lds <= 160 * 1024, "LDS budget");
+  static_assert(lds * OCC <= 160 * 1024, "LDS budget");
+  static_assert(OCC == 1 || (WM * WN + LW + SW) * OCC <= 12, "OCC = 2: three waves per SIMD");
   static bool attr_set = false;
   if (!attr_set) {
-    HIPCHK(hipFuncSetAttribute((const void*)gemm_lcp_kernel<MODE, BM, BN, WM, WN, LW, S, SW, DF, EPI>,
+    HIPCHK(hipFuncSetAttribute((const void*)gemm_lcp_kernel<MODE, BM, BN, WM, WN, LW, S, SW, DF, EPI, OCC>,
                                hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     attr_set = true;
   }
@@ -1073,9 +1076,9 @@ static int launch_lcp(const GemmP& p, hipStream_t stream) {
   }
   SHAPECHK(p.ksplit <= 1, "gemm: the persistent kernel has no split-K path");
   const int tiles = cdiv(p.M, BM) * cdiv(p.N, BN);
-  const int grid = tiles < g_num_cus ? tiles : g_num_cus;
+  const int grid = tiles < g_num_cus * OCC ? tiles : g_num_cus * OCC;
   SHAPECHK(EPI == 0 || p.epi_fast, "gemm: variant needs the batched-load epilogue");
-  hipLaunchKernelGGL((gemm_lcp_kernel<MODE, BM, BN, WM, WN, LW, S, SW, DF, EPI>), dim3(grid),
+  hipLaunchKernelGGL((gemm_lcp_kernel<MODE, BM, BN, WM, WN, LW, S, SW, DF, EPI, OCC>), dim3(grid),
                      dim3((WM * WN + LW + SW) * 64), lds, stream, p);
   return PEA_OK;
 }
@@ -1101,6 +1104,8 @@ extern "C" void pea_debug_set_gemm_variant(int v) { g_gemm_variant = v; }
     case 33: rc = launch_lcp<MODE, 256, 128, 4, 2, 4, 3, 0, 0, 1>(p, stream); break; \
     case 34: rc = launch_lcp<MODE, 128, 160, 4, 2, 4, 3, 4>(p, stream); break; /* staged epilogue */ \
     case 35: rc = launch_lcp<MODE, 128, 160, 4, 2, 4, 3, 0, 1>(p, stream); break; /* deferred epilogue */ \
+    case 36: rc = launch_lcp<MODE, 128, 160, 2, 2, 2, 2, 0, 0, 1, 2>(p, stream); break; /* two workgroups per CU */ \
+    case 37: rc = launch_lcp<MODE, 128, 128, 2, 2, 2, 2, 0, 0, 1, 2>(p, stream); break; \
     default: rc = launch_lc<MODE, 128, 128, 2, 2, 4, 4, false, true>(p, stream); break; \
   }
 

@@ -172,6 +172,7 @@ struct Tape {
   int build();
   int build_vae_encoder();
   int build_vae_decoder();
+  int release_acts();
   int build_text();
   int build_text_t5();
   PeaTextCfg tcfg{};                 // graph 4: text encoder

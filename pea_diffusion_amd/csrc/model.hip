@@ -783,7 +783,9 @@ int Tape::alloc() {
   size_t ao = 0, go = 0;
   for (Tn& t : tn) {
     t.off_d = ao; ao += al256((size_t)t.rows * t.cols * 2);
-    if (needs_grad && t.rg) { t.off_g = go; go += al256((size_t)t.rows * t.cols * 2); }
+    // gradients exist only for the differentiated samples (merged passes: the leading bwd_batch of B; every tensor is
+    // batch-major and the backward pass works on rb(t) = rows / B * bwd_batch leading rows)
+    if (needs_grad && t.rg) { t.off_g = go; go += al256((size_t)(bwd_batch > 0 ? t.rows / B * bwd_batch : t.rows) * t.cols * 2); }
   }
   for (Op& o : ops)
     if (o.aux_bytes) { o.aux_off = ao; ao += al256(o.aux_bytes); }
@@ -865,6 +867,22 @@ int Tape::ensure_acts() {
   }
   if (graph == 3) HIPCHK(hipMalloc((void**)&vae_h, sizeof(float) * (size_t)B * cfg.in_channels * H * W));   // post_quant_conv(z / s)
   RC(pea_zero_page(&zeros));
+  return PEA_OK;
+}
+
+// Give the activation / gradient arenas and the scratch buffers back (weights stay).  The next forward allocates them
+// again (ensure_acts).  For trainers that hold one context per aspect-ratio bucket (utils/custom_dataset_sdxl.py:30) and
+// keep only the recently used ones resident.
+int Tape::release_acts() {
+  HIPCHK(hipDeviceSynchronize());
+  void** bufs[] = {(void**)&aarena, (void**)&garena, (void**)&gn_scratch, (void**)&delta, (void**)&ups_tmp, (void**)&tproj_grad,
+                   (void**)&cs_scratch, (void**)&attn_part, (void**)&kv_part, (void**)&geglu_tmp, (void**)&am_scores,
+                   (void**)&am_vt, (void**)&vae_h, (void**)&kvlen, (void**)&rel_bias, (void**)&rel_bucket};
+  for (void** b : bufs)
+    if (*b) { HIPCHK(hipFree(*b)); *b = nullptr; }
+  for (Tn& t : tn) { t.d = nullptr; t.g = nullptr; }
+  for (Op& o : ops) o.aux = nullptr;
+  ce_valid = false;
   return PEA_OK;
 }
 

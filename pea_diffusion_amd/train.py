@@ -7,7 +7,8 @@ from __future__ import annotations
 
 import ctypes
 import os
-from typing import Dict, Optional
+from collections import OrderedDict
+from typing import Dict, Optional, Sequence, Tuple
 
 import torch
 
@@ -177,3 +178,100 @@ class PEATrainer:
         torch.save({k: v.detach().cpu().clone() for k, v in self.adapter.state_dict().items()},
                    os.path.join(d, "pytorch_model.bin"))
         return d
+
+
+class BucketedTrainer(PEATrainer):
+    """The KD step over the reference's aspect-ratio buckets (utils/custom_dataset_sdxl.py:30,384-409: every batch comes
+    from ONE of nine (height, width) buckets, 448x896 ... 896x448, and `training_step` simply runs on whatever shape
+    arrives).  The HIP tape is planned per shape, so this trainer keeps one (student, teacher, trainer) context per
+    latent shape -- created on first use, all of them borrowing the weights of the contexts it was built with -- behind
+    the one PEATrainer surface: one adapter, one AdamW state, one LR schedule, one gradient buffer.
+
+    HBM: a context's activation + gradient arenas are resident from its first step (17 + 12 GB per bucket for SDXL at
+    B = 4, merged passes); `max_resident_gb` bounds their sum -- before a context that is not resident runs, the least
+    recently used ones are released (`pea_trainer_release_activations`) until its planned size fits.  The default keeps
+    every one of the nine SDXL buckets resident at B = 4 on a 288 GB MI355X."""
+
+    def __init__(self, adapter: PEAAdapter, student: HipUNet, teacher: HipUNet, max_resident_gb: float = 240.0, **kw):
+        super().__init__(adapter, student, teacher, **kw)
+        self._kw = dict(feat_weight=kw.get("feat_weight", 0.1), nan_guard=kw.get("nan_guard", False))
+        self._primary = (student, teacher)
+        self._ctx: "OrderedDict[Tuple[int, int], tuple]" = OrderedDict()
+        self._ctx[(student.H, student.W)] = (student, teacher, self._h)
+        self._options: Dict[str, int] = {}
+        self._known: Dict[Tuple[int, int], int] = {}
+        self.max_resident_bytes = int(max_resident_gb * 2 ** 30)
+
+    # ---- context management
+    def _planned_bytes(self, h: int, w: int) -> int:
+        """upper bound of what a step at this shape allocates: the merged-pass context (2B samples, with gradients)"""
+        from . import config as _cfg
+        s0 = self._primary[0]
+        c = _cfg.to_c(s0.cfg)
+        ab, gb = ctypes.c_longlong(), ctypes.c_longlong()
+        check(lib().pea_unet_plan(ctypes.byref(c), 2 * s0.B, h, w, self._primary[1].L, 1, None, None, None, None,
+                                  ctypes.byref(ab), ctypes.byref(gb)))
+        return ab.value + gb.value
+
+    def _resident_bytes(self, ctx) -> int:
+        st, te, h = ctx
+        n = 0
+        for u in (st, te):
+            m = u.memory()
+            n += m["activation_bytes"] + m["grad_bytes"]
+        return n + (lib().pea_trainer_get_option(h, b"merged_mib") << 20)
+
+    def resident_bytes(self) -> int:
+        return sum(self._resident_bytes(c) for c in self._ctx.values())
+
+    def _select(self, h: int, w: int):
+        key = (int(h), int(w))
+        if key not in self._ctx:
+            s0, t0 = self._primary
+            st = HipUNet(s0.cfg, s0.B, key[0], key[1], s0.L, needs_grad=True, share_weights_from=s0)
+            te = HipUNet(t0.cfg, t0.B, key[0], key[1], t0.L, share_weights_from=t0)
+            hd = ctypes.c_void_p()
+            self.adapter.prepare(2 * s0.B, s0.L)                    # a stand-alone proj(x) call may have re-shaped it
+            check(lib().pea_trainer_create(self.adapter._h, st._h, te._h, self._kw["feat_weight"],
+                                           int(self._kw["nan_guard"]), ptr(self._ac), ctypes.byref(hd)))
+            for name, value in self._options.items():
+                check(lib().pea_trainer_set_option(hd, name.encode(), int(value)))
+            self._ctx[key] = (st, te, hd)
+        self._ctx.move_to_end(key)
+        cur = self._ctx[key]
+        # make room first: what this context is about to allocate (0 when it is resident) + what is resident must fit
+        have = self._resident_bytes(cur)
+        if have:
+            self._known[key] = have                                 # what this shape really takes, for its next admission
+        need = 0 if have else self._known.get(key) or self._planned_bytes(*key)
+        for k in list(self._ctx):                                   # least recently used first
+            if self.resident_bytes() + need <= self.max_resident_bytes:
+                break
+            if k != key and self._resident_bytes(self._ctx[k]):
+                check(lib().pea_trainer_release_activations(self._ctx[k][2]))
+        self.student, self.teacher, self._h = cur
+
+    @property
+    def shapes(self) -> Sequence[Tuple[int, int]]:
+        """latent shapes with a context, least recently used first"""
+        return list(self._ctx)
+
+    def set_option(self, name: str, value: int):
+        self._options[name] = int(value)
+        for _, _, h in self._ctx.values():
+            check(lib().pea_trainer_set_option(h, name.encode(), int(value)))
+
+    def training_step(self, batch: Dict[str, torch.Tensor], batch_idx: int = 0, sync: bool = False):
+        h, w = batch["latents"].shape[-2:]
+        self._select(h, w)
+        return super().training_step(batch, batch_idx, sync=sync)
+
+    def __del__(self):
+        try:
+            for _, _, h in getattr(self, "_ctx", {}).values():
+                if h and h.value:
+                    lib().pea_trainer_destroy(h)
+            self._ctx = OrderedDict()
+            self._h = ctypes.c_void_p()
+        except Exception:
+            pass

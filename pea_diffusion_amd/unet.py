@@ -84,6 +84,10 @@ class HipUNet:
         except Exception:
             pass
 
+    def release_activations(self):
+        """free the activation / gradient arenas (weights stay); the next forward allocates them again"""
+        check(lib().pea_unet_release_activations(self._h))
+
     # ---------------------------------------------------------------- weights
     def weight_table(self) -> Dict[str, tuple]:
         """{diffusers key: torch shape}"""
