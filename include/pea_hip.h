@@ -381,6 +381,8 @@ int pea_prof_report(int fam, double* ms, double* flops, double* bytes, long long
 void pea_debug_set_attn_tr(int v);
 /* A/B aid: 1 = dQ and dK/dV workgroups of an attention backward in ONE launch (default), 0 = two launches */
 void pea_debug_set_attn_fused_bwd(int v);
+/* 0: cross-attention backward (<= 128 keys, head_dim 64) on the general kernels instead of the one-pass kernel (A/B) */
+void pea_debug_set_attn_xattn(int v);
 /* benchmark aid: force GEMM tile variant (>= 0) or restore the shape-based choice (-1) */
 void pea_debug_set_gemm_variant(int v);
 /* timing-only probes of the loader/consumer GEMM (results are wrong while set): 1 no DMA, 2 no barriers, 4 no ds_reads */

@@ -37,6 +37,31 @@ __device__ __forceinline__ int swz_rc(int row, int col) {   // byte offset of el
   return row * 128 + ((((col >> 3)) ^ swz_x(row)) << 4) + (col & 7) * 2;
 }
 
+// LDS-DMA issued through inline assembly.  With the builtin, hipcc's waitcnt pass knows that an LDS write is pending and puts
+// `s_waitcnt vmcnt(0)` in front of the next LDS read it cannot prove disjoint -- every ds_read_b64_tr_b16 (an intrinsic
+// without a memory operand) -- i.e. in the middle of the very iteration whose compute is meant to hide the prefetch of the
+// next tile (forward: before the P.V reads; dQ role: before the first read).  The asm form is invisible to that pass; the
+// loops order DMA and reads themselves (`s_waitcnt vmcnt(0)` + barrier at the end of every iteration).
+// vmcnt(0) as the BUILTIN (expcnt / lgkmcnt left at their maxima): the waitcnt pass must see it, or it keeps believing
+// that the prologue's global loads are outstanding and re-waits for them with counted vmcnt(N) inside the loop -- which, with
+// DMA pieces it does not know about in flight, waits for those pieces instead.
+#define WAIT_VM0()                           \
+  do {                                       \
+    __builtin_amdgcn_s_waitcnt(0x0F70);      \
+    asm volatile("" ::: "memory");           \
+  } while (0)
+__device__ __forceinline__ unsigned lds_addr_u32(const void* p) {
+  return (unsigned)(unsigned long long)p;      // a flat pointer into LDS is (shared aperture base << 32) | LDS byte offset
+}
+__device__ __forceinline__ void lds_dma16(const void* gsrc, const char* lds_dst) {     // 64 lanes x 16 bytes -> lds_dst[0..1023]
+  const unsigned a = __builtin_amdgcn_readfirstlane(lds_addr_u32(lds_dst));
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(a), "v"(gsrc) : "m0");
+}
+__device__ __forceinline__ void lds_dma4(const void* gsrc, const char* lds_dst) {      // 64 lanes x 4 bytes -> lds_dst[0..255]
+  const unsigned a = __builtin_amdgcn_readfirstlane(lds_addr_u32(lds_dst));
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, off" ::"s"(a), "v"(gsrc) : "m0");
+}
+
 // stage a 64x64 tile: rows r0.. (clamped to rmax-1) of `src` (row stride ld elements) -> dst (LDS)
 __device__ __forceinline__ void stage_tile(const bf16* src, int ld, int r0, int rmax, char* dst, int wave, int lane) {
 #pragma unroll
@@ -46,8 +71,7 @@ __device__ __forceinline__ void stage_tile(const bf16* src, int ld, int r0, int 
     const int chunk = (lane & 7) ^ swz_x(r);
     int gr = r0 + r;
     gr = gr < rmax ? gr : rmax - 1;
-    __builtin_amdgcn_global_load_lds(PEA_GLB(src + (long long)gr * ld + chunk * 8), PEA_LDS(dst + piece * 1024), 16,
-                                     0, 0);
+    lds_dma16(src + (long long)gr * ld + chunk * 8, dst + piece * 1024);
   }
 }
 
@@ -192,8 +216,11 @@ __device__ __forceinline__ void attn_q_body(const AttnP& p, char* smem, int blk_
     }
   };
   const int nt = (p.Skv + 63) / 64;
+  // read ONCE, before the loop: a global load inside it makes the compiler wait for vmcnt(0) there, i.e. for the DMA
+  // prefetch of the next tile as well
+  const int skv_all = __builtin_amdgcn_readfirstlane(p.kv_len ? p.kv_len[b] : p.Skv);
   stage_kv(smem, 0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  WAIT_VM0();
   __syncthreads();
 
   // Per-lane LDS byte offsets, computed once.  The swizzle term of a row is unchanged by +16 / +32 rows, so every fragment
@@ -259,7 +286,7 @@ __device__ __forceinline__ void attn_q_body(const AttnP& p, char* smem, int blk_
       // TXT (text encoders, inference): causal mask and / or a per-sample key count (padding) -- a separate instance
       // so the UNet's kernel keeps its register budget
       int skv_b = p.Skv;
-      if constexpr (TXT) skv_b = p.kv_len ? p.kv_len[b] : p.Skv;
+      if constexpr (TXT) skv_b = skv_all;
       float cc = c;                     // factor between the values in sacc and the log2 domain
       if constexpr (TXT) {
         if (p.bias) {
@@ -318,7 +345,7 @@ __device__ __forceinline__ void attn_q_body(const AttnP& p, char* smem, int blk_
       m_run = m_new;
     } else {
       // P^T = exp2(c S^T - lse2[q]);  dP^T = V . dO^T;  dS^T = P^T (dP^T - delta[q]) scale
-      const int skv_b = p.kv_len ? p.kv_len[b] : p.Skv;          // per-sample valid keys (padded contexts)
+      const int skv_b = skv_all;                                 // per-sample valid keys (padded contexts)
       f32x16 dpacc[2];
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb)
@@ -374,7 +401,7 @@ __device__ __forceinline__ void attn_q_body(const AttnP& p, char* smem, int blk_
         for (int db = 0; db < 2; ++db)
           oacc[2 * no + db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tfr[ks][db], pf[ks], oacc[2 * no + db], 0, 0, 0);
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    WAIT_VM0();
     __syncthreads();
   }
 
@@ -419,8 +446,8 @@ __device__ __forceinline__ void stage_rowconst(const float* lse, const float* dl
   if (wave != 0) return;
   int r = r0 + lane;
   r = r < rmax ? r : rmax - 1;
-  __builtin_amdgcn_global_load_lds(PEA_GLB(lse + r), PEA_LDS(dst), 4, 0, 0);
-  __builtin_amdgcn_global_load_lds(PEA_GLB(dlt + r), PEA_LDS(dst + 256), 4, 0, 0);
+  lds_dma4(lse + r, dst);
+  lds_dma4(dlt + r, dst + 256);
 }
 
 // ============================================================================= dK / dV
@@ -482,7 +509,7 @@ __device__ __forceinline__ void attn_dkv_body(const AttnP& p, char* smem, int bl
   const int t_begin = split * tps;
   const int nt = min(nt_all, t_begin + tps);
   if (t_begin < nt) stage_q(smem, t_begin * 64);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  WAIT_VM0();
   __syncthreads();
 
   for (int t = t_begin; t < nt; ++t) {
@@ -554,7 +581,7 @@ __device__ __forceinline__ void attn_dkv_body(const AttnP& p, char* smem, int bl
           }
       }
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    WAIT_VM0();
     __syncthreads();
   }
   if (!kstored) return;
@@ -627,6 +654,293 @@ __global__ __launch_bounds__(256, (ND == 1 ? 2 : 1)) void attn_bwd_fused_kernel(
   else attn_q_body<1, USE_TR, ND, false, false>(p, smem, rem - n_dkv, head, b);
 }
 
+// ============================================================================= cross-attention backward, ONE pass
+// Few keys (the text context: 77 tokens -> KB = 3 blocks of 32), many queries, head_dim 64.  The general path costs three
+// launches (delta, dQ + dK/dV roles, split reduce) that each stream Q / dO again and are latency-bound on their short
+// key loops.  Here a workgroup owns a run of 128-query units of one (batch, head): K and V stay in LDS for its whole
+// life, a unit's Q / dO tiles (+ lse) arrive by LDS-DMA one unit ahead, delta = rowsum(dO * O) is formed in-kernel
+// (dO from the staged tile, O prefetched from HBM one unit ahead), and both orientations run off the same tiles:
+//   query on the lane (wave w = queries 32w..32w+31):  S^T, dP^T -> dS^T -> dQ^T = K^T dS^T           (written per unit)
+//   key on the lane   (wave w = keys 32w..32w+31, w < KB):  S, dP -> P, dS -> dV^T += dO^T P, dK^T += Q^T dS
+// dK / dV partial sums of the workgroup go to p.dkv_part[split] (fixed-order reduce, attn_dkv_reduce_kernel) or, with
+// one split, straight to dK / dV.
+template <int KB>
+__global__ __launch_bounds__(256, 2) void xattn_bwd_kernel(const AttnP p, int upw) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  // LDS: K rows 0..127 | V rows 0..127 (two 64-row tiles each; 32 KB) | ONE stage: Q tiles 0,1 | dO tiles 0,1 | lse | delta
+  // = 65 KB, two workgroups per CU: the other workgroup's compute covers this one's DMA wait (the stage is not double
+  // buffered: with one wave per SIMD and 98 KB the single resident workgroup ran its dependency chains back to back,
+  // 10 us per unit)
+  char* const Ksm = smem;
+  char* const Vsm = smem + 2 * TILE_BYTES;
+  char* const S0 = smem + 4 * TILE_BYTES;
+  float* const rc = (float*)(S0 + 4 * TILE_BYTES);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int frow = lane & 31, fh = lane >> 5;
+  int split, head, b;
+  attn_block_coords(p.xcd_remap, split, head, b);
+  const int nu = (p.Sq + 127) >> 7;
+  const int u_begin = split * upw, u_end = min(nu, u_begin + upw);
+  const float c = p.scale * LOG2E;
+  const bf16* Qb = p.Q + (long long)b * p.Sq * p.ldq + head * 64;
+  const bf16* dOb = p.dO + (long long)b * p.Sq * p.lddo + head * 64;
+  const bf16* Ob = p.O + (long long)b * p.Sq * p.ldo + head * 64;
+  const bf16* Kb = p.K + (long long)b * p.Skv * p.ldk + head * 64;
+  const bf16* Vb = p.V + (long long)b * p.Skv * p.ldv + head * 64;
+  const float* lseb = p.lse + ((long long)b * p.H + head) * p.Sq;
+  const int skv_b = __builtin_amdgcn_readfirstlane(p.kv_len ? p.kv_len[b] : p.Skv);
+
+  auto stage_unit = [&](int u) {
+    const int r0 = u * 128;
+    stage_tile(Qb, p.ldq, r0, p.Sq, S0, wave, lane);
+    stage_tile(Qb, p.ldq, r0 + 64, p.Sq, S0 + TILE_BYTES, wave, lane);
+    stage_tile(dOb, p.lddo, r0, p.Sq, S0 + 2 * TILE_BYTES, wave, lane);
+    stage_tile(dOb, p.lddo, r0 + 64, p.Sq, S0 + 3 * TILE_BYTES, wave, lane);
+    if (wave < 2) {
+      int r = r0 + wave * 64 + lane;
+      r = r < p.Sq ? r : p.Sq - 1;
+      lds_dma4(lseb + r, S0 + 4 * TILE_BYTES + wave * 256);
+    }
+  };
+  // delta: thread = (query of the unit, half of the head dimension); its O values are fetched together with the stage
+  const int dq_l = tid >> 1, dhalf = tid & 1;
+  bf16x8 o_pf[4];
+  auto fetch_o = [&](int u) {
+    int r = u * 128 + dq_l;
+    r = r < p.Sq ? r : p.Sq - 1;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) o_pf[i] = *(const bf16x8*)(Ob + (long long)r * p.ldo + dhalf * 32 + 8 * i);
+  };
+
+  stage_tile(Kb, p.ldk, 0, p.Skv, Ksm, wave, lane);
+  stage_tile(Vb, p.ldv, 0, p.Skv, Vsm, wave, lane);
+  if (KB > 2) {
+    stage_tile(Kb, p.ldk, 64, p.Skv, Ksm + TILE_BYTES, wave, lane);
+    stage_tile(Vb, p.ldv, 64, p.Skv, Vsm + TILE_BYTES, wave, lane);
+  }
+  if (u_begin < u_end) {
+    stage_unit(u_begin);
+    fetch_o(u_begin);
+  }
+  // key-on-the-lane role: this wave's 32 keys as B-operand fragments, for the whole kernel
+  int krow = wave * 32 + frow;
+  const bool kstored = krow < p.Skv, kvalid = krow < skv_b;
+  krow = kstored ? krow : p.Skv - 1;
+  const bool wave_keys = wave < KB && wave * 32 < p.Skv;       // wave-uniform
+  f32x16 dk[2], dv[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dk[i][r] = dv[i][r] = 0.f;
+  // this wave's keys as B-operand fragments come from the K / V images in LDS, per query block (kept in registers for the
+  // whole kernel they cost 32 VGPRs and the 256-register budget of two workgroups per CU spills)
+  const char* const Kmine = Ksm + (wave >> 1) * TILE_BYTES;
+  const char* const Vmine = Vsm + (wave >> 1) * TILE_BYTES;
+  const int kmine_row = (wave & 1) * 32 + frow;
+
+  for (int u = u_begin; u < u_end; ++u) {
+    WAIT_VM0();
+    __syncthreads();                                             // the unit's tiles, lse and this thread's O values are here
+    {
+      const char* dt = S0 + (2 + (dq_l >> 6)) * TILE_BYTES;
+      const int row = dq_l & 63;
+      float dsum = 0.f;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const bf16x8 d = *(const bf16x8*)(dt + row * 128 + (((dhalf * 4 + i) ^ swz_x(row)) << 4));
+#pragma unroll
+        for (int j = 0; j < 8; ++j) dsum += (float)d[j] * (float)o_pf[i][j];
+      }
+      dsum += __shfl_xor(dsum, 1, 64);
+      if (dhalf == 0) rc[128 + dq_l] = dsum;
+    }
+    __syncthreads();
+
+    // ---- query on the lane: dQ of this wave's 32 queries
+    {
+      const char* Qt = S0 + (wave >> 1) * TILE_BYTES;
+      const char* dOt = S0 + (2 + (wave >> 1)) * TILE_BYTES;
+      const int rb0 = (wave & 1) * 32;
+      const int qg = u * 128 + wave * 32 + frow;
+      bf16x8 qf[4], dof[4];
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        qf[s] = read_row_frag(Qt, rb0 + frow, s, fh);
+        dof[s] = read_row_frag(dOt, rb0 + frow, s, fh);
+      }
+      const float lse2 = rc[wave * 32 + frow] * LOG2E, dlt = rc[128 + wave * 32 + frow];
+      f32x16 oacc[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[i][r] = 0.f;
+#pragma unroll 1
+      for (int kb = 0; kb < KB; ++kb) {
+        const char* Kt = Ksm + (kb >> 1) * TILE_BYTES;
+        const char* Vt = Vsm + (kb >> 1) * TILE_BYTES;
+        const int kr0 = (kb & 1) * 32;
+        f32x16 sacc, dpacc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sacc[r] = dpacc[r] = 0.f;
+        {
+          bf16x8 kfr[4], vfr[4];
+#pragma unroll
+          for (int s = 0; s < 4; ++s) {
+            kfr[s] = read_row_frag(Kt, kr0 + frow, s, fh);
+            vfr[s] = read_row_frag(Vt, kr0 + frow, s, fh);
+          }
+#pragma unroll
+          for (int s = 0; s < 4; ++s) {
+            sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr[s], qf[s], sacc, 0, 0, 0);
+            dpacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfr[s], dof[s], dpacc, 0, 0, 0);
+          }
+        }
+        bf16x8 tfr[2][2];
+#pragma unroll
+        for (int k2 = 0; k2 < 2; ++k2)
+#pragma unroll
+          for (int db = 0; db < 2; ++db) tfr[k2][db] = read_transposed_frag<true>(Kt, kr0 + k2 * 16, db * 32, lane);
+        bf16x8 pf[2];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+          const float pr = key < skv_b ? fast_exp2(fmaf(sacc[r], c, -lse2)) : 0.f;
+          pf[r >> 3][r & 7] = (bf16)(pr * (dpacc[r] - dlt) * p.scale);
+        }
+#pragma unroll
+        for (int k2 = 0; k2 < 2; ++k2)
+#pragma unroll
+          for (int db = 0; db < 2; ++db)
+            oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tfr[k2][db], pf[k2], oacc[db], 0, 0, 0);
+      }
+      if (qg < p.Sq) {
+        bf16* dst0 = p.dQ + ((long long)b * p.Sq + qg) * p.lddq + head * 64;
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            bf16* dst = dst0 + db * 32 + 8 * g + 4 * fh;
+            bf16x4 o;
+            if (p.accum_dq) o = *(const bf16x4*)dst;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] = (bf16)(oacc[db][4 * g + j] + (p.accum_dq ? (float)o[j] : 0.f));
+            *(bf16x4*)dst = o;
+          }
+      }
+    }
+    // ---- key on the lane: dK / dV of this wave's 32 keys, the unit's four 32-query blocks
+    if (wave_keys) {
+#pragma unroll 1
+      for (int qb = 0; qb < 4; ++qb) {
+        const char* Qt = S0 + (qb >> 1) * TILE_BYTES;
+        const char* dOt = S0 + (2 + (qb >> 1)) * TILE_BYTES;
+        const int rb0 = (qb & 1) * 32;
+        f32x16 sacc, dpacc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sacc[r] = dpacc[r] = 0.f;
+        {
+          bf16x8 qfr[4], kf[4];
+#pragma unroll
+          for (int s = 0; s < 4; ++s) {
+            qfr[s] = read_row_frag(Qt, rb0 + frow, s, fh);
+            kf[s] = read_row_frag(Kmine, kmine_row, s, fh);
+          }
+#pragma unroll
+          for (int s = 0; s < 4; ++s) sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qfr[s], kf[s], sacc, 0, 0, 0);
+        }
+        {
+          bf16x8 dfr[4], vf[4];
+#pragma unroll
+          for (int s = 0; s < 4; ++s) {
+            dfr[s] = read_row_frag(dOt, rb0 + frow, s, fh);
+            vf[s] = read_row_frag(Vmine, kmine_row, s, fh);
+          }
+#pragma unroll
+          for (int s = 0; s < 4; ++s) dpacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dfr[s], vf[s], dpacc, 0, 0, 0);
+        }
+        bf16x8 dot[2][2], qt[2][2];
+#pragma unroll
+        for (int k2 = 0; k2 < 2; ++k2)
+#pragma unroll
+          for (int db = 0; db < 2; ++db) {
+            dot[k2][db] = read_transposed_frag<true>(dOt, rb0 + k2 * 16, db * 32, lane);
+            qt[k2][db] = read_transposed_frag<true>(Qt, rb0 + k2 * 16, db * 32, lane);
+          }
+        bf16x8 pfr[2], dsfr[2];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int ql = qb * 32 + 8 * g + 4 * fh;               // 4 consecutive query rows of the unit
+          f32x4 l4, d4;
+          if (u * 128 + ql < p.Sq) {                             // Sq % 4 == 0: all-or-nothing
+            l4 = *(const f32x4*)(rc + ql);
+            d4 = *(const f32x4*)(rc + 128 + ql);
+          } else {
+            l4 = (f32x4){INFINITY, INFINITY, INFINITY, INFINITY};
+            d4 = (f32x4){0.f, 0.f, 0.f, 0.f};
+          }
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int r = 4 * g + j;
+            const float pr = kvalid ? fast_exp2(fmaf(sacc[r], c, -l4[j] * LOG2E)) : 0.f;
+            const float ds = pr * (dpacc[r] - d4[j]) * p.scale;
+            pfr[g >> 1][(g & 1) * 4 + j] = (bf16)pr;
+            dsfr[g >> 1][(g & 1) * 4 + j] = (bf16)ds;
+          }
+        }
+#pragma unroll
+        for (int k2 = 0; k2 < 2; ++k2)
+#pragma unroll
+          for (int db = 0; db < 2; ++db) {
+            dv[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dot[k2][db], pfr[k2], dv[db], 0, 0, 0);
+            dk[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qt[k2][db], dsfr[k2], dk[db], 0, 0, 0);
+          }
+      }
+    }
+    __syncthreads();                                             // every wave is done with the stage
+    if (u + 1 < u_end) {
+      stage_unit(u + 1);
+      fetch_o(u + 1);
+    }
+  }
+  if (!wave_keys || !kstored) return;
+  if (p.nsplit > 1) {
+    float* pr = p.dkv_part + ((((long long)split * p.B + b) * p.H + head) * p.Skv + krow) * 128;
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int d = db * 32 + 8 * g + 4 * fh;
+        f32x4 a, cc;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { a[j] = dk[db][4 * g + j]; cc[j] = dv[db][4 * g + j]; }
+        *(f32x4*)(pr + d) = a;
+        *(f32x4*)(pr + 64 + d) = cc;
+      }
+    return;
+  }
+  bf16* dKr = p.dK + ((long long)b * p.Skv + krow) * p.lddk + head * 64;
+  bf16* dVr = p.dV + ((long long)b * p.Skv + krow) * p.lddv + head * 64;
+#pragma unroll
+  for (int db = 0; db < 2; ++db)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int d = db * 32 + 8 * g + 4 * fh;
+      bf16x4 ok, ov;
+      if (p.accum_dkv) {
+        ok = *(const bf16x4*)(dKr + d);
+        ov = *(const bf16x4*)(dVr + d);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        ok[j] = (bf16)(dk[db][4 * g + j] + (p.accum_dkv ? (float)ok[j] : 0.f));
+        ov[j] = (bf16)(dv[db][4 * g + j] + (p.accum_dkv ? (float)ov[j] : 0.f));
+      }
+      *(bf16x4*)(dKr + d) = ok;
+      *(bf16x4*)(dVr + d) = ov;
+    }
+}
+
 // delta[b][h][q] = sum_d dO[q][h*D+d] * O[q][h*D+d]; 8 lanes per (row, head), each sums D/8 elements
 __global__ __launch_bounds__(256) void attn_delta_kernel(const AttnP p) {
   const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;   // one thread per (b, q, head, 8-lane slot)
@@ -684,12 +998,23 @@ __global__ void attn_dkv_reduce_kernel(const AttnP p) {
   *(bf16x4*)dst = o;
 }
 
-// query-range splitting for the dK/dV kernel when the key count gives too few workgroups
+// query-range splitting of the cross-attention backward (few keys, many queries): a workgroup owns `u` consecutive
+// 128-query units of one (batch, head); pick the u that minimises (rounds of 512 workgroups: two per CU) x u, then the
+// split count (fp32 partials per split).  1024 tokens, B*H = 80: u = 2 -> 320 workgroups, 4 splits; 4096 tokens, 40:
+// u = 3 -> 440 workgroups, 11 splits.
 int attention_bwd_nsplit(int B, int H, int Sq, int Skv) {
   if (Skv > 128 || Sq < 512) return 1;
-  const int nt = (Sq + 63) / 64;
-  int ns = nt / 4;                               // 256 queries per split
-  return ns < 1 ? 1 : ns;
+  const int nu = (Sq + 127) / 128;
+  const long long bh = (long long)B * H;
+  long long best = -1;
+  int best_ns = 1;
+  for (int u = 1; u <= nu; ++u) {
+    const int ns = (nu + u - 1) / u;
+    const long long rounds = (bh * ns + 511) / 512;
+    const long long cost = rounds * u * 64 + ns;
+    if (best < 0 || cost < best) { best = cost; best_ns = ns; }
+  }
+  return best_ns;
 }
 size_t attention_bwd_scratch_bytes(int B, int H, int Sq, int Skv, int nd) {
   const int ns = attention_bwd_nsplit(B, H, Sq, Skv);
@@ -750,11 +1075,42 @@ static int attn_fwd_nd(const AttnP& p, hipStream_t s) {
   return PEA_OK;
 }
 static int g_attn_fused_bwd = getenv("PEA_ATTN_BWD_SPLIT") ? 0 : 1;      // PEA_ATTN_BWD_SPLIT=1: the two-launch form (A/B)
+static int g_attn_xattn = getenv("PEA_XATTN_OFF") ? 0 : 1;               // PEA_XATTN_OFF=1: cross-attention on the general kernels (A/B)
+extern "C" void pea_debug_set_attn_xattn(int v) { g_attn_xattn = v; }
+// the one-pass cross-attention backward: head_dim 64, at most 128 keys, all three gradients wanted
+static bool attn_use_xattn(const AttnP& p) {
+  return g_attn_xattn && g_attn_use_tr && p.nd == 1 && p.Skv <= 128 && p.dQ && p.dK && p.dV && (p.nsplit <= 1 || p.dkv_part);
+}
 extern "C" void pea_debug_set_attn_fused_bwd(int v) { g_attn_fused_bwd = v; }
 template <int ND>
 static int attn_bwd_nd(const AttnP& p, hipStream_t s) {
   int rc = attn_set_lds_attr<ND>();
   if (rc) return rc;
+  if constexpr (ND == 1) {
+    if (attn_use_xattn(p)) {
+      constexpr int lds = 4 * TILE_BYTES + (4 * TILE_BYTES + 1024);
+      static bool attr = false;
+      if (!attr) {
+        HIPCHK(hipFuncSetAttribute((const void*)xattn_bwd_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        HIPCHK(hipFuncSetAttribute((const void*)xattn_bwd_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        HIPCHK(hipFuncSetAttribute((const void*)xattn_bwd_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        HIPCHK(hipFuncSetAttribute((const void*)xattn_bwd_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        attr = true;
+      }
+      const int ns = p.nsplit > 1 ? p.nsplit : 1, nu = cdiv(p.Sq, 128), upw = cdiv(nu, ns);
+      const dim3 grid(ns, p.H, p.B);
+      const int kb = cdiv(p.Skv, 32);
+      if (kb == 1) hipLaunchKernelGGL(xattn_bwd_kernel<1>, grid, dim3(256), lds, s, p, upw);
+      else if (kb == 2) hipLaunchKernelGGL(xattn_bwd_kernel<2>, grid, dim3(256), lds, s, p, upw);
+      else if (kb == 3) hipLaunchKernelGGL(xattn_bwd_kernel<3>, grid, dim3(256), lds, s, p, upw);
+      else hipLaunchKernelGGL(xattn_bwd_kernel<4>, grid, dim3(256), lds, s, p, upw);
+      if (p.nsplit > 1) {
+        const long long total = (long long)p.B * p.H * p.Skv * 2 * 16;
+        hipLaunchKernelGGL(attn_dkv_reduce_kernel, dim3((unsigned)cdivl(total, 256)), dim3(256), 0, s, p);
+      }
+      return PEA_OK;
+    }
+  }
   if (p.dQ && p.dK && p.dV && g_attn_fused_bwd) {
     static bool attr = false;
     constexpr int lds = 2 * (2 * ND * TILE_BYTES + 512);
@@ -819,7 +1175,7 @@ int launch_attention_bwd(const AttnP& p0, hipStream_t s) {
   PROF_BEGIN(3, 10.0 * p.B * p.H * (double)p.Sq * p.Skv * 64 * p.nd, 2.0 * p.B * p.H * 64 * p.nd * (4.0 * p.Sq + 4.0 * p.Skv), s);
   // delta: its own (memory-bound) kernel for the fused launch and for dK/dV-only calls; the two-launch form computes it
   // inside the dQ pass
-  if (!p.dQ || (p.dK && p.dV && g_attn_fused_bwd))
+  if (!attn_use_xattn(p) && (!p.dQ || (p.dK && p.dV && g_attn_fused_bwd)))
     hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)cdivl(total, 256)), dim3(256), 0, s, p);
   rc = p.nd == 1 ? attn_bwd_nd<1>(p, s) : p.nd == 2 ? attn_bwd_nd<2>(p, s) : attn_bwd_nd<3>(p, s);
   PROF_END(s);

@@ -31,6 +31,15 @@ for (B, H, Sq, Skv) in shapes:
             tb = timeit(lambda: ops.attention_bwd(q, k, v, o, do, lse, H))
             res.setdefault(mode, []).append(tb)
     lib().pea_debug_set_attn_fused_bwd(1)
+    xline = ""
+    if Skv <= 128:                            # one-pass cross-attention backward vs the general kernels
+        tx = {0: 1e9, 1: 1e9}
+        for rnd in range(3):
+            for mode in (0, 1):
+                lib().pea_debug_set_attn_xattn(mode)
+                tx[mode] = min(tx[mode], timeit(lambda: ops.attention_bwd(q, k, v, o, do, lse, H), 20))
+        lib().pea_debug_set_attn_xattn(1)
+        xline = f" [one-pass {tx[1]*1e6:6.1f} us vs general kernels {tx[0]*1e6:6.1f} us]"
     g1 = ops.attention_bwd(q, k, v, o, do, lse, H)
     lib().pea_debug_set_attn_fused_bwd(0)
     g0 = ops.attention_bwd(q, k, v, o, do, lse, H)
@@ -38,4 +47,4 @@ for (B, H, Sq, Skv) in shapes:
     same = all(torch.equal(a, b) for a, b in zip(g1, g0))
     t1, t0 = min(res[1]), min(res[0])
     print(f"attn B{B} H{H} Sq{Sq} Skv{Skv}: fwd {tf*1e6:7.1f} us {fl/tf/1e12:6.1f} TF | bwd fused {t1*1e6:7.1f} us {2.5*fl/t1/1e12:6.1f} TF, "
-          f"two launches {t0*1e6:7.1f} us {2.5*fl/t0/1e12:6.1f} TF (bit-identical: {same}) | max err {err:.3e}", flush=True)
+          f"two launches {t0*1e6:7.1f} us {2.5*fl/t0/1e12:6.1f} TF (bit-identical: {same}) | max err {err:.3e}{xline}", flush=True)

@@ -274,7 +274,10 @@ def _attn_ref(q, k, v, H):
 
 @pytest.mark.parametrize("use_tr", [1, 0])
 @pytest.mark.parametrize("B,H,Sq,Skv", [(2, 2, 256, 256), (1, 3, 128, 77), (2, 2, 16, 16), (1, 2, 1024, 200),
-                                        (1, 1, 64, 7), (2, 2, 1024, 77), (1, 2, 576, 77)])
+                                        (1, 1, 64, 7), (2, 2, 1024, 77), (1, 2, 576, 77),
+                                        # one-pass cross-attention backward (<= 128 keys): ragged query counts of the aspect-ratio
+                                        # buckets (14x26, 28x52 tokens), 1..4 key blocks, several query splits
+                                        (1, 2, 364, 77), (2, 3, 1456, 77), (1, 2, 640, 128), (1, 2, 512, 100), (1, 2, 260, 33)])
 def test_attention_fwd_bwd(ops, use_tr, B, H, Sq, Skv):
     from pea_diffusion_amd._lib import lib
     lib().pea_debug_set_attn_tr(use_tr)
