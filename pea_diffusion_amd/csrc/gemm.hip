@@ -811,6 +811,9 @@ __global__ __launch_bounds__((WM * WN + LW + SW) * 64, (OCC == 2 ? 3 : 1)) void 
   }
   if (wave >= NWC) {
     // ============================== loader waves
+    // DMA waves issue ahead of the MFMA waves: +0.3..1.0 % on every shape (scripts/gemm_prio_probe.py; bit 64 of the debug
+    // word = the old equal priorities for an A/B)
+    if (!(p.debug & 64)) __builtin_amdgcn_s_setprio(3);
     const int lw = wave - NWC;
     const int lrow = lane >> 3, cpos = lane & 7;
     const bf16* a_src[PA];
