@@ -101,7 +101,7 @@ int pea_op_attention_fwd(const void* Q, int ldq, const void* K, int ldk, const v
 int pea_op_attention_fwd_masked(const void* Q, int ldq, const void* K, int ldk, const void* V, int ldv, void* O, int ldo,
                                 float* lse, int B, int H, int Sq, int Skv, float scale, int causal, const int* kv_len,
                                 void* stream);
-/* dQ/dK/dV (dQ may be NULL; dK and dV together); delta: fp32 scratch [B][H][Sq]; scratch: optional device
+/* dQ/dK/dV (dQ may be NULL; dK and dV together); delta: fp32 scratch [2][B][H][Sq] (row constants of the backward kernels); scratch: optional device
  * buffer of pea_op_attention_bwd_scratch_bytes(...) bytes enabling the query-split dK/dV form used when the
  * key count is small (cross-attention); NULL = single pass                                            */
 long long pea_op_attention_bwd_scratch_bytes(int B, int H, int Sq, int Skv, int nd);

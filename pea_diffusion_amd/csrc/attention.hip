@@ -198,8 +198,18 @@ __device__ __forceinline__ void attn_q_body(const AttnP& p, char* smem, int blk_
       }
     dsum += __shfl_xor(dsum, 32, 64);
     dlt = dsum;
-    if (WRITE_DELTA && qvalid && fh == 0 && chunk == 0) p.delta[li] = dsum;
+    if (WRITE_DELTA && qvalid && fh == 0 && chunk == 0) {       // row constants of the dK/dV kernel (see attn_delta_kernel)
+      p.delta[li] = -dsum;
+      p.delta[(long long)p.B * p.H * p.Sq + li] = -lse2;
+    }
   }
+  // dP^T accumulates ON TOP OF -delta[q] (the MFMA's C operand: this lane's query, the same value in all 16 registers, for
+  // every key tile), so dS^T = P^T (dP^T - delta) costs one multiply per score; the softmax scale is applied once, to the
+  // finished dQ^T.  The backward loops are VALU-issue-bound (a probe with a 4-cycle stand-in for the 8-cycle v_exp_f32 ran
+  // 11 % faster): per score fma + exp + mul + half a conversion instead of fma + exp + sub + mul + mul + conversion.
+  f32x16 negd;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) negd[r] = -dlt;
 
   f32x16 oacc[2 * NO];
 #pragma unroll
@@ -319,7 +329,7 @@ __device__ __forceinline__ void attn_q_body(const AttnP& p, char* smem, int blk_
       }
       float mx = fmaxf(sacc[0][0], sacc[1][0]);
 #pragma unroll
-      for (int r = 1; r < 16; ++r) mx = fmaxf(mx, fmaxf(sacc[0][r], sacc[1][r]));
+      for (int r = 1; r < 16; ++r) mx = fmaxf(fmaxf(mx, sacc[0][r]), sacc[1][r]);     // one v_max3 per pair of scores
       mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
       const float m_new = fmaxf(m_run, mx);
       const bool moved = m_new != m_run;
@@ -348,10 +358,6 @@ __device__ __forceinline__ void attn_q_body(const AttnP& p, char* smem, int blk_
       const int skv_b = skv_all;                                 // per-sample valid keys (padded contexts)
       f32x16 dpacc[2];
 #pragma unroll
-      for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) dpacc[kb][r] = 0.f;
-#pragma unroll
       for (int nd = 0; nd < ND; ++nd) {
         bf16x8 vfr[2][4];
 #pragma unroll
@@ -363,7 +369,8 @@ __device__ __forceinline__ void attn_q_body(const AttnP& p, char* smem, int blk_
         for (int s = 0; s < 4; ++s)
 #pragma unroll
           for (int kb = 0; kb < 2; ++kb)
-            dpacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfr[kb][s], dof[MODE == 1 ? nd : 0][s], dpacc[kb], 0, 0, 0);
+            dpacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfr[kb][s], dof[MODE == 1 ? nd : 0][s],
+                                                                (nd == 0 && s == 0) ? negd : dpacc[kb], 0, 0, 0);
       }
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb)
@@ -372,7 +379,7 @@ __device__ __forceinline__ void attn_q_body(const AttnP& p, char* smem, int blk_
           const int key = kv0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
           float pr = fast_exp2(fmaf(sacc[kb][r], c, -lse2));
           if (kv0 + 64 > skv_b) pr = key < skv_b ? pr : 0.f;      // uniform branch: only tiles holding masked keys
-          sacc[kb][r] = pr * (dpacc[kb][r] - dlt) * p.scale;
+          sacc[kb][r] = pr * dpacc[kb][r];                         // = P (dP - delta); x scale in the epilogue
         }
     }
 #pragma unroll
@@ -406,7 +413,7 @@ __device__ __forceinline__ void attn_q_body(const AttnP& p, char* smem, int blk_
   }
 
   // epilogue: oacc[2*no+db][4g+j] = X^T[d = no*64 + db*32 + 8g + 4h + j][q = lane&31]
-  float inv = 1.f;
+  float inv = MODE == 1 ? p.scale : 1.f;
   if (MODE == 0) {
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
     inv = 1.f / l_tot;
@@ -473,8 +480,9 @@ __device__ __forceinline__ void attn_dkv_body(const AttnP& p, char* smem, int bl
   const bf16* dOb = p.dO + (long long)b * p.Sq * p.lddo + head * 64 * ND;
   const bf16* Kb = p.K + (long long)b * p.Skv * p.ldk + head * 64 * ND;
   const bf16* Vb = p.V + (long long)b * p.Skv * p.ldv + head * 64 * ND;
-  const float* lseb = p.lse + ((long long)b * p.H + head) * p.Sq;
+  // row constants written by attn_delta_kernel (or the dQ pass): -delta[q] and -lse[q] * log2(e)
   const float* dltb = p.delta + ((long long)b * p.H + head) * p.Sq;
+  const float* lseb = dltb + (long long)p.B * p.H * p.Sq;
 
   int krow = k0 + frow;
   const bool kstored = krow < p.Skv;          // the row exists in K / V / dK / dV
@@ -495,6 +503,9 @@ __device__ __forceinline__ void attn_dkv_body(const AttnP& p, char* smem, int bl
   for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int r = 0; r < 16; ++r) dk[i][r] = dv[i][r] = 0.f;
+  f32x16 kmask;                                // C operand of the S products: 0, or -inf on the lane of a padding key
+#pragma unroll
+  for (int r = 0; r < 16; ++r) kmask[r] = kvalid ? 0.f : -INFINITY;
 
   auto stage_q = [&](char* dst, int r0) {
 #pragma unroll
@@ -518,19 +529,35 @@ __device__ __forceinline__ void attn_dkv_body(const AttnP& p, char* smem, int bl
     const char* Qs = smem + cur * STG;
     const char* dOs = Qs + ND * TILE_BYTES;
     const float* rc = (const float*)(Qs + 2 * ND * TILE_BYTES);
+    if (t * 64 + 64 > p.Sq) {
+      // ragged last tile (uniform, once per workgroup): the staged rows >= Sq repeat row Sq-1; give them -lse*log2e = -inf
+      // (P = exp2(-inf) = 0) so the loop below needs no per-row predicate
+      if (wave == 0 && t * 64 + lane >= p.Sq) {
+        float* rw = (float*)(Qs + 2 * ND * TILE_BYTES);
+        rw[lane] = -INFINITY;
+        rw[64 + lane] = 0.f;
+      }
+      __syncthreads();
+    }
     if (wave_active) {
-      // S[q][key] = Q . K^T ; dP[q][key] = dO . V^T   (rows q in registers, key on the lane)
+      // S[q][key] = Q . K^T ; dP[q][key] = dO . V^T   (rows q in registers, key on the lane).  Both accumulations start
+      // from a C operand instead of zero: S from kmask (0, or -inf for a padding key: P = 0 without a select per score), dP
+      // from the staged -delta[q] (row q = register index: the four 16-byte LDS loads ARE the MFMA's C operand)
       f32x16 sacc[2], dpacc[2];
 #pragma unroll
       for (int qb = 0; qb < 2; ++qb) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) sacc[qb][r] = dpacc[qb][r] = 0.f;
+        for (int g = 0; g < 4; ++g) {
+          const f32x4 d4 = *(const f32x4*)(rc + 64 + qb * 32 + 8 * g + 4 * fh);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) dpacc[qb][4 * g + j] = d4[j];
+        }
 #pragma unroll
         for (int nd = 0; nd < ND; ++nd)
 #pragma unroll
           for (int s = 0; s < 4; ++s) {
             const bf16x8 qfr = read_row_frag(Qs + nd * TILE_BYTES, qb * 32 + frow, s, fh);
-            sacc[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qfr, kf[nd][s], sacc[qb], 0, 0, 0);
+            sacc[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qfr, kf[nd][s], (nd == 0 && s == 0) ? kmask : sacc[qb], 0, 0, 0);
             const bf16x8 dfr = read_row_frag(dOs + nd * TILE_BYTES, qb * 32 + frow, s, fh);
             dpacc[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dfr, vf[nd][s], dpacc[qb], 0, 0, 0);
           }
@@ -540,20 +567,12 @@ __device__ __forceinline__ void attn_dkv_body(const AttnP& p, char* smem, int bl
       for (int qb = 0; qb < 2; ++qb)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-          const int q = t * 64 + qb * 32 + 8 * g + 4 * fh;     // 4 consecutive query rows
-          f32x4 l4, d4;
-          if (q < p.Sq) {                                      // Sq % 4 == 0: all-or-nothing
-            l4 = *(const f32x4*)(rc + qb * 32 + 8 * g + 4 * fh);
-            d4 = *(const f32x4*)(rc + 64 + qb * 32 + 8 * g + 4 * fh);
-          } else {
-            l4 = (f32x4){INFINITY, INFINITY, INFINITY, INFINITY};
-            d4 = (f32x4){0.f, 0.f, 0.f, 0.f};
-          }
+          const f32x4 l4 = *(const f32x4*)(rc + qb * 32 + 8 * g + 4 * fh);      // -lse * log2(e) of 4 consecutive query rows
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
             const int r = 4 * g + j;
-            const float pr = kvalid ? fast_exp2(fmaf(sacc[qb][r], c, -l4[j] * LOG2E)) : 0.f;
-            const float ds = pr * (dpacc[qb][r] - d4[j]) * p.scale;
+            const float pr = fast_exp2(fmaf(sacc[qb][r], c, l4[j]));
+            const float ds = pr * dpacc[qb][r];                // P (dP - delta); x scale on the finished dK
             const int ks = qb * 2 + (g >> 1), e = (g & 1) * 4 + j;
             pfr[ks][e] = (bf16)pr;
             dsfr[ks][e] = (bf16)ds;
@@ -585,6 +604,10 @@ __device__ __forceinline__ void attn_dkv_body(const AttnP& p, char* smem, int bl
     __syncthreads();
   }
   if (!kstored) return;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dk[i][r] *= p.scale;
   const int D = 64 * ND;
   if (p.nsplit > 1) {
     float* pr = p.dkv_part + ((((long long)split * p.B + b) * p.H + head) * p.Skv + krow) * 2 * D + chunk * 64;
@@ -735,6 +758,7 @@ __global__ __launch_bounds__(256, 2) void xattn_bwd_kernel(const AttnP p, int up
     for (int r = 0; r < 16; ++r) dk[i][r] = dv[i][r] = 0.f;
   // this wave's keys as B-operand fragments come from the K / V images in LDS, per query block (kept in registers for the
   // whole kernel they cost 32 VGPRs and the 256-register budget of two workgroups per CU spills)
+  const bool wave_pad = wave * 32 + 32 > skv_b;                 // wave-uniform: this wave's key block holds padding keys
   const char* const Kmine = Ksm + (wave >> 1) * TILE_BYTES;
   const char* const Vmine = Vsm + (wave >> 1) * TILE_BYTES;
   const int kmine_row = (wave & 1) * 32 + frow;
@@ -753,7 +777,11 @@ __global__ __launch_bounds__(256, 2) void xattn_bwd_kernel(const AttnP p, int up
         for (int j = 0; j < 8; ++j) dsum += (float)d[j] * (float)o_pf[i][j];
       }
       dsum += __shfl_xor(dsum, 1, 64);
-      if (dhalf == 0) rc[128 + dq_l] = dsum;
+      if (dhalf == 0) {                       // the unit's row constants, negated: C operand of dP, addend of the exp2 argument
+        const bool rv = u * 128 + dq_l < p.Sq;             // rows past Sq (ragged last unit): P = exp2(-inf) = 0
+        rc[128 + dq_l] = rv ? -dsum : 0.f;
+        rc[dq_l] = rv ? -rc[dq_l] * LOG2E : -INFINITY;
+      }
     }
     __syncthreads();
 
@@ -769,7 +797,10 @@ __global__ __launch_bounds__(256, 2) void xattn_bwd_kernel(const AttnP p, int up
         qf[s] = read_row_frag(Qt, rb0 + frow, s, fh);
         dof[s] = read_row_frag(dOt, rb0 + frow, s, fh);
       }
-      const float lse2 = rc[wave * 32 + frow] * LOG2E, dlt = rc[128 + wave * 32 + frow];
+      const float nlse2 = rc[wave * 32 + frow], ndlt = rc[128 + wave * 32 + frow];
+      f32x16 negd;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) negd[r] = ndlt;
       f32x16 oacc[2];
 #pragma unroll
       for (int i = 0; i < 2; ++i)
@@ -781,8 +812,6 @@ __global__ __launch_bounds__(256, 2) void xattn_bwd_kernel(const AttnP p, int up
         const char* Vt = Vsm + (kb >> 1) * TILE_BYTES;
         const int kr0 = (kb & 1) * 32;
         f32x16 sacc, dpacc;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) sacc[r] = dpacc[r] = 0.f;
         {
           bf16x8 kfr[4], vfr[4];
 #pragma unroll
@@ -790,8 +819,11 @@ __global__ __launch_bounds__(256, 2) void xattn_bwd_kernel(const AttnP p, int up
             kfr[s] = read_row_frag(Kt, kr0 + frow, s, fh);
             vfr[s] = read_row_frag(Vt, kr0 + frow, s, fh);
           }
+          const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+          sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr[0], qf[0], zero16, 0, 0, 0);
+          dpacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfr[0], dof[0], negd, 0, 0, 0);
 #pragma unroll
-          for (int s = 0; s < 4; ++s) {
+          for (int s = 1; s < 4; ++s) {
             sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr[s], qf[s], sacc, 0, 0, 0);
             dpacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfr[s], dof[s], dpacc, 0, 0, 0);
           }
@@ -804,9 +836,10 @@ __global__ __launch_bounds__(256, 2) void xattn_bwd_kernel(const AttnP p, int up
         bf16x8 pf[2];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const int key = kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
-          const float pr = key < skv_b ? fast_exp2(fmaf(sacc[r], c, -lse2)) : 0.f;
-          pf[r >> 3][r & 7] = (bf16)(pr * (dpacc[r] - dlt) * p.scale);
+          float pr = fast_exp2(fmaf(sacc[r], c, nlse2));
+          if (kb * 32 + 32 > skv_b)                               // uniform: only the key block that holds padding keys
+            pr = kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh < skv_b ? pr : 0.f;
+          pf[r >> 3][r & 7] = (bf16)(pr * dpacc[r]);
         }
 #pragma unroll
         for (int k2 = 0; k2 < 2; ++k2)
@@ -824,7 +857,7 @@ __global__ __launch_bounds__(256, 2) void xattn_bwd_kernel(const AttnP p, int up
             bf16x4 o;
             if (p.accum_dq) o = *(const bf16x4*)dst;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) o[j] = (bf16)(oacc[db][4 * g + j] + (p.accum_dq ? (float)o[j] : 0.f));
+            for (int j = 0; j < 4; ++j) o[j] = (bf16)(oacc[db][4 * g + j] * p.scale + (p.accum_dq ? (float)o[j] : 0.f));
             *(bf16x4*)dst = o;
           }
       }
@@ -838,7 +871,11 @@ __global__ __launch_bounds__(256, 2) void xattn_bwd_kernel(const AttnP p, int up
         const int rb0 = (qb & 1) * 32;
         f32x16 sacc, dpacc;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) sacc[r] = dpacc[r] = 0.f;
+        for (int g = 0; g < 4; ++g) {                            // dP starts from -delta[q] (row = register index)
+          const f32x4 d4 = *(const f32x4*)(rc + 128 + qb * 32 + 8 * g + 4 * fh);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) dpacc[4 * g + j] = d4[j];
+        }
         {
           bf16x8 qfr[4], kf[4];
 #pragma unroll
@@ -846,8 +883,10 @@ __global__ __launch_bounds__(256, 2) void xattn_bwd_kernel(const AttnP p, int up
             qfr[s] = read_row_frag(Qt, rb0 + frow, s, fh);
             kf[s] = read_row_frag(Kmine, kmine_row, s, fh);
           }
+          const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+          sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qfr[0], kf[0], zero16, 0, 0, 0);
 #pragma unroll
-          for (int s = 0; s < 4; ++s) sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qfr[s], kf[s], sacc, 0, 0, 0);
+          for (int s = 1; s < 4; ++s) sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qfr[s], kf[s], sacc, 0, 0, 0);
         }
         {
           bf16x8 dfr[4], vf[4];
@@ -870,20 +909,13 @@ __global__ __launch_bounds__(256, 2) void xattn_bwd_kernel(const AttnP p, int up
         bf16x8 pfr[2], dsfr[2];
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-          const int ql = qb * 32 + 8 * g + 4 * fh;               // 4 consecutive query rows of the unit
-          f32x4 l4, d4;
-          if (u * 128 + ql < p.Sq) {                             // Sq % 4 == 0: all-or-nothing
-            l4 = *(const f32x4*)(rc + ql);
-            d4 = *(const f32x4*)(rc + 128 + ql);
-          } else {
-            l4 = (f32x4){INFINITY, INFINITY, INFINITY, INFINITY};
-            d4 = (f32x4){0.f, 0.f, 0.f, 0.f};
-          }
+          const f32x4 l4 = *(const f32x4*)(rc + qb * 32 + 8 * g + 4 * fh);     // -lse * log2(e) of 4 consecutive query rows
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
             const int r = 4 * g + j;
-            const float pr = kvalid ? fast_exp2(fmaf(sacc[r], c, -l4[j] * LOG2E)) : 0.f;
-            const float ds = pr * (dpacc[r] - d4[j]) * p.scale;
+            float pr = fast_exp2(fmaf(sacc[r], c, l4[j]));
+            if (wave_pad) pr = kvalid ? pr : 0.f;                // only the wave whose key block holds padding keys
+            const float ds = pr * dpacc[r];
             pfr[g >> 1][(g & 1) * 4 + j] = (bf16)pr;
             dsfr[g >> 1][(g & 1) * 4 + j] = (bf16)ds;
           }
@@ -904,6 +936,10 @@ __global__ __launch_bounds__(256, 2) void xattn_bwd_kernel(const AttnP p, int up
     }
   }
   if (!wave_keys || !kstored) return;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dk[i][r] *= p.scale;
   if (p.nsplit > 1) {
     float* pr = p.dkv_part + ((((long long)split * p.B + b) * p.H + head) * p.Skv + krow) * 128;
 #pragma unroll
@@ -941,7 +977,8 @@ __global__ __launch_bounds__(256, 2) void xattn_bwd_kernel(const AttnP p, int up
     }
 }
 
-// delta[b][h][q] = sum_d dO[q][h*D+d] * O[q][h*D+d]; 8 lanes per (row, head), each sums D/8 elements
+// row constants of the backward kernels: delta[0][b][h][q] = -sum_d dO[q][h*D+d] * O[q][h*D+d], delta[1][b][h][q] = -lse * log2(e);
+// 8 lanes per (row, head), each sums D/8 elements
 __global__ __launch_bounds__(256) void attn_delta_kernel(const AttnP p) {
   const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;   // one thread per (b, q, head, 8-lane slot)
   const long long total = (long long)p.B * p.Sq * p.H * 8;
@@ -966,7 +1003,9 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const AttnP p) {
     const int head = (int)(row % p.H);
     const long long bq = row / p.H;
     const int b = (int)(bq / p.Sq), q = (int)(bq % p.Sq);
-    p.delta[((long long)b * p.H + head) * p.Sq + q] = s;
+    const long long li = ((long long)b * p.H + head) * p.Sq + q;
+    p.delta[li] = -s;                                                    // C operand of the dP products
+    p.delta[(long long)p.B * p.H * p.Sq + li] = -p.lse[li] * LOG2E;      // addend of the exp2 argument
   }
 }
 

@@ -833,7 +833,7 @@ int Tape::ensure_acts() {
   HIPCHK(hipMalloc((void**)&gn_scratch, gn_bytes));
   if (needs_grad) HIPCHK(hipMalloc((void**)&cs_scratch, cs_bytes));
   if (needs_grad) {
-    if (delta_elems) HIPCHK(hipMalloc((void**)&delta, delta_elems * 4));
+    if (delta_elems) HIPCHK(hipMalloc((void**)&delta, delta_elems * 4 * 2));   // two row constants per (b, h, q): -delta, -lse*log2e
     if (ups_elems) HIPCHK(hipMalloc((void**)&ups_tmp, ups_elems * 2));
     if (geglu_elems) HIPCHK(hipMalloc((void**)&geglu_tmp, geglu_elems * 2));
     if (part_bytes) HIPCHK(hipMalloc((void**)&attn_part, part_bytes));

@@ -86,7 +86,7 @@ struct AttnP {
   // backward
   const bf16* dO; int lddo;
   bf16 *dQ, *dK, *dV; int lddq, lddk, lddv;
-  float* delta;                    // [B][H][Sq] scratch: rowsum(dO * O)
+  float* delta;                    // [2][B][H][Sq] scratch: -rowsum(dO * O) and -lse * log2(e)
   int accum_dq, accum_dkv;         // += into existing gradients
   float* dkv_part; int nsplit;     // optional fp32 scratch (attention_bwd_scratch_bytes) enabling the query split
   int nd;                          // padded head_dim / 64 (0 is read as 1)

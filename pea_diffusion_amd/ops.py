@@ -168,7 +168,7 @@ def attention_bwd(q, k, v, o, do, lse, heads, scale=None):
     nd = C // heads // 64
     scale = scale if scale is not None else (C // heads) ** -0.5
     dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
-    delta = torch.empty(B, heads, Sq, device=q.device, dtype=torch.float32)
+    delta = torch.empty(2, B, heads, Sq, device=q.device, dtype=torch.float32)     # scratch: -delta and -lse*log2(e) per row
     nb = lib().pea_op_attention_bwd_scratch_bytes(B, heads, Sq, Skv, nd)
     scratch = torch.empty(nb, device=q.device, dtype=torch.uint8) if nb else None
     check(lib().pea_op_attention_bwd(ptr(q), q.stride(1), ptr(k), k.stride(1), ptr(v), v.stride(1), ptr(o), C, ptr(do),
