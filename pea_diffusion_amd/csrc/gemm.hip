@@ -16,6 +16,9 @@
 #include <stdlib.h>
 
 #include "pea_kernels.h"
+#ifndef PEA_GEMM_BUFFER_DMA
+#define PEA_GEMM_BUFFER_DMA 1
+#endif
 
 #define BK 64
 
@@ -816,6 +819,80 @@ __global__ __launch_bounds__((WM * WN + LW + SW) * 64, (OCC == 2 ? 3 : 1)) void 
     if (!(p.debug & 64)) __builtin_amdgcn_s_setprio(3);
     const int lw = wave - NWC;
     const int lrow = lane >> 3, cpos = lane & 7;
+#if PEA_GEMM_BUFFER_DMA && defined(__HIP_DEVICE_COMPILE__)   // (the host pass has no buffer-resource type; it only needs the stub)
+    // Buffer form of the LDS-DMA (buffer_load_dwordx4 ... offen lds): a per-lane 32-bit byte offset + a scalar offset
+    // instead of a 64-bit address per lane -- half the address registers handed to the memory pipe per piece, and for the
+    // plain GEMM no vector instruction at all per K-step (the K offset is the scalar one).  Reads past num_records return
+    // zeros, which is what the conv gather wants for its halo and zero-stuffed taps.
+    const long long a_elems = MODE == 0 ? (long long)p.M * p.lda : (long long)(p.M / (p.Ho * p.Wo)) * p.Hs * p.Ws * p.Cin;
+    const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, (int)min(a_elems * 2, 0x7fffffffLL), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc((void*)p.W, 0, 0x7fffffff, 0x00020000);
+    int a_off[PA], a_iy0[PA], a_ix0[PA], w_off[PB];
+    auto setup = [&](int ti) {
+      int bm, bn;
+      tile_of(ti, bm, bn);
+#pragma unroll
+      for (int j = 0; j < PA; ++j) {
+        const int r = (lw * PA + j) * 8 + lrow;
+        const int chunk = cpos ^ ((r >> 1) & 7);
+        int gm = bm * BM + r;
+        gm = gm < p.M ? gm : p.M - 1;
+        if (MODE == 0) {
+          a_off[j] = (gm * p.lda + chunk * 8) * 2;
+          a_iy0[j] = a_ix0[j] = 0;
+        } else {
+          const int hw = p.Ho * p.Wo;
+          const int b = gm / hw;
+          const int rem = gm - b * hw;
+          const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+          a_iy0[j] = oy * p.stride - 1 + p.pad_off;
+          a_ix0[j] = ox * p.stride - 1 + p.pad_off;
+          a_off[j] = (b * p.Hs * p.Ws * p.Cin + chunk * 8) * 2;
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < PB; ++j) {
+        const int r = (lw * PB + j) * 8 + lrow;
+        const int chunk = cpos ^ ((r >> 1) & 7);
+        int gn = bn * BN + r;
+        gn = gn < p.N ? gn : p.N - 1;
+        w_off[j] = (gn * p.ldw + chunk * 8) * 2;
+      }
+    };
+    const int Hv = p.Hs << p.shift, Wv = p.Ws << p.shift;
+    int tap_off[PA];                    // conv: per-lane byte offset of the current tap's pixel (or out of range), refreshed
+    int tap_cur = -1;                   // only when the K-step enters a new tap; the channel offset rides in the scalar offset
+    auto issue = [&](int st, int k0) {
+      char* base = smem + st * STAGE;
+      int c0 = 0;
+      if (MODE == 1) {
+        const int tap = k0 / p.Cin;
+        c0 = k0 - tap * p.Cin;
+        if (tap != tap_cur) {
+          tap_cur = tap;
+          const int ky = tap / 3, kx = tap - ky * 3;
+#pragma unroll
+          for (int j = 0; j < PA; ++j) {
+            const int iy = a_iy0[j] + ky, ix = a_ix0[j] + kx;
+            bool ok = ((unsigned)iy < (unsigned)Hv) && ((unsigned)ix < (unsigned)Wv);
+            if (p.parity) ok = ok && (((iy | ix) & 1) == 0);
+            const int sy = iy >> p.shift, sx = ix >> p.shift;
+            tap_off[j] = ok ? a_off[j] + (sy * p.Ws + sx) * p.Cin * 2 : 0x7f000000;     // out of range: the load returns zeros
+          }
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < PA; ++j) {
+        if (MODE == 0)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, PEA_LDS(base + (lw * PA + j) * 1024), 16, a_off[j], k0 * 2, 0, 0);
+        else
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, PEA_LDS(base + (lw * PA + j) * 1024), 16, tap_off[j], c0 * 2, 0, 0);
+      }
+#pragma unroll
+      for (int j = 0; j < PB; ++j)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, PEA_LDS(base + A_BYTES + (lw * PB + j) * 1024), 16, w_off[j], k0 * 2, 0, 0);
+    };
+#else
     const bf16* a_src[PA];
     int a_iy0[PA], a_ix0[PA];
     const bf16* w_src[PB];
@@ -879,6 +956,7 @@ __global__ __launch_bounds__((WM * WN + LW + SW) * 64, (OCC == 2 ? 3 : 1)) void 
         __builtin_amdgcn_global_load_lds(PEA_GLB(w_src[j] + k0), PEA_LDS(base + A_BYTES + (lw * PB + j) * 1024), 16,
                                          0, 0);
     };
+#endif
     // producer position (tile ordinal, K-step) of the next stage to issue
     int ptile = 0, pt = 0;
     setup(0);
