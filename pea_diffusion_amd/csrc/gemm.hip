@@ -491,6 +491,73 @@ __global__ __launch_bounds__((WM * WN + LW) * 64, MINW) void gemm_lc_kernel(cons
     // ============================== loader waves
     const int lw = wave - NWC;
     const int lrow = lane >> 3, cpos = lane & 7;
+#if PEA_GEMM_BUFFER_DMA && defined(__HIP_DEVICE_COMPILE__)
+    // buffer form of the LDS-DMA, as in gemm_lcp_kernel: no vector instruction per K-step in the DMA waves
+    const long long a_elems = MODE == 0 ? (long long)p.M * p.lda : (long long)(p.M / (p.Ho * p.Wo)) * p.Hs * p.Ws * p.Cin;
+    const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, (int)min(a_elems * 2, 0x7fffffffLL), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc((void*)p.W, 0, 0x7fffffff, 0x00020000);
+    int a_off[PA], a_iy0[PA], a_ix0[PA], w_off[PB];
+#pragma unroll
+    for (int j = 0; j < PA; ++j) {
+      const int r = (lw * PA + j) * 8 + lrow;
+      const int chunk = cpos ^ ((r >> 1) & 7);
+      int gm = bm * BM + r;
+      gm = gm < p.M ? gm : p.M - 1;
+      if (MODE == 0) {
+        a_off[j] = (gm * p.lda + chunk * 8) * 2;
+        a_iy0[j] = a_ix0[j] = 0;
+      } else {
+        const int hw = p.Ho * p.Wo;
+        const int b = gm / hw;
+        const int rem = gm - b * hw;
+        const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+        a_iy0[j] = oy * p.stride - 1 + p.pad_off;
+        a_ix0[j] = ox * p.stride - 1 + p.pad_off;
+        a_off[j] = (b * p.Hs * p.Ws * p.Cin + chunk * 8) * 2;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < PB; ++j) {
+      const int r = (lw * PB + j) * 8 + lrow;
+      const int chunk = cpos ^ ((r >> 1) & 7);
+      int gn = bn * BN + r;
+      gn = gn < p.N ? gn : p.N - 1;
+      w_off[j] = (gn * p.ldw + chunk * 8) * 2;
+    }
+    const int Hv = p.Hs << p.shift, Wv = p.Ws << p.shift;
+    int tap_off[PA];
+    int tap_cur = -1;
+    auto issue = [&](int st, int k0) {
+      char* base = smem + st * STAGE;
+      int c0 = 0;
+      if (MODE == 1) {
+        const int tap = k0 / p.Cin;
+        c0 = k0 - tap * p.Cin;
+        if (tap != tap_cur) {
+          tap_cur = tap;
+          const int ky = tap / 3, kx = tap - ky * 3;
+#pragma unroll
+          for (int j = 0; j < PA; ++j) {
+            const int iy = a_iy0[j] + ky, ix = a_ix0[j] + kx;
+            bool ok = ((unsigned)iy < (unsigned)Hv) && ((unsigned)ix < (unsigned)Wv);
+            if (p.parity) ok = ok && (((iy | ix) & 1) == 0);
+            const int sy = iy >> p.shift, sx = ix >> p.shift;
+            tap_off[j] = ok ? a_off[j] + (sy * p.Ws + sx) * p.Cin * 2 : 0x7f000000;
+          }
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < PA; ++j) {
+        if (MODE == 0)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, PEA_LDS(base + (lw * PA + j) * 1024), 16, a_off[j], k0 * 2, 0, 0);
+        else
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, PEA_LDS(base + (lw * PA + j) * 1024), 16, tap_off[j], c0 * 2, 0, 0);
+      }
+#pragma unroll
+      for (int j = 0; j < PB; ++j)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, PEA_LDS(base + A_BYTES + (lw * PB + j) * 1024), 16, w_off[j], k0 * 2, 0, 0);
+    };
+#else
     const bf16* a_src[PA];
     int a_iy0[PA], a_ix0[PA];
     const bf16* w_src[PB];
@@ -550,6 +617,7 @@ __global__ __launch_bounds__((WM * WN + LW) * 64, MINW) void gemm_lc_kernel(cons
         __builtin_amdgcn_global_load_lds(PEA_GLB(w_src[j] + k0), PEA_LDS(base + A_BYTES + (lw * PB + j) * 1024), 16,
                                          0, 0);
     };
+#endif
 #pragma unroll
     for (int i = 0; i < S; ++i)
       if (i < nt) issue(i, kb0 + i * BK);
