@@ -62,16 +62,39 @@ __device__ __forceinline__ void lds_dma4(const void* gsrc, const char* lds_dst) 
   asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, off" ::"s"(a), "v"(gsrc) : "m0");
 }
 
-// stage a 64x64 tile: rows r0.. (clamped to rmax-1) of `src` (row stride ld elements) -> dst (LDS)
-__device__ __forceinline__ void stage_tile(const bf16* src, int ld, int r0, int rmax, char* dst, int wave, int lane) {
+// A 64x64-tile source for the LDS-DMA in BUFFER form (buffer_load_dwordx4 ... offen lds): a buffer resource over the
+// matrix (rows beyond `rows` read as zeros -- they are masked keys / ragged query rows), and this lane's two byte offsets
+// inside a tile; the tile's first row goes into the scalar offset.  The 64-bit address form cost ~10 integer vector
+// instructions per 1 KiB piece (row clamp, swizzle, 64-bit multiply-add), every key tile, in loops whose bound is the
+// vector issue port that the MFMAs share.
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+struct TileSrc {
+  i32x4 rsrc;
+  int voff[2];
+  int row_bytes;
+};
+__device__ __forceinline__ TileSrc tile_src(const bf16* base, int ld, int rows, int wave, int lane) {
+  TileSrc t;
+  const unsigned long long a = (unsigned long long)base;
+  t.rsrc[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)a);
+  t.rsrc[1] = __builtin_amdgcn_readfirstlane((int)(unsigned)(a >> 32));
+  t.rsrc[2] = __builtin_amdgcn_readfirstlane((rows - 1) * ld * 2 + 128);      // num_records (bytes): last valid row's 128 bytes
+  t.rsrc[3] = 0x00020000;
+  t.row_bytes = ld * 2;
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
-    const int piece = wave * 2 + j;
-    const int r = piece * 8 + (lane >> 3);
-    const int chunk = (lane & 7) ^ swz_x(r);
-    int gr = r0 + r;
-    gr = gr < rmax ? gr : rmax - 1;
-    lds_dma16(src + (long long)gr * ld + chunk * 8, dst + piece * 1024);
+    const int r = (wave * 2 + j) * 8 + (lane >> 3);
+    t.voff[j] = r * ld * 2 + (((lane & 7) ^ swz_x(r)) << 4);
+  }
+  return t;
+}
+// stage rows r0 .. r0+63 -> dst (LDS image of 64 rows x 128 bytes, source-side XOR swizzle); 4 waves x 2 pieces
+__device__ __forceinline__ void stage_tile(const TileSrc& t, int r0, char* dst, int wave) {
+  const int soff = __builtin_amdgcn_readfirstlane(r0 * t.row_bytes);
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const unsigned a = __builtin_amdgcn_readfirstlane(lds_addr_u32(dst + (wave * 2 + j) * 1024));
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(a), "v"(t.voff[j]), "s"(t.rsrc), "s"(soff) : "m0");
   }
 }
 
@@ -218,11 +241,17 @@ __device__ __forceinline__ void attn_q_body(const AttnP& p, char* smem, int blk_
     for (int r = 0; r < 16; ++r) oacc[i][r] = 0.f;
   float m_run = -INFINITY, l_run = 0.f;
 
+  TileSrc ksrc[ND], vsrc[ND];
+#pragma unroll
+  for (int nd = 0; nd < ND; ++nd) {
+    ksrc[nd] = tile_src(Kb + nd * 64, p.ldk, p.Skv, wave, lane);
+    vsrc[nd] = tile_src(Vb + nd * 64, p.ldv, p.Skv, wave, lane);
+  }
   auto stage_kv = [&](char* dst, int r0) {
 #pragma unroll
     for (int nd = 0; nd < ND; ++nd) {
-      stage_tile(Kb + nd * 64, p.ldk, r0, p.Skv, dst + nd * TILE_BYTES, wave, lane);
-      stage_tile(Vb + nd * 64, p.ldv, r0, p.Skv, dst + (ND + nd) * TILE_BYTES, wave, lane);
+      stage_tile(ksrc[nd], r0, dst + nd * TILE_BYTES, wave);
+      stage_tile(vsrc[nd], r0, dst + (ND + nd) * TILE_BYTES, wave);
     }
   };
   const int nt = (p.Skv + 63) / 64;
@@ -507,11 +536,17 @@ __device__ __forceinline__ void attn_dkv_body(const AttnP& p, char* smem, int bl
 #pragma unroll
   for (int r = 0; r < 16; ++r) kmask[r] = kvalid ? 0.f : -INFINITY;
 
+  TileSrc qsrc[ND], dosrc[ND];
+#pragma unroll
+  for (int nd = 0; nd < ND; ++nd) {
+    qsrc[nd] = tile_src(Qb + nd * 64, p.ldq, p.Sq, wave, lane);
+    dosrc[nd] = tile_src(dOb + nd * 64, p.lddo, p.Sq, wave, lane);
+  }
   auto stage_q = [&](char* dst, int r0) {
 #pragma unroll
     for (int nd = 0; nd < ND; ++nd) {
-      stage_tile(Qb + nd * 64, p.ldq, r0, p.Sq, dst + nd * TILE_BYTES, wave, lane);
-      stage_tile(dOb + nd * 64, p.lddo, r0, p.Sq, dst + (ND + nd) * TILE_BYTES, wave, lane);
+      stage_tile(qsrc[nd], r0, dst + nd * TILE_BYTES, wave);
+      stage_tile(dosrc[nd], r0, dst + (ND + nd) * TILE_BYTES, wave);
     }
     stage_rowconst(lseb, dltb, r0, p.Sq, dst + 2 * ND * TILE_BYTES, wave, lane);
   };
@@ -714,12 +749,13 @@ __global__ __launch_bounds__(256, 2) void xattn_bwd_kernel(const AttnP p, int up
   const float* lseb = p.lse + ((long long)b * p.H + head) * p.Sq;
   const int skv_b = __builtin_amdgcn_readfirstlane(p.kv_len ? p.kv_len[b] : p.Skv);
 
+  const TileSrc qsrc = tile_src(Qb, p.ldq, p.Sq, wave, lane), dosrc = tile_src(dOb, p.lddo, p.Sq, wave, lane);
   auto stage_unit = [&](int u) {
     const int r0 = u * 128;
-    stage_tile(Qb, p.ldq, r0, p.Sq, S0, wave, lane);
-    stage_tile(Qb, p.ldq, r0 + 64, p.Sq, S0 + TILE_BYTES, wave, lane);
-    stage_tile(dOb, p.lddo, r0, p.Sq, S0 + 2 * TILE_BYTES, wave, lane);
-    stage_tile(dOb, p.lddo, r0 + 64, p.Sq, S0 + 3 * TILE_BYTES, wave, lane);
+    stage_tile(qsrc, r0, S0, wave);
+    stage_tile(qsrc, r0 + 64, S0 + TILE_BYTES, wave);
+    stage_tile(dosrc, r0, S0 + 2 * TILE_BYTES, wave);
+    stage_tile(dosrc, r0 + 64, S0 + 3 * TILE_BYTES, wave);
     if (wave < 2) {
       int r = r0 + wave * 64 + lane;
       r = r < p.Sq ? r : p.Sq - 1;
@@ -736,11 +772,14 @@ __global__ __launch_bounds__(256, 2) void xattn_bwd_kernel(const AttnP p, int up
     for (int i = 0; i < 4; ++i) o_pf[i] = *(const bf16x8*)(Ob + (long long)r * p.ldo + dhalf * 32 + 8 * i);
   };
 
-  stage_tile(Kb, p.ldk, 0, p.Skv, Ksm, wave, lane);
-  stage_tile(Vb, p.ldv, 0, p.Skv, Vsm, wave, lane);
-  if (KB > 2) {
-    stage_tile(Kb, p.ldk, 64, p.Skv, Ksm + TILE_BYTES, wave, lane);
-    stage_tile(Vb, p.ldv, 64, p.Skv, Vsm + TILE_BYTES, wave, lane);
+  {
+    const TileSrc ksrc = tile_src(Kb, p.ldk, p.Skv, wave, lane), vsrc = tile_src(Vb, p.ldv, p.Skv, wave, lane);
+    stage_tile(ksrc, 0, Ksm, wave);
+    stage_tile(vsrc, 0, Vsm, wave);
+    if (KB > 2) {
+      stage_tile(ksrc, 64, Ksm + TILE_BYTES, wave);
+      stage_tile(vsrc, 64, Vsm + TILE_BYTES, wave);
+    }
   }
   if (u_begin < u_end) {
     stage_unit(u_begin);
