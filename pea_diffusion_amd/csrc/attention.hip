@@ -24,6 +24,15 @@
 // minus a running max / the log-sum-exp), so a flushed denormal result is an exact zero after bf16 rounding anyway
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 #define LOG2E 1.4426950408889634f
+// max over the two 32-lane halves of the wave (lane l and l ^ 32), in every lane: one v_permlane32_swap + one v_max.
+// __shfl_xor(x, 32) goes through ds_bpermute_b32 -- six address instructions and an LDS round trip in the middle of the
+// softmax's dependency chain (scores -> row max -> exp arguments), every key tile.  (The clang builtin folds
+// max(swap(x, x)) away, hence the assembly; the s_nops are the data hazards of the swap.)
+__device__ __forceinline__ float xhalf_max(float x) {
+  float a = x, b = x;
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+  return fmaxf(a, b);
+}
 
 // XOR term of a tile row: the bits of (row >> 1) & 7 rotated so that rows r and r + 2 differ in bit 2.  Any bijection of
 // (row >> 1) & 7 keeps the 16-byte row reads (ds_read_b128) conflict free; with this one the transposed reads
@@ -359,7 +368,7 @@ __device__ __forceinline__ void attn_q_body(const AttnP& p, char* smem, int blk_
       float mx = fmaxf(sacc[0][0], sacc[1][0]);
 #pragma unroll
       for (int r = 1; r < 16; ++r) mx = fmaxf(fmaxf(mx, sacc[0][r]), sacc[1][r]);     // one v_max3 per pair of scores
-      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      mx = xhalf_max(mx);
       const float m_new = fmaxf(m_run, mx);
       const bool moved = m_new != m_run;
       const float mc = m_new * cc;
