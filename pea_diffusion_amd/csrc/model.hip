@@ -1599,8 +1599,8 @@ int Trainer::step(const float* latents, const float* noise, const long long* tim
   if (merge_passes && merge_state == 0) {
     // eligible: the teacher context shares the student's weight arena (same checkpoint, train_sdxl_zh.py:138,151 load
     // the same model_path) and both see the same context length
-    // (merge_passes 1: only for per-GPU batches <= 4, where doubling the rows pays more than the two-stream overlap --
-    // measured 32.4 vs 32.1 images/s at B = 4 and 34.7 vs 35.8 at B = 8; 2: always when eligible)
+    // (merge_passes 1: for per-GPU batches <= 8 -- end of round 2, one box: 109.2 vs 114.0 ms at B = 4, 203.5 vs 205.2 ms
+    // at B = 8 against the two-stream path; 2: always when eligible)
     // A student context shorter than the teacher's (the reference's default: Chinese-CLIP emits 52 tokens,
     // utils/custom_dataset_sdxl.py:352-353, the teacher's CLIP towers 77) merges too: the merged context is Tt.L tokens
     // long, the student rows carry S.L tokens + zero padding and a per-sample key count masks the padding in the
@@ -1608,7 +1608,7 @@ int Trainer::step(const float* latents, const float* noise, const long long* tim
     bool all_nd1 = true;
     for (const Op& o : S.ops)
       if (o.kind == OP_ATTN && o.p3 != 1) all_nd1 = false;
-    bool ok = (merge_passes >= 2 || B <= 4) && !Tt.owns_weights && Tt.slots.size() == S.slots.size() &&
+    bool ok = (merge_passes >= 2 || B <= 8) && !Tt.owns_weights && Tt.slots.size() == S.slots.size() &&
               (S.L == Tt.L || (S.L < Tt.L && all_nd1)) &&
               S.graph == 0 && Tt.graph == 0 &&
               memcmp(&S.cfg, &Tt.cfg, sizeof(PeaUnetCfg)) == 0;

@@ -1,7 +1,7 @@
 """-m gpu: the BASELINE.json configurations at the sizes they are quoted on, one test each.
 
   C2  SDXL 1024x1024, per-GPU batch 4, teacher == student checkpoint -> the merged 2B-row launch set bench.py times
-  C3  SDXL 1024x1024, per-rank batch 8 (global 64 = 8 x 8)           -> the two-stream path at B = 8
+  C3  SDXL 1024x1024, per-rank batch 8 (global 64 = 8 x 8)           -> merged passes (default) and the two-stream path at B = 8
   C4  SSD-1B student (real per-position layout, no mid block) under the SDXL teacher: full width vs the fp32 CPU oracle
       at 512x512, and at 1024x1024 through size-independent properties
 The oracle cannot finish 1024x1024 in seconds, so full-size cases are checked through properties the step offers:
@@ -60,10 +60,10 @@ def _properties(tr, ad, B, hw, L, same_weights):
                                       + 0.1 * float(out3["train_loss_features"]))) <= 1e-5 * abs(float(out3["loss"]))
 
 
-@pytest.mark.parametrize("B,merged", [(4, 1), (8, -1)])
-def test_sdxl_1024_bench_workloads(gpu, B, merged):
+@pytest.mark.parametrize("B,two_stream", [(4, False), (8, False), (8, True)])
+def test_sdxl_1024_bench_workloads(gpu, B, two_stream):
     """C2 (B = 4: exactly the launch set bench.py times -- merged passes, 2B = 8 rows per forward launch) and C3's
-    per-rank workload (B = 8: teacher forward on the side stream)."""
+    per-rank workload (B = 8) on both of its paths: merged passes (the default) and the teacher forward on the side stream."""
     from pea_diffusion_amd import config as pc
     from pea_diffusion_amd.adapter import PEAAdapter
     from pea_diffusion_amd.train import PEATrainer
@@ -75,8 +75,10 @@ def test_sdxl_1024_bench_workloads(gpu, B, merged):
     torch.manual_seed(0)
     ad = PEAAdapter(1024, 1280, 1024, 2048, False).cuda()
     tr = PEATrainer(ad, student, teacher)
+    if two_stream:
+        tr.set_option("merge_passes", 0)
     _properties(tr, ad, B, hw, L, same_weights=True)
-    assert lib_merge_state(tr) == merged
+    assert (lib_merge_state(tr) == 1) == (not two_stream)
     del tr, student, teacher
     torch.cuda.empty_cache()
 
