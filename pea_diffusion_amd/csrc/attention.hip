@@ -721,6 +721,160 @@ __global__ __launch_bounds__(256, (ND == 1 ? 2 : 1)) void attn_bwd_fused_kernel(
   else attn_q_body<1, USE_TR, ND, false, false>(p, smem, rem - n_dkv, head, b);
 }
 
+// ============================================================================= cross-attention forward, K / V resident
+// <= 128 keys (the 77-token text context: KB = 3 blocks of 32), head_dim 64.  The general forward spends a workgroup per 128
+// queries on two 64-key tiles (25 % of them padding), a K / V staging round trip and two barriers for 2 x 8 MFMAs per wave.
+// Here a workgroup stages K and V ONCE and its four waves then walk 128-query units independently -- no barrier in the loop:
+// Q fragments straight from HBM (this lane's query row: four 16-byte loads), S^T over KB key blocks, the softmax in one
+// shot (all scores of a query are in registers: no running max, no rescale), O^T = V^T P^T, store.  Per-sample key counts
+// (merged passes with a shorter student context) mask through the same compare as the padding keys.
+__device__ __forceinline__ float xhalf_sum(float x) {
+  float a = x, b = x;
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+  return a + b;
+}
+template <int KB>
+__global__ __launch_bounds__(256, 3) void xattn_fwd_kernel(const AttnP p, int upw) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int KT = (KB + 1) / 2;                               // 64-key tiles
+  char* const Ksm = smem;
+  char* const Vsm = smem + KT * TILE_BYTES;
+  char* const Osm = smem + 2 * KT * TILE_BYTES;                  // 4 waves x 32 rows x 144 bytes
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int frow = lane & 31, fh = lane >> 5;
+  int split, head, b;
+  attn_block_coords(p.xcd_remap, split, head, b);
+  const int nu = (p.Sq + 127) >> 7;
+  const int u_begin = split * upw, u_end = min(nu, u_begin + upw);
+  const float c = p.scale * LOG2E;
+  const bf16* Qb = p.Q + (long long)b * p.Sq * p.ldq + head * 64;
+  const bf16* Kb = p.K + (long long)b * p.Skv * p.ldk + head * 64;
+  const bf16* Vb = p.V + (long long)b * p.Skv * p.ldv + head * 64;
+  const int skv_b = __builtin_amdgcn_readfirstlane(p.kv_len ? p.kv_len[b] : p.Skv);
+  {
+    const TileSrc ksrc = tile_src(Kb, p.ldk, p.Skv, wave, lane), vsrc = tile_src(Vb, p.ldv, p.Skv, wave, lane);
+#pragma unroll
+    for (int t = 0; t < KT; ++t) {
+      stage_tile(ksrc, t * 64, Ksm + t * TILE_BYTES, wave);
+      stage_tile(vsrc, t * 64, Vsm + t * TILE_BYTES, wave);
+    }
+  }
+  int rf_off[4], tr_off[2][2];
+#pragma unroll
+  for (int s4 = 0; s4 < 4; ++s4) rf_off[s4] = frow * 128 + (((2 * s4 + fh) ^ swz_x(frow)) << 4);
+  {
+    const int i16 = lane & 15, rr = 4 * fh + (i16 >> 2), cc = 16 * ((lane >> 4) & 1) + 4 * (i16 & 3);
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+      for (int hl = 0; hl < 2; ++hl) tr_off[db][hl] = swz_rc(rr + 8 * hl, db * 32 + cc);
+  }
+  int qrow = u_begin * 128 + wave * 32 + frow;
+  bf16x8 qf[4];
+  // Q: this wave's 32 rows as a 4 KiB swizzled image in its own LDS region, filled by LDS-DMA (whole 128-byte rows per
+  // 8 lanes) one unit ahead; direct 16-byte loads of a row per lane touched 32 lines per instruction
+  char* const qst = Osm + 4 * 32 * 144 + wave * 4096;
+  const TileSrc qsrc = tile_src(Qb, p.ldq, p.Sq, 0, lane);      // pieces 0 / 1 of a tile: rows 0..15; + 16 rows via the scalar offset
+  auto stage_q = [&](int row0) {
+    stage_tile(qsrc, row0, qst, 0);
+    stage_tile(qsrc, row0 + 16, qst + 2048, 0);
+  };
+  if (u_begin < u_end) stage_q(u_begin * 128 + wave * 32);
+  WAIT_VM0();
+  __syncthreads();
+  for (int u = u_begin; u < u_end; ++u, qrow += 128) {
+    const bool qvalid = qrow < p.Sq;
+    WAIT_VM0();                                                  // this wave's Q image (and its stores of the last unit)
+#pragma unroll
+    for (int s = 0; s < 4; ++s) qf[s] = *(const bf16x8*)(qst + rf_off[s]);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (u + 1 < u_end) stage_q((u + 1) * 128 + wave * 32);      // next unit's rows fly under this unit's work
+    // S^T[key][q] = K . Q^T over the KB key blocks
+    f32x16 sacc[KB];
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) {
+      bf16x8 kfr[4];
+#pragma unroll
+      for (int s = 0; s < 4; ++s) kfr[s] = *(const bf16x8*)(Ksm + rf_off[s] + ((kb >> 1) * TILE_BYTES + (kb & 1) * 4096));
+      const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr[0], qf[0], zero16, 0, 0, 0);
+#pragma unroll
+      for (int s = 1; s < 4; ++s) sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr[s], qf[s], sacc[kb], 0, 0, 0);
+    }
+    // padding keys / keys past this sample's count: -inf (only the blocks that hold any)
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb)
+      if (kb * 32 + 32 > skv_b) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+          sacc[kb][r] = key < skv_b ? sacc[kb][r] : -INFINITY;
+        }
+      }
+    float mx = sacc[0][0];
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+      for (int r = (kb == 0 ? 1 : 0); r < 16; ++r) mx = fmaxf(mx, sacc[kb][r]);
+    mx = xhalf_max(mx);
+    const float mc = mx * c;
+    float ls = 0.f;
+    bf16x8 pf[2 * KB];
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float e = fast_exp2(fmaf(sacc[kb][r], c, -mc));
+        ls += e;
+        pf[2 * kb + (r >> 3)][r & 7] = (bf16)e;
+      }
+    const float l_tot = xhalf_sum(ls);
+    // O^T[d][q] = V^T[d][key] P^T[key][q]
+    f32x16 oacc[2];
+#pragma unroll
+    for (int ks = 0; ks < 2 * KB; ++ks) {
+      const int vb = (ks >> 2) * TILE_BYTES + (ks & 3) * 2048;
+#pragma unroll
+      for (int db = 0; db < 2; ++db) {
+        const bf16x8 tf = read_transposed_frag_at(Vsm + tr_off[db][0] + vb, Vsm + tr_off[db][1] + vb);
+        if (ks == 0) {
+          const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+          oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tf, pf[0], zero16, 0, 0, 0);
+        } else {
+          oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tf, pf[ks], oacc[db], 0, 0, 0);
+        }
+      }
+    }
+    const float inv = 1.f / l_tot;
+    if (qvalid && p.lse && fh == 0) p.lse[((long long)b * p.H + head) * p.Sq + qrow] = mx * p.scale + log2f(l_tot) * 0.6931471805599453f;
+    // O leaves through a per-wave LDS image (32 rows x 128 bytes, 144-byte pitch): the accumulator layout has a query row
+    // per lane, i.e. eight 8-byte stores per lane that each touch 32 different 128-byte lines; from the image every store
+    // instruction writes eight whole rows (16 bytes per lane).  With 77 keys the output is most of this kernel's traffic.
+    char* const ost = Osm + wave * (32 * 144);
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        bf16x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = (bf16)(oacc[db][4 * g + j] * inv);
+        *(bf16x4*)(ost + frow * 144 + (db * 32 + 8 * g + 4 * fh) * 2) = o;
+      }
+    {
+      const int r8 = lane >> 3, ch = lane & 7;
+      const int q0w = u * 128 + wave * 32;
+      bf16* Ob = p.O + (long long)b * p.Sq * p.ldo + head * 64 + ch * 8;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int row = i * 8 + r8;
+        const bf16x8 v = *(const bf16x8*)(ost + row * 144 + ch * 16);
+        if (q0w + row < p.Sq) *(bf16x8*)(Ob + (long long)(q0w + row) * p.ldo) = v;
+      }
+    }
+  }
+}
+
 // ============================================================================= cross-attention backward, ONE pass
 // Few keys (the text context: 77 tokens -> KB = 3 blocks of 32), many queries, head_dim 64.  The general path costs three
 // launches (delta, dQ + dK/dV roles, split reduce) that each stream Q / dO again and are latency-bound on their short
@@ -1109,6 +1263,8 @@ size_t attention_bwd_scratch_bytes(int B, int H, int Sq, int Skv, int nd) {
 }
 
 static int g_attn_use_tr = 1;
+static int g_attn_xattn = getenv("PEA_XATTN_OFF") ? 0 : 1;               // PEA_XATTN_OFF=1: cross-attention on the general kernels (A/B)
+extern "C" void pea_debug_set_attn_xattn(int v) { g_attn_xattn = v; }
 static int g_attn_xcd = getenv("PEA_ATTN_NO_XCD") ? 0 : 1;
 extern "C" void pea_debug_set_attn_tr(int v) { g_attn_use_tr = v; }
 
@@ -1145,6 +1301,22 @@ static int attn_fwd_nd(const AttnP& p, hipStream_t s) {
   int rc = attn_set_lds_attr<ND>();
   if (rc) return rc;
   const dim3 grid(cdiv(p.Sq, 128), p.H, p.B);
+  if constexpr (ND == 1) {
+    if (g_attn_xattn && g_attn_use_tr && p.Skv <= 128 && !p.causal && !p.bias && p.Sq >= 128) {   // cross-attention: K / V resident
+      const int kb = cdiv(p.Skv, 32), kt = (kb + 1) / 2;
+      const int lds = 2 * kt * TILE_BYTES + 4 * 32 * 144 + 4 * 4096;
+      const int nu = cdiv(p.Sq, 128);
+      const long long units = (long long)p.B * p.H * nu;
+      int upw = (int)((units + 511) / 512);                       // one round of two workgroups per CU (66 KB of LDS each)
+      upw = upw < 1 ? 1 : (upw > nu ? nu : upw);
+      const dim3 g2(cdiv(nu, upw), p.H, p.B);
+      if (kb == 1) hipLaunchKernelGGL(xattn_fwd_kernel<1>, g2, dim3(256), lds, s, p, upw);
+      else if (kb == 2) hipLaunchKernelGGL(xattn_fwd_kernel<2>, g2, dim3(256), lds, s, p, upw);
+      else if (kb == 3) hipLaunchKernelGGL(xattn_fwd_kernel<3>, g2, dim3(256), lds, s, p, upw);
+      else hipLaunchKernelGGL(xattn_fwd_kernel<4>, g2, dim3(256), lds, s, p, upw);
+      return PEA_OK;
+    }
+  }
   if (p.causal || p.kv_len || p.bias) {       // text-encoder masks / score bias: separate instance (head_dim 64 only)
     SHAPECHK(ND == 1, "attention: causal / key-length masks need head_dim 64");
     if constexpr (ND == 1) {
@@ -1162,8 +1334,6 @@ static int attn_fwd_nd(const AttnP& p, hipStream_t s) {
   return PEA_OK;
 }
 static int g_attn_fused_bwd = getenv("PEA_ATTN_BWD_SPLIT") ? 0 : 1;      // PEA_ATTN_BWD_SPLIT=1: the two-launch form (A/B)
-static int g_attn_xattn = getenv("PEA_XATTN_OFF") ? 0 : 1;               // PEA_XATTN_OFF=1: cross-attention on the general kernels (A/B)
-extern "C" void pea_debug_set_attn_xattn(int v) { g_attn_xattn = v; }
 // the one-pass cross-attention backward: head_dim 64, at most 128 keys, all three gradients wanted
 static bool attn_use_xattn(const AttnP& p) {
   return g_attn_xattn && g_attn_use_tr && p.nd == 1 && p.Skv <= 128 && p.dQ && p.dK && p.dV && (p.nsplit <= 1 || p.dkv_part);
