@@ -458,23 +458,42 @@ __device__ __forceinline__ void attn_q_body(const AttnP& p, char* smem, int blk_
     if (p.lse && qvalid && fh == 0)
       p.lse[((long long)b * p.H + head) * p.Sq + qrow] = m_run * p.scale + log2f(l_tot) * 0.6931471805599453f;
   }
-  if (!qvalid) return;
-  bf16* Ob = MODE == 0 ? p.O + (long long)b * p.Sq * p.ldo + head * 64 * ND + (long long)qrow * p.ldo
-                       : p.dQ + (long long)b * p.Sq * p.lddq + head * 64 * ND + chunk * 64 + (long long)qrow * p.lddq;
+  // The accumulator layout has a query row per lane: written straight out that is eight 8-byte stores per lane, each
+  // touching 32 different 128-byte lines.  The wave's 32 x 64 block goes through an LDS image instead (its own 4.5 KiB of
+  // the K / V ring, which every wave has left behind the loop's last barrier; 144-byte pitch), from which every store
+  // instruction writes eight whole rows, 16 bytes per lane.
   const bool accum = MODE == 1 && p.accum_dq;
+  char* const ost = smem + wave * (32 * 144);
+  const int r8 = lane >> 3, ch = lane & 7;
 #pragma unroll
-  for (int no = 0; no < NO; ++no)
+  for (int no = 0; no < NO; ++no) {
 #pragma unroll
     for (int db = 0; db < 2; ++db)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        bf16* dst = Ob + no * 64 + db * 32 + 8 * g + 4 * fh;
         bf16x4 o;
-        if (accum) o = *(const bf16x4*)dst;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) o[j] = (bf16)(oacc[2 * no + db][4 * g + j] * inv + (accum ? (float)o[j] : 0.f));
-        *(bf16x4*)dst = o;
+        for (int j = 0; j < 4; ++j) o[j] = (bf16)(oacc[2 * no + db][4 * g + j] * inv);
+        *(bf16x4*)(ost + frow * 144 + (db * 32 + 8 * g + 4 * fh) * 2) = o;
       }
+    bf16* Ob = MODE == 0 ? p.O + (long long)b * p.Sq * p.ldo + head * 64 * ND + no * 64 + ch * 8
+                         : p.dQ + (long long)b * p.Sq * p.lddq + head * 64 * ND + chunk * 64 + ch * 8;
+    const int ldo_ = MODE == 0 ? p.ldo : p.lddq;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = i * 8 + r8;
+      if (q0 + row < p.Sq) {
+        bf16x8 v = *(const bf16x8*)(ost + row * 144 + ch * 16);
+        bf16* dst = Ob + (long long)(q0 + row) * ldo_;
+        if (accum) {
+          const bf16x8 old = *(const bf16x8*)dst;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] = (bf16)((float)v[j] + (float)old[j]);
+        }
+        *(bf16x8*)dst = v;
+      }
+    }
+  }
 }
 
 template <int MODE, bool USE_TR, int ND, bool TXT = false>
