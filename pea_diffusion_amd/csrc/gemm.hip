@@ -437,6 +437,30 @@ __device__ __forceinline__ void gemm_epilogue16_lean(const GemmP& p, f32x4 (&acc
   }
 }
 
+#if PEA_GEMM_BUFFER_DMA && defined(__HIP_DEVICE_COMPILE__)
+// Buffer resource of one row-tile's A operand.  The resource starts at the tile's first row (plain GEMM) or at the first
+// sample the tile touches (conv gather), so the per-lane 32-bit offsets only span one tile / a couple of samples and the
+// operand itself may be any size (the SDXL VAE decoder's [4][1024][1024][256] activations are 2^31 bytes).  num_records
+// never exceeds 0x7f000000, the offset the conv gather uses for "halo: return zeros"; launch_gemm checks that a tile's
+// own span stays below it.  org = the row / sample the offsets are relative to.
+template <int MODE, int BM>
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t tile_rsrc(const GemmP& p, int bm, int& org) {
+  long long first, left;
+  if (MODE == 0) {
+    org = __builtin_amdgcn_readfirstlane(bm * BM);
+    first = (long long)org * p.lda;
+    left = (long long)(p.M - org) * p.lda;
+  } else {
+    const int hw = p.Ho * p.Wo;
+    const long long sample = (long long)p.Hs * p.Ws * p.Cin;
+    org = __builtin_amdgcn_readfirstlane((bm * BM) / hw);
+    first = org * sample;
+    left = (p.M / hw - org) * sample;
+  }
+  return __builtin_amdgcn_make_buffer_rsrc((void*)(p.A + first), 0, (int)min(left * 2, 0x7f000000LL), 0x00020000);
+}
+#endif
+
 // ------------------------------------------------------------------------------------------------
 // Loader / consumer kernel.  WM x WN consumer waves run ONLY ds_reads + MFMAs (register double-buffered
 // fragments as above); LW extra loader waves run ONLY the LDS-DMA stream (address arithmetic + pieces), so
@@ -493,8 +517,8 @@ __global__ __launch_bounds__((WM * WN + LW) * 64, MINW) void gemm_lc_kernel(cons
     const int lrow = lane >> 3, cpos = lane & 7;
 #if PEA_GEMM_BUFFER_DMA && defined(__HIP_DEVICE_COMPILE__)
     // buffer form of the LDS-DMA, as in gemm_lcp_kernel: no vector instruction per K-step in the DMA waves
-    const long long a_elems = MODE == 0 ? (long long)p.M * p.lda : (long long)(p.M / (p.Ho * p.Wo)) * p.Hs * p.Ws * p.Cin;
-    const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, (int)min(a_elems * 2, 0x7fffffffLL), 0x00020000);
+    int org;
+    const __amdgpu_buffer_rsrc_t rsrc_a = tile_rsrc<MODE, BM>(p, bm, org);
     const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc((void*)p.W, 0, 0x7fffffff, 0x00020000);
     int a_off[PA], a_iy0[PA], a_ix0[PA], w_off[PB];
 #pragma unroll
@@ -504,7 +528,7 @@ __global__ __launch_bounds__((WM * WN + LW) * 64, MINW) void gemm_lc_kernel(cons
       int gm = bm * BM + r;
       gm = gm < p.M ? gm : p.M - 1;
       if (MODE == 0) {
-        a_off[j] = (gm * p.lda + chunk * 8) * 2;
+        a_off[j] = ((gm - org) * p.lda + chunk * 8) * 2;
         a_iy0[j] = a_ix0[j] = 0;
       } else {
         const int hw = p.Ho * p.Wo;
@@ -513,7 +537,7 @@ __global__ __launch_bounds__((WM * WN + LW) * 64, MINW) void gemm_lc_kernel(cons
         const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
         a_iy0[j] = oy * p.stride - 1 + p.pad_off;
         a_ix0[j] = ox * p.stride - 1 + p.pad_off;
-        a_off[j] = (b * p.Hs * p.Ws * p.Cin + chunk * 8) * 2;
+        a_off[j] = ((b - org) * p.Hs * p.Ws * p.Cin + chunk * 8) * 2;
       }
     }
 #pragma unroll
@@ -892,13 +916,13 @@ __global__ __launch_bounds__((WM * WN + LW + SW) * 64, (OCC == 2 ? 3 : 1)) void 
     // instead of a 64-bit address per lane -- half the address registers handed to the memory pipe per piece, and for the
     // plain GEMM no vector instruction at all per K-step (the K offset is the scalar one).  Reads past num_records return
     // zeros, which is what the conv gather wants for its halo and zero-stuffed taps.
-    const long long a_elems = MODE == 0 ? (long long)p.M * p.lda : (long long)(p.M / (p.Ho * p.Wo)) * p.Hs * p.Ws * p.Cin;
-    const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, (int)min(a_elems * 2, 0x7fffffffLL), 0x00020000);
+    __amdgpu_buffer_rsrc_t rsrc_a;
     const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc((void*)p.W, 0, 0x7fffffff, 0x00020000);
     int a_off[PA], a_iy0[PA], a_ix0[PA], w_off[PB];
     auto setup = [&](int ti) {
-      int bm, bn;
+      int bm, bn, org;
       tile_of(ti, bm, bn);
+      rsrc_a = tile_rsrc<MODE, BM>(p, bm, org);
 #pragma unroll
       for (int j = 0; j < PA; ++j) {
         const int r = (lw * PA + j) * 8 + lrow;
@@ -906,7 +930,7 @@ __global__ __launch_bounds__((WM * WN + LW + SW) * 64, (OCC == 2 ? 3 : 1)) void 
         int gm = bm * BM + r;
         gm = gm < p.M ? gm : p.M - 1;
         if (MODE == 0) {
-          a_off[j] = (gm * p.lda + chunk * 8) * 2;
+          a_off[j] = ((gm - org) * p.lda + chunk * 8) * 2;
           a_iy0[j] = a_ix0[j] = 0;
         } else {
           const int hw = p.Ho * p.Wo;
@@ -915,7 +939,7 @@ __global__ __launch_bounds__((WM * WN + LW + SW) * 64, (OCC == 2 ? 3 : 1)) void 
           const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
           a_iy0[j] = oy * p.stride - 1 + p.pad_off;
           a_ix0[j] = ox * p.stride - 1 + p.pad_off;
-          a_off[j] = (b * p.Hs * p.Ws * p.Cin + chunk * 8) * 2;
+          a_off[j] = ((b - org) * p.Hs * p.Ws * p.Cin + chunk * 8) * 2;
         }
       }
 #pragma unroll
@@ -1307,6 +1331,14 @@ int launch_gemm(const GemmP& p_in, hipStream_t stream) {
     SHAPECHK(p0.Cin % BK == 0 && p0.K == 9 * p0.Cin, "conv: Cin=%d must be a multiple of %d and K=9*Cin", p0.Cin, BK);
     SHAPECHK(p0.zeros != nullptr, "conv: zero page missing");
     SHAPECHK(p0.M % (p0.Ho * p0.Wo) == 0, "conv: M=%d not a multiple of Ho*Wo", p0.M);
+  }
+  {
+    // 32-bit buffer offsets of the DMA loaders (tile_rsrc): relative to the row tile for A, to the tensor for W
+    const long long hw = p0.mode ? (long long)p0.Ho * p0.Wo : 1;
+    const long long span = p0.mode ? (256 / hw + 2) * (long long)p0.Hs * p0.Ws * p0.Cin * 2 : 256LL * p0.lda * 2;
+    const long long whole = p0.mode ? (p0.M / hw) * (long long)p0.Hs * p0.Ws * p0.Cin * 2 : (long long)p0.M * p0.lda * 2;
+    SHAPECHK((span < whole ? span : whole) <= 0x7f000000LL, "gemm: one row tile of A spans %lld bytes (limit 0x7f000000)", span);
+    SHAPECHK((long long)p0.N * p0.ldw * 2 <= 0x7fffffffLL, "gemm: W of %d x %d exceeds the 2 GB buffer range", p0.N, p0.ldw);
   }
   {
     // algorithmic work: 2*M*N*K; a transposed (zero-stuffed) conv only has 1/4 of its taps real

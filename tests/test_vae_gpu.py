@@ -134,3 +134,22 @@ def test_vae_decode_full_size_properties(gpu):
     assert a.shape == (2, 3, 1024, 1024) and torch.isfinite(a).all() and torch.equal(a, b)
     c = hip.decode(torch.stack([z[1], z[0]]))[0]
     assert torch.equal(c[0], a[1]) and torch.equal(c[1], a[0])
+
+
+def test_vae_decode_batch4_full_size_matches_single(gpu):
+    """Batch 4 at 1024x1024: the decoder's [4][1024][1024][256] activation is exactly 2^31 bytes, past what a 32-bit
+    buffer offset from the tensor base reaches -- the conv gather must address it per row tile.  Every sample of the
+    batch equals the same latent decoded alone."""
+    from pea_diffusion_amd import config as pc
+    from pea_diffusion_amd.vae import HipVAEDecoder
+    z = torch.randn(4, 4, 128, 128, generator=torch.Generator().manual_seed(8)).cuda()
+    hip4 = HipVAEDecoder(pc.sdxl_vae_config(), 4)
+    hip4.init_random(5)
+    a = hip4.decode(z)[0].clone()
+    del hip4
+    hip1 = HipVAEDecoder(pc.sdxl_vae_config(), 1)
+    hip1.init_random(5)
+    assert a.shape == (4, 3, 1024, 1024) and torch.isfinite(a).all()
+    for i in (3, 0):
+        one = hip1.decode(z[i:i + 1])[0]
+        assert torch.equal(one[0], a[i]), f"sample {i} of the batch differs from its single decode"
