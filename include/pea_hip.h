@@ -383,6 +383,8 @@ void pea_debug_set_attn_tr(int v);
 void pea_debug_set_attn_fused_bwd(int v);
 /* 0: cross-attention backward (<= 128 keys, head_dim 64) on the general kernels instead of the one-pass kernel (A/B) */
 void pea_debug_set_attn_xattn(int v);
+/* A/B aid: 1 = GEGLU backward inside the FF output projection's dgrad GEMM (default), 0 = its own kernel */
+void pea_debug_set_geglu_bwd_fused(int v);
 /* benchmark aid: force GEMM tile variant (>= 0) or restore the shape-based choice (-1) */
 void pea_debug_set_gemm_variant(int v);
 /* timing-only probes of the loader/consumer GEMM (results are wrong while set): 1 no DMA, 2 no barriers, 4 no ds_reads */

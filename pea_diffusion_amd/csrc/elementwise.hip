@@ -387,15 +387,28 @@ int launch_mean_tokens_bwd(const bf16* dy, bf16* dx, int B, int L, int C, int ac
   return PEA_OK;
 }
 
-__global__ void colsum_kernel(const bf16* __restrict__ x, float* __restrict__ db, int R, int C, int accum) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+// db[c] (+)= sum_r x[r][c].  A block owns 64 columns; its 16 waves take the rows round-robin and their partial sums are added in
+// wave order (deterministic) -- one thread per column walked the adapter's 616 rows serially in 144 us.
+__global__ __launch_bounds__(1024) void colsum_kernel(const bf16* __restrict__ x, float* __restrict__ db, int R, int C, int accum) {
+  __shared__ float part[16][64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + lane;
   float s = 0.f;
-  for (int r = 0; r < R; ++r) s += (float)x[(long long)r * C + c];
-  db[c] = accum ? db[c] + s : s;
+  if (c < C) {
+#pragma unroll 4
+    for (int r = w; r < R; r += 16) s += (float)x[(long long)r * C + c];
+  }
+  part[w][lane] = s;
+  __syncthreads();
+  if (w == 0 && c < C) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t += part[k][lane];
+    db[c] = accum ? db[c] + t : t;
+  }
 }
 int launch_colsum(const bf16* x, float* db, int R, int C, int accum, hipStream_t s) {
-  hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(C, 64)), dim3(64), 0, s, x, db, R, C, accum);
+  hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(C, 64)), dim3(1024), 0, s, x, db, R, C, accum);
   HIPCHK(hipGetLastError());
   return PEA_OK;
 }

@@ -253,9 +253,11 @@ __device__ __forceinline__ void gemm_epilogue16(const GemmP& p, f32x4 (&acc)[NT]
 // UN-normalised input of a LayerNorm folded into this GEMM -- W holds W' = W . gamma, p.bias holds t, and
 //   value = rstd[m] * (acc - mean[m] * s[n]) + t[n]        (p.ln_stats = [M][2] (mean, rstd), p.ln_s = s[N]);
 // such GEMMs have no residual and no row vector (QKV, attn2.to_q, FF projection with GEGLU).
-template <int MT, int NT, bool LNF = false>
+// EK: 0 = common form, 1 = LNF, 2 = the fused GEGLU backward (p.gbwd_pre; own instantiations for the same reason)
+template <int MT, int NT, int EK = 0>
 __device__ __forceinline__ void gemm_epilogue16_fast(const GemmP& p, f32x4 (&acc)[NT][MT], int m_base, int n_base, int r16,
                                                      int q4) {
+  constexpr bool LNF = EK == 1;
   typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
   typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
   // ---- loads: bias (+ row vector) per n-tile
@@ -346,6 +348,42 @@ __device__ __forceinline__ void gemm_epilogue16_fast(const GemmP& p, f32x4 (&acc
       }
     }
     return;
+  }
+  if constexpr (EK == 2) {
+    {
+      // GEGLU backward in the epilogue of the FF output projection's dgrad: a lane's 4 columns n..n+3 of d y meet the 4 stashed
+      // (h, gate) pairs at columns 2n..2n+7 (one 16-byte load) and leave as 4 (dh, dgate) pairs (one 16-byte store; the four
+      // lanes of a row cover 64 contiguous bytes).  Pairs one 16-row block ahead, as the residual quads below.
+      bf16x8 pq[2][NT];
+      auto load_pre = [&](int buf, int mt) {
+        const long long mo = (long long)min(m_base + mt * 16 + r16, p.M - 1) * p.ldgp;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) pq[buf][nt] = *(const bf16x8*)(p.gbwd_pre + mo + 2 * min(n_base + nt * 16 + 4 * q4, p.N - 4));
+      };
+      load_pre(0, 0);
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        if (mt + 1 < MT) load_pre((mt + 1) & 1, mt + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        const int m = m_base + mt * 16 + r16;
+        bf16* crow = (bf16*)p.C + (long long)min(m, p.M - 1) * p.ldc;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          const int n = n_base + nt * 16 + 4 * q4;
+          bf16x8 o;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            float dh, dg;
+            geglu_pair_bwd((float)pq[mt & 1][nt][2 * j], (float)pq[mt & 1][nt][2 * j + 1], val(nt, mt, j), dh, dg);
+            o[2 * j] = (bf16)dh;
+            o[2 * j + 1] = (bf16)dg;
+          }
+          if (m < p.M && n < p.N) *(bf16x8*)(crow + 2 * n) = o;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      return;
+    }
   }
   // residual quads one 16-row block ahead of the arithmetic (two buffers of NT quads): the loads of block mt + 1 are issued
   // before the stores of block mt, so the wait for them leaves those stores in flight; holding the whole tile's quads
@@ -708,7 +746,7 @@ __global__ __launch_bounds__((WM * WN + LW) * 64, MINW) void gemm_lc_kernel(cons
       cur = nxt;
     }
     if constexpr (LNF) {
-      gemm_epilogue16_fast<MT, NT, true>(p, acc, bm * BM + wr * (BM / WM), bn * BN + wc * (BN / WN), r16, q4);
+      gemm_epilogue16_fast<MT, NT, 1>(p, acc, bm * BM + wr * (BM / WM), bn * BN + wc * (BN / WN), r16, q4);
       return;
     }
     if (p.epi_fast) {
@@ -827,7 +865,7 @@ static int launch_lc(const GemmP& p, hipStream_t stream) {
 // per SIMD): the two run out of phase, so one's tile transition / DMA wait is the other's main loop.
 template <int MODE, int BM, int BN, int WM, int WN, int LW, int S, int SW = 0, int DF = 0, int EPI = 0, int OCC = 1>
 __global__ __launch_bounds__((WM * WN + LW + SW) * 64, (OCC == 2 ? 3 : 1)) void gemm_lcp_kernel(const GemmP p) {
-  constexpr bool FASTONLY = EPI != 0;     // EPI 1: batched-load epilogue only; 2: the same with the folded LayerNorm
+  constexpr bool FASTONLY = EPI != 0;     // EPI 1: batched-load epilogue only; 2: the same with the folded LayerNorm; 3: with the fused GEGLU backward
   constexpr int PITCH = BN * 2 + 16;                            // staging row pitch: conflict-free 8-byte writes
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int NWC = WM * WN;
@@ -1209,7 +1247,7 @@ __global__ __launch_bounds__((WM * WN + LW + SW) * 64, (OCC == 2 ? 3 : 1)) void 
         // inside the epilogue instead of being hoisted to kernel entry and kept (spilled) across the whole tile loop
         int r16e = r16, q4e = q4;
         asm volatile("" : "+v"(r16e), "+v"(q4e));
-        if (!PEA_PROBE(16)) gemm_epilogue16_fast<MT, NT, EPI == 2>(p, acc, bm * BM + wr * (BM / WM), bn * BN + wc * (BN / WN), r16e, q4e);
+        if (!PEA_PROBE(16)) gemm_epilogue16_fast<MT, NT, (EPI == 2 ? 1 : EPI == 3 ? 2 : 0)>(p, acc, bm * BM + wr * (BM / WM), bn * BN + wc * (BN / WN), r16e, q4e);
         else if (acc[0][0][0] == 12345.678f) *(float*)p.C = 1.f;   // timing probe: keep the accumulators alive
         // the next tile's first fragments were fetched at the last barrier already; fetching them AGAIN here makes that
         // copy dead across the epilogue, so its 36 registers are free for the residual quads (the K-loop body itself
@@ -1305,7 +1343,7 @@ static int pick_variant(const GemmP& p) {
   // measured (in-run A/B, profiles/r01_gemm_variants.log): +4..11 % in the hot microbenchmark, nothing in situ -> off
   // unless PEA_GEMM_DEFER is set
   static const bool defer = getenv("PEA_GEMM_DEFER") != nullptr;
-  const bool lean = defer && !p.out_f32 && !p.res && !p.rowvec && !p.act && !p.geglu_y && !p.preact && p.ksplit <= 1 &&
+  const bool lean = defer && !p.out_f32 && !p.res && !p.rowvec && !p.act && !p.geglu_y && !p.gbwd_pre && !p.preact && p.ksplit <= 1 &&
                     p.ldc % 8 == 0 && (((unsigned long long)p.C & 15) == 0);
   if (t128 <= 256) return lean ? 35 : 25;            // exactly one 128x160 tile per CU
   if (t256 <= 256) return t256 > 192 ? 24 : (lean ? 35 : 28);
@@ -1364,6 +1402,21 @@ int launch_gemm(const GemmP& p_in, hipStream_t stream) {
     SHAPECHK(p.out_f32 && !p.accum_f32 && !p.bias && !p.res && !p.rowvec && !p.preact && p.act == 0 && p.mode == 0,
              "gemm: split-K writes plain fp32 partials");
     v = 18;                                         // loader/consumer 128x128 (the only kernel with the K-split path)
+  }
+  if (p.gbwd_pre) {
+    // fused GEGLU backward: own instantiations of the persistent kernels (every tile form the shape rule picks for the FF
+    // output projection's dgrad maps to one of the three)
+    SHAPECHK(p.epi_fast && p.mode == 0 && !p.res && !p.rowvec && !p.bias && !p.geglu_y && !p.ln_stats && p.ldgp % 8 == 0 &&
+                 p.ldc >= 2 * p.N && (((unsigned long long)p.gbwd_pre & 15) == 0),
+             "gemm: the fused GEGLU backward needs the batched-load epilogue (bf16 [M][2N] output, no bias / residual / row vector)");
+    int rc;
+    if (v == 27 || v == 24) rc = launch_lcp<0, 256, 160, 4, 2, 4, 3, 0, 0, 3>(p, stream);   // (128-row tiles here: +1.0-1.5 ms per step)
+    else if (v == 31) rc = launch_lcp<0, 64, 160, 2, 2, 4, 4, 0, 0, 3>(p, stream);
+    else rc = launch_lcp<0, 128, 160, 4, 2, 4, 3, 0, 0, 3>(p, stream);
+    PROF_END(stream);
+    if (rc != PEA_OK) return rc;
+    HIPCHK(hipGetLastError());
+    return PEA_OK;
   }
   if (!p.epi_fast) {                                // the 256-row persistent kernels carry the batched-load epilogue only
     if (v == 27) v = 28;

@@ -1190,6 +1190,10 @@ int Tape::exec_ops(size_t begin, size_t end, bool skip_cached, hipStream_t s) {
 }
 
 // ============================================================================ backward
+// 1 (default): the GEGLU backward runs in the epilogue of the FF output projection's dgrad GEMM; 0: as its own kernel (A/B,
+// and the cross-check of tests/test_model_gpu.py).  PEA_GEGLU_BWD_UNFUSED in the environment starts with 0.
+static int g_geglu_bwd_fused = getenv("PEA_GEGLU_BWD_UNFUSED") ? 0 : 1;
+extern "C" void pea_debug_set_geglu_bwd_fused(int v) { g_geglu_bwd_fused = v; }
 void Tape::begin_backward() {
   for (Tn& t : tn) { t.gw = false; t.gpend = nullptr; }
 }
@@ -1227,6 +1231,7 @@ int Tape::backward(const float* deps, hipStream_t s) {
     RC(launch_accum(from.g, r.g, rb(r) * r.cols, 1, s));
     return PEA_OK;
   };
+  int dpre_of = -1;          // tensor whose gradient currently lives in geglu_tmp as d(pre-activation) (fused GEGLU backward)
   for (int oi = (int)ops.size() - 1; oi >= 0; --oi) {
     Op& o = ops[oi];
     if (o.kind == OP_CONV_OUT) {
@@ -1263,7 +1268,8 @@ int Tape::backward(const float* deps, hipStream_t s) {
         }
         if (a.rg && o.p3 == 3) {          // fused GEGLU: d(pre-activation) into scratch, then the dgrad GEMM over K = 8C
           Tn& hg = tn[o.c];
-          RC(launch_geglu_bwd_il(hg.d, out.g, geglu_tmp, rb(out), out.cols, s));
+          if (dpre_of != o.out) RC(launch_geglu_bwd_il(hg.d, out.g, geglu_tmp, rb(out), out.cols, s));
+          dpre_of = -1;
           WSlot& w = slots[o.w];
           GemmP p; fill_gemm(p);
           p.A = geglu_tmp; p.lda = hg.cols; p.M = (int)rb(out); p.K = hg.cols; p.N = a.cols;
@@ -1280,10 +1286,24 @@ int Tape::backward(const float* deps, hipStream_t s) {
           if (o.fused >= 0) { FusedMat& f = fused[o.fused]; p.W = f.wt; p.ldw = f.N; }
           else { WSlot& w = slots[o.w]; p.W = w.wt; p.ldw = w.ldwt; }
           SHAPECHK(p.W != nullptr, "unet: dgrad weights missing for op %d", oi);
-          p.C = a.g; p.ldc = a.cols;
-          if (const bf16* ad = addend(a)) { p.res = ad; p.ldres = a.cols; }
-          RC(launch_gemm(p, s));
-          a.gw = true;
+          // The FF output projection right behind a fused-GEGLU projection: its input gradient d y is only ever consumed
+          // by the GEGLU backward, so that runs in this GEMM's epilogue and d(pre-activation) lands in the scratch the
+          // next (GEGLU) op's dgrad reads -- d y is never written, one launch and a read + write of it less per block.
+          const Op* prev = oi > 0 ? &ops[oi - 1] : nullptr;
+          if (g_geglu_bwd_fused && prev && prev->kind == OP_LINEAR && prev->p3 == 3 && prev->out == o.a && prev->c >= 0 &&
+              tn[prev->a].rg && !a.gw && !a.gpend && geglu_tmp && a.cols % 16 == 0) {
+            Tn& hg = tn[prev->c];
+            p.gbwd_pre = hg.d; p.ldgp = hg.cols;
+            p.C = geglu_tmp; p.ldc = hg.cols;
+            RC(launch_gemm(p, s));
+            a.gw = true;
+            dpre_of = o.a;
+          } else {
+            p.C = a.g; p.ldc = a.cols;
+            if (const bf16* ad = addend(a)) { p.res = ad; p.ldres = a.cols; }
+            RC(launch_gemm(p, s));
+            a.gw = true;
+          }
         }
         if (o.res >= 0 && tn[o.res].rg) RC(pass_on(out, tn[o.res]));
         break;

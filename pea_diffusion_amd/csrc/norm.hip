@@ -536,21 +536,35 @@ int launch_ln_fold(const bf16* W, int ldw, const float* gamma, const float* beta
   return PEA_OK;
 }
 
-// dgamma[c] += sum_r dy[r][c] * xhat[r][c]; dbeta[c] += sum_r dy[r][c]; one thread per column, rows in
-// order (deterministic; only the adapter's LayerNorm has trainable affine parameters, R = 2*B*L rows)
-__global__ void ln_param_grad_kernel(const bf16* __restrict__ x, const bf16* __restrict__ dy,
-                                     const float* __restrict__ stats, float* __restrict__ dgamma,
-                                     float* __restrict__ dbeta, int R, int C) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+// dgamma[c] += sum_r dy[r][c] * xhat[r][c]; dbeta[c] += sum_r dy[r][c].  A block owns 64 columns; its 16 waves take the rows
+// round-robin (128-byte row segments per load, four rows in flight per wave) and the 16 partial sums are added in wave
+// order: deterministic.  Only the adapter's LayerNorm has trainable affine parameters (R = 2*B*L rows); the one-thread-
+// per-column form this replaces walked the 616 rows serially in 245 us.
+__global__ __launch_bounds__(1024) void ln_param_grad_kernel(const bf16* __restrict__ x, const bf16* __restrict__ dy,
+                                                             const float* __restrict__ stats, float* __restrict__ dgamma,
+                                                             float* __restrict__ dbeta, int R, int C) {
+  __shared__ float sg[16][64], sb[16][64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + lane;
   float g = 0.f, b = 0.f;
-  for (int r = 0; r < R; ++r) {
-    const float d = (float)dy[(long long)r * C + c];
-    g += d * ((float)x[(long long)r * C + c] - stats[2 * r]) * stats[2 * r + 1];
-    b += d;
+  if (c < C) {
+#pragma unroll 4
+    for (int r = w; r < R; r += 16) {
+      const float d = (float)dy[(long long)r * C + c];
+      g += d * ((float)x[(long long)r * C + c] - stats[2 * r]) * stats[2 * r + 1];
+      b += d;
+    }
   }
-  dgamma[c] += g;
-  dbeta[c] += b;
+  sg[w][lane] = g;
+  sb[w][lane] = b;
+  __syncthreads();
+  if (w == 0 && c < C) {
+    float gs = 0.f, bs = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) { gs += sg[k][lane]; bs += sb[k][lane]; }
+    dgamma[c] += gs;
+    dbeta[c] += bs;
+  }
 }
 
 int launch_layernorm_bwd(const bf16* x, const bf16* dy, const float* gamma, const float* stats, bf16* dx,
@@ -561,7 +575,7 @@ int launch_layernorm_bwd(const bf16* x, const bf16* dy, const float* gamma, cons
 #define LN_BWD(N) hipLaunchKernelGGL(ln_bwd_kernel<N>, dim3(cdiv(R, 4 * LN_NR)), dim3(256), 0, s, x, dy, gamma, stats, dx, dgamma, dbeta, R, C, add)
   if (dx) { if (nch <= 1) LN_BWD(1); else if (nch == 2) LN_BWD(2); else if (nch == 3) LN_BWD(3); else if (nch == 4) LN_BWD(4); else LN_BWD(8); }
 #undef LN_BWD
-  if (dgamma) hipLaunchKernelGGL(ln_param_grad_kernel, dim3(cdiv(C, 64)), dim3(64), 0, s, x, dy, stats, dgamma, dbeta, R, C);
+  if (dgamma) hipLaunchKernelGGL(ln_param_grad_kernel, dim3(cdiv(C, 64)), dim3(1024), 0, s, x, dy, stats, dgamma, dbeta, R, C);
   PROF_END(s);
   HIPCHK(hipGetLastError());
   return PEA_OK;

@@ -38,6 +38,10 @@ struct GemmP {
   // folded LayerNorm on the A operand (A = the UN-normalised rows, W = W' = W.gamma, bias = t):
   //   value = rstd[m] * (acc - mean[m] * ln_s[n]) + bias[n];  ln_stats = [M][2] (mean, rstd).  Needs epi_fast.
   const float* ln_stats; const float* ln_s;
+  // GEGLU backward fused into this (dgrad) GEMM: the result is d y[m][n] of y = h * gelu(gate); gbwd_pre[m][2n], [2n+1] are
+  // the stashed (h, gate); C becomes [M][2N] (ldc >= 2N): C[m][2n] = dy * gelu(gate), C[m][2n+1] = dy * h * gelu'(gate).
+  // Needs epi_fast (bf16 output, no activation / residual / row vector).
+  const bf16* gbwd_pre; int ldgp;
 };
 int launch_splitk_reduce(const float* part, int nsplit, long long stride, bf16* out, int ldo, int M, int N, int accum,
                          hipStream_t s);

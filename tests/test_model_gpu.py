@@ -103,7 +103,23 @@ def test_unet_forward_tiny(gpu, B, L):
     assert e < 2e-2
 
 
-def test_unet_backward_tiny(gpu):
+@pytest.mark.parametrize("geglu_bwd_fused", [1, 0])
+def test_unet_backward_tiny(gpu, geglu_bwd_fused):
+    """geglu_bwd_fused 1 (default): the GEGLU backward runs in the epilogue of the FF output projection's dgrad GEMM
+    (d y is never stored); 0: as its own kernel.  Both against the fp32 oracle."""
+    from oracle.unet_ref import cast_hook_ref, tap_names, tiny_config
+    from pea_diffusion_amd._lib import check, lib, ptr, stream_ptr
+    lib().pea_debug_set_geglu_bwd_fused(geglu_bwd_fused)
+    try:
+        _unet_backward_tiny(geglu_bwd_fused)
+    finally:
+        lib().pea_debug_set_geglu_bwd_fused(1)
+
+
+_bwd_tiny_grads = {}
+
+
+def _unet_backward_tiny(mode):
     from oracle.unet_ref import cast_hook_ref, tap_names, tiny_config
     from pea_diffusion_amd._lib import check, lib, ptr, stream_ptr
     B, L = 2, 9
@@ -131,9 +147,14 @@ def test_unet_backward_tiny(gpu):
         mask |= 1 << i
     d_ehs, d_text = hip.backward(d_eps.cuda(), mask)
     e1, e2 = rel_l2(d_ehs, ehs_r.grad), rel_l2(d_text, te_r.grad)
-    print(f"[unet bwd tiny] d_ehs rel_l2={e1:.3e} |ref|={ehs_r.grad.norm():.3e}  d_text rel_l2={e2:.3e} "
+    print(f"[unet bwd tiny, geglu bwd fused={mode}] d_ehs rel_l2={e1:.3e} |ref|={ehs_r.grad.norm():.3e}  d_text rel_l2={e2:.3e} "
           f"|ref|={te_r.grad.norm():.3e}")
     assert e1 < 4e-2 and e2 < 4e-2
+    _bwd_tiny_grads[mode] = d_ehs.clone()
+    if len(_bwd_tiny_grads) == 2:      # the two forms differ by one bf16 rounding of d y: close, and NOT bit-identical
+        d = rel_l2(_bwd_tiny_grads[1], _bwd_tiny_grads[0])
+        print(f"[unet bwd tiny] fused vs own-kernel GEGLU backward: rel_l2={d:.3e}")
+        assert 0 < d < 3e-2, "fused path not taken (bit-identical) or far from the unfused one"
 
 
 def test_adapter_module_matches_reference_golden(gpu, golden_dir):
