@@ -1559,10 +1559,122 @@ __global__ __launch_bounds__(256) void conv_out_kernel(const bf16* __restrict__ 
   }
 }
 
+// conv_out on the matrix cores.  The GEMM is [pixels][9 Cin] x [9 Cin][Cout <= 8]: Cout fills at most half of a 16-wide
+// MFMA, so the spare rows carry the LOW halves of the fp32 weights (w = hi + lo, both bf16: the fp32 weights of the layer
+// are kept to 16 mantissa bits instead of being rounded to bf16) and one v_mfma_f32_16x16x32_bf16 multiplies 16 pixels x 32
+// channels of one tap by both.  Weights (rows n = 4 q + r: hi parts in the first Cq = ceil(Cout / 4) quads, lo parts in
+// the next Cq) are split once per workgroup into LDS, laid out so that a lane's fragment is one 16-byte read; the pixel
+// operand comes straight from global memory (16 bytes per lane, the 9 taps of a pixel re-read through L1 / L2).
+// A wave owns 4 strips of 16 consecutive pixels (one weight fragment feeds 4 MFMAs); 4 waves per workgroup, 46 KB of LDS
+// for the UNet's 320 -> 4 (three workgroups per CU).
+// The direct form below (one wave per pixel, weights re-read per pixel) took 232 us on the UNet's [8][128][128][320].
+__global__ __launch_bounds__(256) void conv_out_mfma_kernel(const bf16* __restrict__ x, const float* __restrict__ w,
+                                                            const float* __restrict__ bias, float* __restrict__ y,
+                                                            int B, int Cin, int H, int W, int Cout) {
+  extern __shared__ __attribute__((aligned(16))) char cosm[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int c32n = Cin / 32, ksteps = 9 * c32n;
+  const int Cq = (Cout + 3) / 4;
+  const int NR = 8 * Cq;                                    // weight rows kept in LDS: hi parts, then lo parts (the rest are zero)
+  // ---- weights -> LDS: [kstep][g][n < NR][8] bf16
+  for (int i = tid; i < ksteps * 4 * NR; i += 256) {
+    const int n = i % NR, g = (i / NR) & 3, ks = i / (4 * NR);
+    const int tap = ks / c32n, c0 = (ks - tap * c32n) * 32 + g * 8;
+    const int part = n / (4 * Cq), co = n - part * 4 * Cq;
+    bf16x8 o = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (co < Cout) {
+      const float* wp = w + ((long long)co * 9 + tap) * Cin + c0;
+      const f32x4 w0 = *(const f32x4*)wp, w1 = *(const f32x4*)(wp + 4);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float wv = j < 4 ? w0[j] : w1[j - 4];
+        const float hi = (float)(bf16)wv;
+        o[j] = (bf16)(part ? wv - hi : hi);
+      }
+    }
+    *(bf16x8*)(cosm + (long long)i * 16) = o;
+  }
+  __syncthreads();
+  const long long npix = (long long)B * H * W;
+  const long long p0 = (long long)blockIdx.x * 256 + wave * 64;
+  const int pr = lane & 15, g = lane >> 4;
+  int py[4], px[4];
+  long long pb[4];                                          // element offset of sample b
+  bool pv[4];
+#pragma unroll
+  for (int s4 = 0; s4 < 4; ++s4) {
+    const long long P = p0 + s4 * 16 + pr;
+    pv[s4] = P < npix;
+    const long long Pc = pv[s4] ? P : 0;
+    px[s4] = (int)(Pc % W);
+    py[s4] = (int)((Pc / W) % H);
+    pb[s4] = (Pc / ((long long)W * H)) * H * W * Cin;
+  }
+  f32x4 acc[4];
+#pragma unroll
+  for (int s4 = 0; s4 < 4; ++s4) acc[s4] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+  const bool wrow = pr < NR;                                // lanes of the zero rows read a valid address and drop it
+  const int wlane = g * NR + (wrow ? pr : 0);
+  for (int tap = 0; tap < 9; ++tap) {
+    const int ky = tap / 3, kx = tap - ky * 3;
+    const bf16* src[4];
+    bool ok[4];
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) {
+      const int iy = py[s4] + ky - 1, ix = px[s4] + kx - 1;
+      ok[s4] = pv[s4] && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+      src[s4] = x + pb[s4] + ((long long)(ok[s4] ? iy : 0) * W + (ok[s4] ? ix : 0)) * Cin + g * 8;   // always a valid address
+    }
+    const char* wl = cosm + ((long long)tap * c32n * 4 * NR + wlane) * 16;
+#pragma unroll 5
+    for (int c = 0; c < c32n; ++c) {
+      bf16x8 wf = *(const bf16x8*)(wl + c * (4 * NR * 16));
+      wf = wrow ? wf : zero8;
+      bf16x8 xf[4];
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) xf[s4] = *(const bf16x8*)(src[s4] + c * 32);     // unconditional: the loads of an unrolled
+#pragma unroll                                                                        // group leave back to back
+      for (int s4 = 0; s4 < 4; ++s4) {
+        const bf16x8 xv = ok[s4] ? xf[s4] : zero8;
+        acc[s4] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, xv, acc[s4], 0, 0, 0);
+      }
+    }
+  }
+  // lane (pixel pr, quad g) holds rows n = 4 g + r: quads [0, Cq) = hi parts of couts 4 g + r, quads [Cq, 2 Cq) = lo parts
+#pragma unroll
+  for (int s4 = 0; s4 < 4; ++s4) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float lo = __shfl(acc[s4][r], (lane + 16 * Cq) & 63, 64);
+      const int co = 4 * g + r;
+      if (g < Cq && co < Cout && pv[s4]) {
+        const long long P = p0 + s4 * 16 + pr;
+        const long long bq = P / ((long long)W * H), rem = P - bq * W * H;
+        y[(bq * Cout + co) * H * W + rem] = acc[s4][r] + lo + bias[co];
+      }
+    }
+  }
+}
+
 int launch_conv_out(const bf16* x, const float* w, const float* bias, float* y, int B, int Cin, int H, int W,
                     int Cout, hipStream_t s) {
   SHAPECHK(Cout <= 8 && Cin % 8 == 0, "conv_out: Cout<=8, Cin%%8");
   const long long pix = (long long)B * H * W;
+  static const bool direct = getenv("PEA_CONV_OUT_DIRECT") != nullptr;        // A/B switch: the one-wave-per-pixel form
+  const size_t lds = (size_t)9 * (Cin / 32) * 4 * 8 * ((Cout + 3) / 4) * 16;       // [9 Cin / 32][4][8 or 16 rows][16 bytes]
+  if (!direct && Cin % 32 == 0 && lds <= 160 * 1024) {
+    if (lds > 64 * 1024) {
+      static bool attr_set = false;
+      if (!attr_set) {
+        HIPCHK(hipFuncSetAttribute((const void*)conv_out_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+      }
+    }
+    hipLaunchKernelGGL(conv_out_mfma_kernel, dim3((unsigned)cdivl(pix, 256)), dim3(256), lds, s, x, w, bias, y, B, Cin, H, W, Cout);
+    HIPCHK(hipGetLastError());
+    return PEA_OK;
+  }
   hipLaunchKernelGGL(conv_out_kernel, dim3((unsigned)cdivl(pix, 4)), dim3(256), 0, s, x, w, bias, y, B, Cin, H, W,
                      Cout);
   HIPCHK(hipGetLastError());

@@ -226,6 +226,21 @@ def test_conv_in_out(ops):
     close_bf16("conv_out dgrad", ops.conv_out_dgrad(dy.cuda(), wp, C), _nhwc(hh.grad))
 
 
+@pytest.mark.parametrize("B,H,W,C,Cout", [(2, 32, 32, 320, 4), (1, 12, 20, 128, 3), (3, 8, 24, 512, 8), (1, 40, 40, 64, 4),
+                                          (2, 16, 16, 72, 4)])
+def test_conv_out_shapes(ops, B, H, W, C, Cout):
+    """conv_out on the matrix cores (weights as hi + lo bf16 halves): UNet eps head (320 -> 4), VAE decoder head (128 -> 3),
+    VAE encoder moments (512 -> 8), pixel counts that are not multiples of the 512-pixel workgroup or the 16-pixel strip;
+    Cin = 72 takes the direct kernel (Cin % 32 != 0)."""
+    g = torch.Generator().manual_seed(B * 100 + C)
+    h = (torch.randn(B, C, H, W, generator=g) * 1.5).to(BF)
+    w_out = torch.randn(Cout, C, 3, 3, generator=g) * (1.0 / (3.0 * C ** 0.5))
+    b_out = torch.randn(Cout, generator=g)
+    wp = ops.pack_conv_out(w_out.cuda())
+    got = ops.conv_out(_nhwc(h).cuda(), wp, b_out.cuda())
+    close_f32(f"conv_out {C}->{Cout} {B}x{H}x{W}", got, F.conv2d(h.float(), w_out, b_out, padding=1))
+
+
 # ------------------------------------------------------------------------------------ norms
 @pytest.mark.parametrize("B,HW,C,silu", [(2, 256, 320, True), (2, 64, 64, False), (1, 1024, 960, True),
                                          (3, 16, 2560, True), (2, 4096, 640, False)])
