@@ -1503,9 +1503,120 @@ __global__ __launch_bounds__(256) void conv_in_kernel(const float* __restrict__ 
   }
 }
 
+// The same with 4 consecutive pixels of a row per thread (W % 4 == 0): a weight vector read from LDS feeds 4 pixels and a
+// row segment of 6 inputs feeds 3 taps x 4 pixels, so the loop is bound by its FMAs, not by the LDS reads (1 byte of LDS per
+// FMA instead of 4).  It serves both 4-channel ends that produce a wide NHWC tensor from a narrow fp32 NCHW one:
+//   FLIP = false: conv_in                x [B][Cs][H][W], w [N][Cs][3][3]  ->  y [pix][N] (+ bias, optional SiLU)
+//   FLIP = true : dgrad of conv_out     dy [B][Cs][H][W], w [Cs][3][3][N] ->  dx [pix][N]   (taps mirrored)
+template <bool FLIP>
+__global__ __launch_bounds__(256) void conv_few4_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                        const float* __restrict__ bias, bf16* __restrict__ y, int B,
+                                                        int Cs, int H, int W, int N, int groups_per_block, int ldy,
+                                                        int silu) {
+  extern __shared__ __attribute__((aligned(16))) char cfsm[];
+  float* wl = (float*)cfsm;                       // [Cs*9][N]
+  const int K = Cs * 9;
+  for (int i = threadIdx.x; i < K * N; i += blockDim.x) {
+    if (FLIP) {
+      wl[i] = w[i];                               // already [k = co*9 + tap][n]
+    } else {
+      const int n = i / K, k = i - n * K;         // w[n][ci][ky][kx] -> k = ci*9 + ky*3 + kx
+      wl[k * N + n] = w[i];
+    }
+  }
+  __syncthreads();
+  const int nchunk = N / 8;
+  const int ppb = blockDim.x / nchunk;
+  const int ck = threadIdx.x % nchunk, pl = threadIdx.x / nchunk;
+  if (pl >= ppb) return;
+  const int c0 = ck * 8;
+  float bs[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) bs[j] = bias ? bias[c0 + j] : 0.f;
+  const int W4 = W / 4;
+  const long long ngroups = (long long)B * H * W4;
+  const long long g0 = (long long)blockIdx.x * groups_per_block;
+  const long long g1 = g0 + groups_per_block < ngroups ? g0 + groups_per_block : ngroups;
+  for (long long grp = g0 + pl; grp < g1; grp += ppb) {
+    const int x0 = (int)(grp % W4) * 4, yh = (int)((grp / W4) % H), b = (int)(grp / ((long long)W4 * H));
+    float acc[4][8];
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[p][j] = bs[j];
+    for (int ci = 0; ci < Cs; ++ci)
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky) {
+        const int iy = FLIP ? yh + 1 - ky : yh + ky - 1;
+        if ((unsigned)iy >= (unsigned)H) continue;
+        const float* row = x + (((long long)b * Cs + ci) * H + iy) * W;
+        float v[6];                               // inputs x0-1 .. x0+4 (x0 % 4 == 0: the middle four are one aligned 16-byte load)
+        const f32x4 mid = *(const f32x4*)(row + x0);
+        v[0] = x0 > 0 ? row[x0 - 1] : 0.f;
+        v[1] = mid[0]; v[2] = mid[1]; v[3] = mid[2]; v[4] = mid[3];
+        v[5] = x0 + 4 < W ? row[x0 + 4] : 0.f;
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+          const float* wr = wl + (ci * 9 + ky * 3 + kx) * N + c0;
+          const f32x4 w0 = *(const f32x4*)wr, w1 = *(const f32x4*)(wr + 4);
+#pragma unroll
+          for (int p = 0; p < 4; ++p) {
+            const float vv = FLIP ? v[p + 2 - kx] : v[p + kx];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              acc[p][j] += vv * w0[j];
+              acc[p][4 + j] += vv * w1[j];
+            }
+          }
+        }
+      }
+    const long long pix = ((long long)b * H + yh) * W + x0;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      bf16x8 o;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] = (bf16)(silu ? siluf_(acc[p][j]) : acc[p][j]);
+      *(bf16x8*)(y + (pix + p) * ldy + c0) = o;
+    }
+  }
+}
+
+// shared launcher of the two uses; returns false when the shape needs the one-pixel-per-thread kernels
+template <bool FLIP>
+static bool launch_conv_few4(const float* x, const float* w, const float* bias, bf16* y, int B, int Cs, int H, int W, int N,
+                             int ldy, int silu, hipStream_t s, int* rc) {
+  static const bool off = getenv("PEA_CONV_ENDS_1PX") != nullptr;               // A/B switch
+  const size_t lds = (size_t)Cs * 9 * N * 4;
+  if (off || W % 4 != 0 || N % 8 != 0 || N / 8 > 256 || lds > 160 * 1024 || (((unsigned long long)x) & 15) != 0) return false;
+  *rc = PEA_OK;
+  if (lds > 64 * 1024) {
+    static bool attr_set = false;
+    if (!attr_set) {
+      if (hipFuncSetAttribute((const void*)conv_few4_kernel<FLIP>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+        *rc = PEA_E_HIP;
+        return true;
+      }
+      attr_set = true;
+    }
+  }
+  const int ppb = 256 / (N / 8);
+  const long long ngroups = (long long)B * H * (W / 4);
+  // two to three workgroups per CU each walk their share of the pixel groups (the weights are staged once per workgroup)
+  long long per = cdivl(ngroups, 768);
+  per = cdivl(per, ppb) * ppb;
+  hipLaunchKernelGGL(conv_few4_kernel<FLIP>, dim3((unsigned)cdivl(ngroups, per)), dim3(256), lds, s, x, w, bias, y, B, Cs, H, W, N,
+                     (int)per, ldy, silu);
+  if (hipGetLastError() != hipSuccess) *rc = PEA_E_HIP;
+  return true;
+}
+
 int launch_conv_in(const float* x, const float* w, const float* bias, bf16* y, int B, int Cin, int H, int W,
                    int Cout, hipStream_t s, int ldy, int silu) {
   if (ldy <= 0) ldy = Cout;
+  {
+    int rc;
+    if (launch_conv_few4<false>(x, w, bias, y, B, Cin, H, W, Cout, ldy, silu, s, &rc)) return rc;
+  }
   SHAPECHK(Cout % 8 == 0 && Cout / 8 <= 256 && Cin * 9 * Cout * 4 <= 160 * 1024, "conv_in: Cout=%d Cin=%d", Cout, Cin);
   if (Cin * 9 * Cout * 4 > 64 * 1024) {           // VAE decoder conv_in (4 -> 512): 72 KB of fp32 weights in LDS
     static bool attr_set = false;
@@ -1713,6 +1824,10 @@ __global__ void conv_out_dgrad_kernel(const float* __restrict__ dy, const float*
 
 int launch_conv_out_dgrad(const float* dy, const float* w, bf16* dx, int B, int Cin, int H, int W, int Cout,
                           hipStream_t s) {
+  {
+    int rc;
+    if (launch_conv_few4<true>(dy, w, nullptr, dx, B, Cout, H, W, Cin, Cin, 0, s, &rc)) return rc;
+  }
   const long long total = (long long)B * H * W * (Cin / 8);
   hipLaunchKernelGGL(conv_out_dgrad_kernel, dim3((unsigned)cdivl(total, 256)), dim3(256), 0, s, dy, w, dx, B, Cin,
                      H, W, Cout);

@@ -241,6 +241,23 @@ def test_conv_out_shapes(ops, B, H, W, C, Cout):
     close_f32(f"conv_out {C}->{Cout} {B}x{H}x{W}", got, F.conv2d(h.float(), w_out, b_out, padding=1))
 
 
+@pytest.mark.parametrize("B,H,W,Cs,N", [(2, 32, 32, 4, 320), (1, 12, 20, 3, 128), (1, 16, 24, 4, 512), (2, 9, 10, 4, 64)])
+def test_conv_in_and_conv_out_dgrad_shapes(ops, B, H, W, Cs, N):
+    """The 4-pixels-per-thread kernel behind conv_in and the conv_out dgrad (W % 4 == 0) and the one-pixel fallback (W = 10):
+    UNet conv_in (4 -> 320), VAE encoder conv_in (3 -> 128), VAE decoder conv_in (4 -> 512, 72 KB of weights in LDS)."""
+    g = torch.Generator().manual_seed(B * 1000 + N + W)
+    x = torch.randn(B, Cs, H, W, generator=g)
+    w_in, b_in = torch.randn(N, Cs, 3, 3, generator=g) * 0.2, torch.randn(N, generator=g)
+    y = ops.conv_in(x.cuda(), w_in.cuda(), b_in.cuda())
+    close_bf16(f"conv_in {Cs}->{N} {B}x{H}x{W}", y, _nhwc(F.conv2d(x, w_in, b_in, padding=1)))
+    w_out = torch.randn(Cs, N, 3, 3, generator=g) * 0.05
+    wp = ops.pack_conv_out(w_out.cuda())
+    hh = torch.zeros(B, N, H, W, requires_grad=True)
+    dy = torch.randn(B, Cs, H, W, generator=g)
+    F.conv2d(hh, w_out, None, padding=1).backward(dy)
+    close_bf16(f"conv_out dgrad {Cs}->{N} {B}x{H}x{W}", ops.conv_out_dgrad(dy.cuda(), wp, N), _nhwc(hh.grad))
+
+
 # ------------------------------------------------------------------------------------ norms
 @pytest.mark.parametrize("B,HW,C,silu", [(2, 256, 320, True), (2, 64, 64, False), (1, 1024, 960, True),
                                          (3, 16, 2560, True), (2, 4096, 640, False)])
