@@ -24,16 +24,61 @@ from ._lib import PeaError
 BUCKETS = [[448, 896], [448, 832], [512, 768], [576, 704], [640, 640], [704, 576], [768, 512], [832, 448], [896, 448]]
 
 
+class _PinnedRing:
+    """Small host tensors (token ids, size / crop lists, flags) go to the device through a ring of pinned slots allocated
+    once: a copy from pageable memory blocks the caller until the stream's earlier work is done -- with the GPU a step
+    behind the host that serialises the host's enqueueing with the GPU -- and pinning a fresh tensor per call goes through
+    the host allocator (measured slower than the blocking copy).  A slot is reused `slots` copies later, after its event."""
+
+    def __init__(self, slots: int = 32, nbytes: int = 1 << 16):
+        self.buf = torch.empty(slots, nbytes, dtype=torch.uint8).pin_memory()
+        self.events, self.next, self.nbytes = [None] * slots, 0, nbytes
+
+    def copy(self, t: torch.Tensor, device) -> torch.Tensor:
+        t = t.contiguous()
+        n = t.numel() * t.element_size()
+        k, self.next = self.next, (self.next + 1) % len(self.events)
+        if self.events[k] is not None:
+            self.events[k].synchronize()
+        view = self.buf[k, :n].view(t.dtype).view(t.shape)
+        view.copy_(t)
+        out = view.to(device, non_blocking=True)
+        self.events[k] = torch.cuda.Event()
+        self.events[k].record(torch.cuda.current_stream(device))
+        return out
+
+
+_ring = None
+ASYNC_COPIES = True      # False: plain (blocking) copies of pageable host tensors, for an A/B
+
+
+def _to_device(t, device, dtype=None) -> torch.Tensor:
+    """host -> device without stalling the host where that is possible: device tensors pass through, pinned tensors (a
+    DataLoader with pin_memory=True) are copied asynchronously, small pageable ones go through the pinned ring."""
+    global _ring
+    t = torch.as_tensor(t)
+    if ASYNC_COPIES and t.device.type == "cpu" and torch.device(device).type == "cuda":
+        if t.is_pinned():
+            t = t.to(device, non_blocking=True)
+        elif 0 < t.numel() * t.element_size() <= (1 << 16):
+            if _ring is None:
+                _ring = _PinnedRing()
+            t = _ring.copy(t, device)
+    return t.to(device=device, dtype=dtype)
+
+
 def add_time_ids_from_batch(batch: Dict, device, buckets: Sequence[Sequence[int]] = BUCKETS) -> torch.Tensor:
     """`torch.cat([original_size, crops_coords_top_left, target_size], 1)` with
     `target_size = [BUCKETS[bucket_id]] * B` (train_sdxl_zh.py:386-389) -> fp32 [B,6]"""
-    osz = torch.as_tensor(batch["original_size"]).to(device).reshape(-1, 2)
-    crop = torch.as_tensor(batch["crops_coords_top_left"]).to(device).reshape(-1, 2)
+    osz = torch.as_tensor(batch["original_size"]).reshape(-1, 2)
+    crop = torch.as_tensor(batch["crops_coords_top_left"]).reshape(-1, 2)
     bid = int(torch.as_tensor(batch["bucket_id"]).reshape(-1)[0])
     if not 0 <= bid < len(buckets):
         raise PeaError(f"bucket_id {bid} outside the {len(buckets)} buckets")
-    tgt = torch.tensor([list(buckets[bid])] * osz.shape[0], device=device)
-    return torch.cat([osz, crop, tgt], 1).to(torch.float32)
+    tgt = torch.tensor([list(buckets[bid])] * osz.shape[0])
+    if osz.device.type != "cpu" or crop.device.type != "cpu":        # already on the device: assemble there
+        return torch.cat([osz.to(device), crop.to(device), tgt.to(device)], 1).to(torch.float32)
+    return _to_device(torch.cat([osz, crop, tgt], 1).to(torch.float32), device)    # assembled on the host, ONE async copy
 
 
 class PEAFrontEnd:
@@ -47,6 +92,19 @@ class PEAFrontEnd:
         self.vae, self.te1, self.te2, self.zh = vae, text_encoder_1, text_encoder_2, student_text_encoder
         self.noise_offset, self.uncond, self.T = noise_offset, uncond, num_train_timesteps
         self.tokenize_en, self.buckets = tokenize_en, buckets
+        # The three text towers run on their own (high-priority) HIP streams beside the VAE encode: at 2B x 77 = 616 rows
+        # their ~800 launches are latency-bound and fill a third of the CUs at best, so one after the other on the VAE's
+        # stream they cost 8.6 ms of a 34.7 ms front end; concurrently the front end takes 29.7 ms and the whole
+        # training_step_from_batch 136.3 instead of 141.8 ms (scripts/full_step_bench.py).
+        self.concurrent_towers = True
+        self.tower_streams = 3          # streams the three towers are spread over (set before the first prepare)
+        # With the towers on their own streams the host first waits for the current stream to drain (one stream
+        # synchronise per call, the KD step of the previous batch): measured, enqueueing the towers while the host is
+        # still ~1000 launches ahead of the GPU loses more (their launches trickle in at the pace the queue frees up:
+        # 145.0 ms per step) than the short idle gap costs (136.3-138.5 ms; 141.8-143.2 with the towers on the VAE stream).
+        self.drain_before_enqueue = True
+        self._tower_streams = None
+        self._tower_outs = None
 
     def _teacher_ids(self, batch, B):
         if "texts_en_ids" in batch:
@@ -77,9 +135,41 @@ class PEAFrontEnd:
         """reference batch dict -> the post-encoder batch of PEATrainer.training_step.  Keys `_noise`, `_timesteps`,
         `_prompt_mask`, `_vae_noise` override the random draws (parity tests feed the oracle the same values)."""
         dev = self.vae.device
-        px = batch["pixel_values"].to(dev, torch.float32)
+        px = _to_device(batch["pixel_values"], dev, torch.float32)
         B = px.shape[0]
+        # every host -> device copy goes through pinned memory (_to_device): the call never waits for the GPU, so the host
+        # keeps enqueueing (this call's towers, the KD step behind it) while the GPU works
+        time_ids = add_time_ids_from_batch(batch, dev, self.buckets)
+        zh_or_not = _to_device(batch["zh_or_not"], dev)
+        ids = _to_device(batch["input_ids"], dev)
+        ids_u = _to_device(batch["input_ids_uncond"], dev)
+        if ids_u.shape[0] != B:
+            ids_u = ids_u.expand(B, -1)
+        ids1, ids2, n1, n2 = self._teacher_ids(batch, B)
+        zh_in = torch.cat([ids, ids_u])
+        t1_in = torch.cat([_to_device(ids1, dev), _to_device(n1, dev)])
+        t2_in = torch.cat([_to_device(ids2, dev), _to_device(n2, dev)])
+        towers = ((self.zh.encode_text, zh_in, {}), (self.te1.encode, t1_in, {"hidden_index": -2}),
+                  (self.te2.encode, t2_in, {"hidden_index": -2}))
+        side = self.concurrent_towers and torch.device(dev).type == "cuda"
+        outs = [None, None, None]
+        if side:
+            if self.drain_before_enqueue:
+                torch.cuda.current_stream(dev).synchronize()
+            if self._tower_streams is None:
+                n = max(1, min(len(towers), int(self.tower_streams)))
+                self._tower_streams = [torch.cuda.Stream(device=dev, priority=-1) for _ in range(n)]
+            main = torch.cuda.current_stream(dev)
+            fork = torch.cuda.Event()
+            fork.record(main)
+        # the VAE's ~60 launches are enqueued first: the GPU works on them while the host enqueues the towers' ~800
         latents = self.vae.encode_latents(px, noise=batch.get("_vae_noise"), generator=generator)       # :306-309
+        if side:
+            for st in self._tower_streams:
+                st.wait_event(fork)
+            for i, (fn, arg, kw) in enumerate(towers):
+                with torch.cuda.stream(self._tower_streams[i % len(self._tower_streams)]):
+                    outs[i] = fn(arg, **kw)
         if "_noise" in batch:
             noise = batch["_noise"].to(dev, torch.float32)
         else:
@@ -88,16 +178,21 @@ class PEAFrontEnd:
                 noise = noise + self.noise_offset * torch.randn(B, latents.shape[1], 1, 1, device=dev, generator=generator)
         t = batch["_timesteps"].to(dev) if "_timesteps" in batch else \
             torch.randint(0, self.T, (B,), device=dev, generator=generator)                             # :318-319
-        ids = batch["input_ids"].to(dev)
-        ids_u = batch["input_ids_uncond"].to(dev)
-        if ids_u.shape[0] != B:
-            ids_u = ids_u.expand(B, -1)
-        enc2, _ = self.zh.encode_text(torch.cat([ids, ids_u]))                                          # :327-329
-        ids1, ids2, n1, n2 = self._teacher_ids(batch, B)
-        pe, npe, pooled = self.encode_prompt(ids1.to(dev), ids2.to(dev), n1.to(dev), n2.to(dev))        # :410
+        if side:
+            for st in self._tower_streams:
+                main.wait_stream(st)
+            # The tower outputs were allocated on the side streams and are consumed on `main`.  They stay referenced until
+            # the next call: their memory then returns to the side streams' pools, whose next use is ordered behind that
+            # call's fork event, i.e. behind every consumer enqueued on `main` (what record_stream would arrange through
+            # the allocator's event polling).
+            self._tower_outs = outs
+        else:
+            outs = [fn(arg, **kw) for fn, arg, kw in towers]
+        (enc2, _), (h1, _), (h2, pooled) = outs                                                         # :327-329, :410
+        pe_all = torch.cat([h1, h2], -1)
+        pe, npe, pooled = pe_all[:B], pe_all[B:], pooled[:B]
         pm = batch["_prompt_mask"].to(dev) if "_prompt_mask" in batch else \
             (torch.rand(B, device=dev, generator=generator) < self.uncond)                              # :392-394
         return {"latents": latents, "noise": noise, "timesteps": t, "enc": enc2[:B], "enc_uncond": enc2[B:],
-                "prompt_mask": pm, "zh_or_not": torch.as_tensor(batch["zh_or_not"]).to(dev),
-                "teacher_ehs": pe, "teacher_neg": npe, "teacher_pooled": pooled,
-                "time_ids": add_time_ids_from_batch(batch, dev, self.buckets)}
+                "prompt_mask": pm, "zh_or_not": zh_or_not,
+                "teacher_ehs": pe, "teacher_neg": npe, "teacher_pooled": pooled, "time_ids": time_ids}

@@ -8,6 +8,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from pea_diffusion_amd import config as pc
 from pea_diffusion_amd.adapter import PEAAdapter
+from pea_diffusion_amd.frontend import PEAFrontEnd
 from pea_diffusion_amd.text import HipTextEncoder
 from pea_diffusion_amd.train import PEATrainer
 from pea_diffusion_amd.unet import HipUNet
@@ -30,68 +31,42 @@ te2 = HipTextEncoder(pc.openclip_bigg_config(), 2 * B, 77); te2.init_random(3)
 zh = HipTextEncoder(pc.cnclip_bert_large_config(), 2 * B, L); zh.init_random(4)   # ids | unconditional ids
 g = torch.Generator().manual_seed(0)
 pixels = torch.randn(B, 3, 1024, 1024, generator=g).clamp_(-1, 1).to(dev)
-ids_t = torch.randint(0, 49000, (2 * B, 77), generator=g); ids_t[:, 0] = 49406; ids_t[:, 20:] = 49407
-ids_t = ids_t.to(dev)
-ids_z = torch.randint(1, 21000, (2 * B, L), generator=g); ids_z[:, 30:] = 0
-ids_z = ids_z.to(dev)
-time_ids = torch.tensor([[1024, 1024, 0, 0, 1024, 1024]] * B).to(dev)
+ids_t = torch.randint(0, 49000, (B, 77), generator=g); ids_t[:, 0] = 49406; ids_t[:, 20:] = 49407
+neg_t = torch.full((B, 77), 49407); neg_t[:, 0] = 49406
+ids_z = torch.randint(1, 21000, (B, L), generator=g); ids_z[:, 30:] = 0
+unc_z = torch.zeros(1, L, dtype=torch.int64); unc_z[:, 0] = 101; unc_z[:, 1] = 102
+# the dataloader's dictionary (utils/custom_dataset_sdxl.py:397-407), English prompts pre-tokenised
+batch = {"pixel_values": pixels, "input_ids": ids_z.to(dev), "input_ids_uncond": unc_z.to(dev),
+         "original_size": [(1024, 1024)] * B, "crops_coords_top_left": [(0, 0)] * B, "bucket_id": [0] * B,
+         "zh_or_not": [1] * B, "texts_en_ids": (ids_t.to(dev), ids_t.to(dev)), "neg_en_ids": (neg_t.to(dev), neg_t.to(dev))}
+fe = PEAFrontEnd(vae, te1, te2, zh)
+trainer.attach_frontend(fe)
 
 def step():
-    latents = vae.encode_latents(pixels)                                                      # :306-309
-    noise = torch.randn_like(latents) + 0.5 * torch.randn(B, 4, 1, 1, device=dev)             # :311-315 (noise_offset)
-    t = torch.randint(0, 1000, (B,), device=dev)
-    h1, _ = te1.encode(ids_t, hidden_index=-2)
-    h2, pooled = te2.encode(ids_t, hidden_index=-2)
-    pe = torch.cat([h1, h2], -1)                                                              # [2B, 77, 2048]
-    enc, _ = zh.encode_text(ids_z)                                                            # [2B, L, 1024]
-    batch = {"latents": latents, "noise": noise, "timesteps": t, "enc": enc[:B], "enc_uncond": enc[B:],
-             "prompt_mask": torch.rand(B, device=dev) < 0.1, "zh_or_not": torch.randint(0, 2, (B,), device=dev),
-             "teacher_ehs": pe[:B], "teacher_neg": pe[B:], "teacher_pooled": pooled[:B], "time_ids": time_ids}
-    out = trainer.training_step(batch)
+    out = trainer.training_step_from_batch(batch)
     trainer.optimizer_step()
     return out
 
-for _ in range(2): step()
-torch.cuda.synchronize()
-t0 = time.perf_counter()
-for _ in range(a.steps): out = step()
-torch.cuda.synchronize()
-dt = (time.perf_counter() - t0) / a.steps
-# the front end alone
-torch.cuda.synchronize(); t1 = time.perf_counter()
-for _ in range(a.steps):
-    vae.encode_latents(pixels); te1.encode(ids_t); te2.encode(ids_t); zh.encode_text(ids_z)
-torch.cuda.synchronize()
-fe = (time.perf_counter() - t1) / a.steps
-# the same with the frozen front end of the NEXT batch on a side HIP stream, overlapped with this batch's step
-side = torch.cuda.Stream()
-def front():
-    latents = vae.encode_latents(pixels)
-    h1, _ = te1.encode(ids_t, hidden_index=-2)
-    h2, pooled = te2.encode(ids_t, hidden_index=-2)
-    enc, _ = zh.encode_text(ids_z)
-    return latents, torch.cat([h1, h2], -1), pooled, enc
-def step_overlapped(cur):
-    side.wait_stream(torch.cuda.current_stream())
-    with torch.cuda.stream(side):
-        nxt = front()
-    latents, pe, pooled, enc = cur
-    noise = torch.randn_like(latents) + 0.5 * torch.randn(B, 4, 1, 1, device=dev)
-    t = torch.randint(0, 1000, (B,), device=dev)
-    batch = {"latents": latents, "noise": noise, "timesteps": t, "enc": enc[:B], "enc_uncond": enc[B:],
-             "prompt_mask": torch.rand(B, device=dev) < 0.1, "zh_or_not": torch.randint(0, 2, (B,), device=dev),
-             "teacher_ehs": pe[:B], "teacher_neg": pe[B:], "teacher_pooled": pooled[:B], "time_ids": time_ids}
-    trainer.training_step(batch)
-    trainer.optimizer_step()
-    torch.cuda.current_stream().wait_stream(side)
-    return nxt
-cur = front()
-for _ in range(2): cur = step_overlapped(cur)
-torch.cuda.synchronize(); t2 = time.perf_counter()
-for _ in range(a.steps): cur = step_overlapped(cur)
-torch.cuda.synchronize()
-ov = (time.perf_counter() - t2) / a.steps
-print(f"front end of the next batch on a side stream: {ov*1e3:.1f} ms/step = {B/ov:.2f} images/s")
-print(f"full reference training_step incl. VAE encode + 3 text encoders, SDXL 1024x1024, batch {B}, ctx {L}: "
-      f"{dt*1e3:.1f} ms/step = {B/dt:.2f} images/s (loss {float(out['loss']):.4f}); frozen front end alone {fe*1e3:.1f} ms "
-      f"(VAE + CLIP-L + OpenCLIP-bigG on 2B prompts + BERT-large on 2B prompts)")
+def timed(f, n):
+    for _ in range(2): f()
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(n): r = f()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / n, r
+
+import pea_diffusion_amd.frontend as fmod
+res = {}
+combos = [(False, False, True), (True, False, True), (True, True, True)]
+for conc, drain, acopy in combos:   # towers on their own streams / host drains first / pinned-ring copies
+    fe.concurrent_towers, fe.drain_before_enqueue, fmod.ASYNC_COPIES = conc, drain, acopy
+    dt, out = timed(step, a.steps)
+    fd, _ = timed(lambda: fe.prepare(batch), a.steps)
+    print(f"towers on their own streams={conc} host drains the stream first={drain}: step {dt*1e3:.1f} ms, front end alone {fd*1e3:.1f} ms", flush=True)
+    res[conc] = (dt, fd, float(out["loss"]))
+fe.concurrent_towers, fe.drain_before_enqueue, fmod.ASYNC_COPIES = True, True, True
+for conc in (True, False):
+    dt, fd, loss = res[conc]
+    print(f"full reference training_step (PEATrainer.training_step_from_batch: VAE encode + 3 text encoders + KD step + AdamW), SDXL "
+          f"1024x1024, batch {B}, ctx {L}, text towers {'on their own streams' if conc else 'on the VAE stream'}: {dt*1e3:.1f} ms/step = "
+          f"{B/dt:.2f} images/s (loss {loss:.4f}); frozen front end alone {fd*1e3:.1f} ms (VAE + CLIP-L + OpenCLIP-bigG on 2B prompts "
+          f"+ BERT-large on 2B prompts)")
