@@ -102,3 +102,13 @@ def test_training_step_from_reference_batch_dict(gpu):
     plain = {k: v for k, v in batch.items() if not k.startswith("_")}
     out2 = tr.training_step_from_batch(plain, 1, generator=torch.Generator(device="cuda").manual_seed(1), sync=True)
     assert torch.isfinite(out2["loss"]).item()
+    # the text towers on their own streams (default) and on the VAE's stream give the same post-encoder batch, bit for bit
+    fe = tr.frontend
+    prepared = {}
+    for conc in (True, False):
+        fe.concurrent_towers = conc
+        prepared[conc] = fe.prepare(batch)
+        torch.cuda.synchronize()
+    fe.concurrent_towers = True
+    for k, v in prepared[True].items():
+        assert torch.equal(v, prepared[False][k]), f"front end output '{k}' differs between concurrent and serial towers"
