@@ -500,14 +500,27 @@ __global__ void colsum_batched_kernel(const bf16* __restrict__ x, float* __restr
     partial[((long long)b * gridDim.x + blockIdx.x) * C + c] = a;
   }
 }
-__global__ void colsum_batched_reduce_kernel(const float* __restrict__ partial, float* __restrict__ out, int nblk,
-                                             int C, int ldo) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+// second stage: a block owns 64 columns of one sample; its 16 waves take the block partials round-robin and their sums are
+// added in wave order (deterministic).  One thread per column walked the up to 171 partials serially (25 us per launch).
+__global__ __launch_bounds__(1024) void colsum_batched_reduce_kernel(const float* __restrict__ partial, float* __restrict__ out,
+                                                                     int nblk, int C, int ldo) {
+  __shared__ float part[16][64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + lane;
   const int b = blockIdx.y;
-  if (c >= C) return;
   float a = 0.f;
-  for (int k = 0; k < nblk; ++k) a += partial[((long long)b * nblk + k) * C + c];
-  out[(long long)b * ldo + c] = a;
+  if (c < C) {
+#pragma unroll 4
+    for (int k = w; k < nblk; k += 16) a += partial[((long long)b * nblk + k) * C + c];
+  }
+  part[w][lane] = a;
+  __syncthreads();
+  if (w == 0 && c < C) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t += part[k][lane];
+    out[(long long)b * ldo + c] = t;
+  }
 }
 static void colsum_geometry(int HW, int C, int* threads, int* per, int* nblk) {
   const int nchunk = C / 8;
@@ -533,7 +546,7 @@ int launch_colsum_batched(const bf16* x, float* out, int B, int HW, int C, int l
   PROF_BEGIN(6, 0.0, 2.0 * B * (double)HW * C, s);
   hipLaunchKernelGGL(colsum_batched_kernel, dim3(nblk, B), dim3(threads), (size_t)ppb * C * 4, s, x, scratch, HW, C,
                      per);
-  hipLaunchKernelGGL(colsum_batched_reduce_kernel, dim3(cdiv(C, 64), B), dim3(64), 0, s, scratch, out, nblk, C, ldo);
+  hipLaunchKernelGGL(colsum_batched_reduce_kernel, dim3(cdiv(C, 64), B), dim3(1024), 0, s, scratch, out, nblk, C, ldo);
   PROF_END(s);
   HIPCHK(hipGetLastError());
   return PEA_OK;
