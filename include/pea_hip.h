@@ -47,6 +47,14 @@ int pea_op_gemm(const void* A, int lda, const void* W, int ldw, void* C, int ldc
                 const float* bias, const void* rowvec, int ldrv, int rows_per_batch, int act, void* preact,
                 int ldpre, const void* res, int ldres, int out_f32, int accum_f32, void* stream);
 
+/* The data-gradient GEMM of the FF output projection with the GEGLU backward in its epilogue (diffusers GEGLU:
+ * y = h * gelu(gate); train_sdxl_zh.py's student backward runs it in every transformer block):
+ *   dy = A[M][K] . W[N][K]^T;  pre[m][2n] = h, pre[m][2n+1] = gate (the stash of the forward);
+ *   C[m][2n] = dy * gelu(gate),  C[m][2n+1] = dy * h * gelu'(gate)      (C: bf16 [M][2N], ldc >= 2N)
+ * dy itself is never stored.  K % 64 == 0, N % 16 == 0, ldc % 8 == 0, ldpre % 8 == 0.                              */
+int pea_op_gemm_geglu_bwd(const void* A, int lda, const void* W, int ldw, const void* pre, int ldpre, void* C, int ldc,
+                          int M, int N, int K, void* stream);
+
 /* LayerNorm folded into the Linear that consumes it (UNet transformer blocks: norm1 -> to_q|k|v, norm2 -> attn2.to_q,
  * norm3 -> ff.net.0.proj):  y = LN(x; gamma, beta, eps) . W^T + bias  computed as  rstd (x . W'^T - mean s) + t  with
  * W' = W . gamma, s[n] = sum_k W'[n][k], t[n] = sum_k beta[k] W[n][k] + bias[n] -- one statistics pass over x and one

@@ -47,6 +47,16 @@ int pea_op_gemm(const void* A, int lda, const void* W, int ldw, void* C, int ldc
   return launch_gemm(p, (hipStream_t)stream);
 }
 
+int pea_op_gemm_geglu_bwd(const void* A, int lda, const void* W, int ldw, const void* pre, int ldpre, void* C, int ldc,
+                          int M, int N, int K, void* stream) {
+  GemmP p;
+  memset(&p, 0, sizeof(p));
+  p.A = (const bf16*)A; p.lda = lda; p.W = (const bf16*)W; p.ldw = ldw; p.C = C; p.ldc = ldc;
+  p.M = M; p.N = N; p.K = K; p.alpha = 1.f; p.rows_per_batch = 1;
+  p.gbwd_pre = (const bf16*)pre; p.ldgp = ldpre;
+  return launch_gemm(p, (hipStream_t)stream);
+}
+
 int pea_op_ln_linear(const void* x, const float* gamma, const float* beta, const void* W, const float* bias, void* y,
                      void* geglu_y, int M, int N, int K, float eps, void* Wf, float* svec, float* tvec, float* stats,
                      void* stream) {

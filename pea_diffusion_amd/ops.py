@@ -34,6 +34,17 @@ def gemm(a, w, bias=None, rowvec=None, rows_per_batch=1, act=0, res=None, want_p
     return (out, pre) if want_preact else out
 
 
+def gemm_geglu_bwd(a, w, pre):
+    """dgrad GEMM of the FF output projection with the GEGLU backward in its epilogue (pea_op_gemm_geglu_bwd):
+    dy = a @ w.T ([M,N], never stored); pre [M,2N] interleaved (h, gate) -> d(pre) [M,2N] interleaved (dh, dgate)."""
+    M, K = a.shape
+    N = w.shape[0]
+    out = torch.empty(M, 2 * N, device=a.device, dtype=BF)
+    check(lib().pea_op_gemm_geglu_bwd(ptr(a), a.stride(0), ptr(w), w.stride(0), ptr(pre), pre.stride(0), ptr(out), out.stride(0),
+                                      M, N, K, stream_ptr()))
+    return out
+
+
 def ln_linear(x, gamma, beta, w, bias=None, eps=1e-5, geglu=False):
     """LayerNorm folded into its consuming Linear (pea_op_ln_linear): x [M,K] bf16, w [N,K] bf16 -> LN(x) @ w.T + bias.
     geglu=True: w rows interleaved (h_i, gate_i); returns (h * gelu(gate) [M,N/2], pre-activation [M,N])."""

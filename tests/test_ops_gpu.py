@@ -226,6 +226,24 @@ def test_conv_in_out(ops):
     close_bf16("conv_out dgrad", ops.conv_out_dgrad(dy.cuda(), wp, C), _nhwc(hh.grad))
 
 
+@pytest.mark.parametrize("M,N,K", [(4096, 5120, 1280), (2048, 2560, 640), (384, 1280, 320), (1000, 5120, 1280)])
+def test_gemm_with_geglu_backward_epilogue(ops, M, N, K):
+    """The FF output projection's dgrad with the GEGLU backward in its epilogue (d y never stored) against fp32 torch:
+    the three tile instantiations (256x160 persistent at 512 tiles, 128x160, 64x160) and a ragged row count."""
+    g = torch.Generator().manual_seed(M + N)
+    a = (torch.randn(M, K, generator=g) * 0.5).to(BF)
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).to(BF)
+    pre = (torch.randn(M, 2 * N, generator=g) * 1.2).to(BF)
+    got = ops.gemm_geglu_bwd(a.cuda(), w.cuda(), pre.cuda())
+    dy = a.float() @ w.float().t()
+    h, gate = pre.float()[:, 0::2], pre.float()[:, 1::2]
+    phi = 0.5 * (1.0 + torch.erf(gate / 2 ** 0.5))
+    dh = dy * gate * phi
+    dg = dy * h * (phi + gate * torch.exp(-0.5 * gate * gate) / (2 * torch.pi) ** 0.5)
+    ref = torch.stack([dh, dg], -1).reshape(M, 2 * N)
+    close_bf16(f"gemm + geglu bwd {M}x{N}x{K}", got, ref)
+
+
 @pytest.mark.parametrize("B,H,W,C,Cout", [(2, 32, 32, 320, 4), (1, 12, 20, 128, 3), (3, 8, 24, 512, 8), (1, 40, 40, 64, 4),
                                           (2, 16, 16, 72, 4)])
 def test_conv_out_shapes(ops, B, H, W, C, Cout):
