@@ -77,9 +77,12 @@ def _fast_fill_(module):
                 p.zero_()
 
 
-def cpu_baseline_worker(model_name, budget_s):
+def cpu_baseline_worker(model_name, budget_s, faithful=False):
     """The CPU oracle (oracle/*.py, the restatement of the reference's PyTorch path) timed on this box's
-    host cores: one KD step at batch 1 (teacher fwd no_grad + student fwd + adapter-only backward)."""
+    host cores: one KD step at batch 1 (teacher fwd no_grad + student fwd + adapter-only backward).
+    `faithful`: additionally the step with the student UNet left trainable, as the reference leaves it
+    (train_sdxl_zh.py:138,166-168: only proj is optimised, but unet.requires_grad stays True, so autograd also
+    produces 2.57 B weight gradients nobody reads)."""
     from oracle.step_ref import AdapterRef, synthetic_batch as sb, training_step_ref
     from oracle.unet_ref import UNet2DConditionRef, cast_hook_ref, sdxl_config, tiny_config
     try:
@@ -111,25 +114,43 @@ def cpu_baseline_worker(model_name, budget_s):
         del out
         if hw != 128 and runs[hw] * 5.5 > budget_s:    # the metric's resolution costs ~4.4-5x the 512 px step
             break
+    faithful_s = None
+    if faithful:
+        import copy
+        hwf = max(runs)
+        stu = copy.deepcopy(unet)                 # the reference holds two copies (unet, unet_teacher)
+        for p in stu.parameters():
+            p.requires_grad_(True)
+        batch = sb(cfg, 1, L=77, enc_dim=enc_dim, seed=0, latent_hw=hwf)
+        t1 = time.time()
+        out = training_step_ref(ad, stu, unet, batch, cast_hook_ref)
+        out["loss"].backward()
+        faithful_s = {"px": hwf * 8, "seconds": round(time.time() - t1, 2),
+                      "unet_wgrad_populated": all(p.grad is not None for p in stu.parameters())}
+        del out, stu
     hw = max(runs)
     dt = runs[hw]
     full = hw == 128 or model_name != "sdxl"
     # value: images/s of the METRIC's workload (1024 px), measured directly -- one whole KD step at batch 1.  Only when
     # the time budget forbids the 1024 px step is the 512 px step reported (value stays null then: no extrapolation).
-    res = {"value": round(1.0 / dt, 5) if full else None, "unit": "images/s", "cores": threads, "kind": "port",
+    res = {"value": round(1.0 / dt, 5) if full else None, "unit": "images/s", "cores": threads,
+           "box_cores": os.cpu_count(), "kind": "port",
            "sample": f"1 KD step (teacher fwd no_grad + student fwd + adapter-only backward), batch 1, {hw * 8}x{hw * 8} px "
                      f"(latent {hw}x{hw}), fp32 torch CPU oracle, teacher==student weights, {dt:.1f} s wall "
                      f"(model build {build_s:.0f} s not counted)" + ("" if full else "; 1024 px step skipped: over the CPU budget"),
            "value_512px": (round(1.0 / runs[64], 5) if 64 in runs else None),
            "seconds": {f"{k * 8}px": round(v, 2) for k, v in runs.items()}}
+    if faithful_s is not None:
+        res["reference_faithful"] = dict(faithful_s, value=round(1.0 / faithful_s["seconds"], 5),
+                                         note="student UNet trainable as in the reference: adapter + 2.57 B unused UNet wgrads")
     print("CPU_BASELINE_JSON " + json.dumps(res), flush=True)
 
 
-def cpu_baseline(model_name, budget_s):
+def cpu_baseline(model_name, budget_s, faithful=False):
     """runs the worker in a child process with a hard time limit, so the bench line is always printed"""
     import subprocess
     cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-worker", "--model", model_name,
-           "--cpu-budget", str(budget_s)]
+           "--cpu-budget", str(budget_s)] + (["--cpu-reference-faithful"] if faithful else [])
     try:
         r = subprocess.run(cmd, capture_output=True, text=True, timeout=budget_s * 1.5 + 240)
     except subprocess.TimeoutExpired:
@@ -150,31 +171,56 @@ def _free_port():
     return port
 
 
-def launch_ranks(n, argv):
+def launch_ranks(n, argv, timeout_s):
     """Start `n` ranks of this script as fresh child processes (one per GPU; RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*
-    set as torch.distributed.run would), relay rank 0's single JSON line, return non-zero if any rank fails.  The
-    parent never initialises the GPU and never re-executes itself (train_sdxl_zh.sh:108-114 is the reference's launcher)."""
+    set as torch.distributed.run would), relay rank 0's single JSON line, return non-zero if any rank fails or the
+    deadline passes (a rank stuck in a collective never exits by itself).  Every rank's stderr (and the stdout of
+    ranks > 0) goes to a file of its own whose tail is printed when something goes wrong.  The parent never
+    initialises the GPU and never re-executes itself (train_sdxl_zh.sh:108-114 is the reference's launcher)."""
     import subprocess
+    import tempfile
     port = _free_port()
-    procs = []
+    logdir = tempfile.mkdtemp(prefix="pea_bench_ranks_")
+    procs, logs = [], []
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC (RCCL across processes on this host driver)
+        err = open(os.path.join(logdir, f"rank{r}.err"), "wb")
+        out = subprocess.PIPE if r == 0 else open(os.path.join(logdir, f"rank{r}.out"), "wb")
+        logs.append(err.name)
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+                                      stdout=out, stderr=err))
     import threading
     out = []
     rd = threading.Thread(target=lambda: out.append(procs[0].stdout.read()), daemon=True)
     rd.start()
+
+    def tails(which):
+        for r in which:
+            try:
+                data = open(logs[r], "rb").read()[-1500:].decode(errors="replace")
+            except OSError:
+                data = ""
+            print(f"---- rank {r} stderr tail ({logs[r]}) ----\n{data}", file=sys.stderr)
+
     rc = 0
+    deadline = time.time() + timeout_s
     while any(p.poll() is None for p in procs):
-        failed = [p for p in procs if p.poll() not in (None, 0)]
-        if failed:                          # a dead rank leaves the others waiting in a collective: stop exactly those
-            rc = failed[0].returncode or 1
-            for p in procs:
-                if p.poll() is None:
-                    p.kill()
+        failed = [i for i, p in enumerate(procs) if p.poll() not in (None, 0)]
+        hung = time.time() > deadline
+        if failed or hung:                  # a dead rank leaves the others waiting in a collective: stop exactly those
+            alive = [i for i, p in enumerate(procs) if p.poll() is None]
+            if hung and not failed:
+                rc = 124
+                print(f"bench.py: deadline of {timeout_s:.0f} s passed; ranks still running: {alive}", file=sys.stderr)
+                tails(alive)
+            else:
+                rc = procs[failed[0]].returncode or 1
+                print(f"bench.py: rank(s) {failed} exited with {rc}; stopping ranks {alive}", file=sys.stderr)
+                tails(failed)
+            for i in alive:
+                procs[i].kill()             # exactly the children started above
             break
         time.sleep(0.2)
     for p in procs:
@@ -189,13 +235,102 @@ def launch_ranks(n, argv):
     elif rc == 0:
         rc = 1
         print("bench.py: rank 0 produced no result line", file=sys.stderr)
+        tails([0])
+    if rc == 0:
+        import shutil
+        shutil.rmtree(logdir, ignore_errors=True)
     return rc
+
+
+class GpuSampler:
+    """sclk / board power of this rank's GPU, sampled from sysfs while the timed steps run (explains box-to-box spread of
+    the same build; informational: the clock an MFMA loop holds in-kernel is up to 10 % under pp_dpm_sclk)."""
+
+    def __init__(self, index):
+        import glob
+        import threading
+        cards = sorted(d for d in glob.glob("/sys/class/drm/card[0-9]*/device") if os.path.exists(d + "/pp_dpm_sclk"))
+        self.dev = cards[index] if index < len(cards) else None
+        self.sclk, self.power = [], []
+        self._stop = threading.Event()
+        self._t = threading.Thread(target=self._run, daemon=True)
+
+    def _read(self):
+        try:
+            for ln in open(self.dev + "/pp_dpm_sclk"):
+                if "*" in ln:
+                    self.sclk.append(int("".join(c for c in ln.split(":")[1] if c.isdigit())))
+        except Exception:
+            pass
+        try:
+            import glob
+            for f in glob.glob(self.dev + "/hwmon/hwmon*/power1_average") + glob.glob(self.dev + "/hwmon/hwmon*/power1_input"):
+                self.power.append(int(open(f).read()) / 1e6)
+                break
+        except Exception:
+            pass
+
+    def _run(self):
+        while not self._stop.is_set():
+            self._read()
+            self._stop.wait(0.05)
+
+    def __enter__(self):
+        if self.dev:
+            self._t.start()
+        return self
+
+    def __exit__(self, *a):
+        self._stop.set()
+        if self.dev:
+            self._t.join(timeout=1)
+
+    def summary(self):
+        med = lambda v: sorted(v)[len(v) // 2] if v else None
+        return {"sclk_mhz_median": med(self.sclk), "sclk_mhz_min": min(self.sclk) if self.sclk else None,
+                "power_w_median": med(self.power), "power_w_max": max(self.power) if self.power else None,
+                "samples": len(self.sclk), "source": "sysfs pp_dpm_sclk / hwmon power1_average, 50 ms period, timed region only"}
+
+
+def run_protocol(args, rank, world, step, barrier, allreduce_max, sampler=None):
+    """The contract's timing protocol, shared by the GPU run and the CPU dry run: W untimed steps, barrier, EXACTLY K
+    timed steps, barrier, MAX over ranks.  `step(i)` returns an object with .elapsed_time() semantics or None."""
+    for i in range(args.warmup):
+        step(None)
+    barrier()
+    marks = []
+    t0 = time.perf_counter()
+    if sampler is not None:
+        sampler.__enter__()
+    for i in range(args.steps):
+        step(marks)
+    barrier()
+    dt = time.perf_counter() - t0
+    if sampler is not None:
+        sampler.__exit__()
+    return allreduce_max(dt), marks
+
+
+def after_timing(args, rank, world, step, instrument, barrier):
+    """What follows the timed region on EVERY rank, in the same order on every rank (a step contains the gradient
+    all-reduce, so a rank that skipped the instrumented replay would leave the others waiting in it): the per-kernel
+    replay, then -- rank 0, one GPU only -- the CPU baseline, then the closing barrier."""
+    roof = None
+    if not args.no_roofline:
+        roof = instrument(step)                  # all ranks replay; only rank 0 keeps the report
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(args.model, args.cpu_budget, args.cpu_reference_faithful)
+    barrier()
+    return (roof if rank == 0 else None), cpu
 
 
 def dry_run_collective(args, rank, world, json_fd):
     """Host-logic check of the N-rank path without a GPU (tests/test_dp_cpu.py): rendezvous over gloo, shard a global
-    batch, ONE all-reduce-mean of a flat buffer through pea_diffusion_amd.dist, barrier, max-over-ranks timing, one
-    JSON line from rank 0.  NOT a benchmark: no kernel of the product runs here."""
+    batch, then the SAME control flow as the GPU run -- run_protocol() (warm-up, barrier, K steps each ending in ONE
+    all-reduce-mean of a flat buffer through pea_diffusion_amd.dist, barrier, max over ranks), after_timing() (the
+    instrumented replay on every rank, closing barrier) -- and one JSON line from rank 0.  NOT a benchmark: no kernel of
+    the product runs here."""
     import torch.distributed as dist
     from pea_diffusion_amd import dist as pdist
     if world > 1:
@@ -205,33 +340,74 @@ def dry_run_collective(args, rank, world, json_fd):
     glob = torch.randn(world * B, 16, generator=g)                         # every rank builds the same global batch
     mine = pdist.shard_batch({"x": glob}, rank, world)["x"]
     flat = mine.sum(0).repeat(64).contiguous()                             # this rank's "gradient"
-    t0 = time.perf_counter()
-    for _ in range(max(1, args.steps)):
+    last = [None]
+    count = [0]
+
+    def step(marks):
         f = flat.clone()
         pdist.allreduce_mean_(f)
-    if world > 1:
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    tmax = torch.tensor([dt], dtype=torch.float64)
-    if world > 1:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        last[0] = f
+        count[0] += 1
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    def allreduce_max(dt):
+        t = torch.tensor([dt], dtype=torch.float64)
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def instrument(step_fn):
+        for _ in range(min(args.steps, 3)):
+            step_fn(None)
+        return {"replayed_steps": min(args.steps, 3)}
+
+    args.no_cpu_baseline = True
+    tmax, _ = run_protocol(args, rank, world, step, barrier, allreduce_max)
+    roof, _ = after_timing(args, rank, world, step, instrument, barrier)
     want = glob.view(world, B, 16).sum(1).mean(0).repeat(64)
-    err = float((f - want).abs().max())
+    err = float((last[0] - want).abs().max())
     if world > 1:
-        dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
         out = {"metric": "launcher dry run (no kernels; not a benchmark)", "value": None, "unit": None, "n_gpus": world,
                "ranks": world, "global_batch": world * B, "per_gpu_batch": B, "allreduce_max_abs_err": err,
-               "seconds_max_over_ranks": float(tmax.item()), "dry_run": True}
+               "seconds_max_over_ranks": tmax, "dry_run": True, "steps_run_per_rank": count[0],
+               "replay": roof}
         os.write(json_fd, (json.dumps(out) + "\n").encode())
+
+
+FAMILY_BOUND = {"gemm_lc[p]_kernel<plain>": "mfma", "gemm_lc[p]_kernel<conv3x3>": "mfma", "attn_fwd": "mfma",
+                "attn_bwd": "mfma", "groupnorm": "hbm", "layernorm": "hbm", "elementwise": "hbm", "kd_loss": "hbm"}
+
+
+def family_rooflines(fams, nprof):
+    """north_star: 'achieved fraction of MFMA and HBM roofline per kernel' -- one entry per kernel family from the
+    HIP-event replay: algorithmic FLOPs (MFMA-bound families) or algorithmic bytes (HBM-bound) over the summed launch
+    durations, against 2.5 PFLOP/s dense bf16 / 8 TB/s."""
+    out = []
+    for x in fams:
+        if not x["launches"]:
+            continue
+        bound = FAMILY_BOUND.get(x["name"], "hbm")
+        sec = x["ms"] * 1e-3
+        if bound == "mfma":
+            ach, peak, unit = x["flops"] / sec / 1e12, MFMA_PEAK_TFLOPS, "TFLOP/s"
+        else:
+            ach, peak, unit = x["bytes"] / sec / 1e9, HBM_PEAK_GBS, "GB/s"
+        out.append({"family": x["name"], "bound": bound, "ms_per_step": round(x["ms"] / nprof, 3),
+                    "launches_per_step": x["launches"] // nprof, "achieved": round(ach, 1), "peak": peak, "unit": unit,
+                    "frac": round(ach / peak, 4)})
+    return out
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=8)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=0,
                     help="per-GPU batch; default 4 at --gpus 1 (BASELINE configs[1]) and 8 at --gpus N>1 (configs[2]: 8 x 8 = 64)")
     ap.add_argument("--collective", default="native", choices=["native", "torch"],
@@ -244,8 +420,11 @@ def main():
     ap.add_argument("--hidden", type=int, default=1024, help="adapter hidden dim (1024 = the 6M-param adapter)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=400.0,
-                    help="seconds the CPU-oracle leg may take for the metric's 1024 px step (measured: 70-90 s on the box)")
+                    help="seconds the CPU-oracle leg may take for the metric's 1024 px step (measured: 55-90 s on the box)")
     ap.add_argument("--cpu-baseline-worker", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--cpu-reference-faithful", action="store_true",
+                    help="also time the CPU step with the student UNet left trainable as the reference leaves it "
+                         "(train_sdxl_zh.py:166-168: 2.57 B unused weight gradients); one-off, recorded under profiles/")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--force-collective", action="store_true", help="init RCCL and all-reduce even with one rank (path test)")
     ap.add_argument("--dump-prof", default="", help="write every profiled launch (shape-tagged) to this CSV")
@@ -253,19 +432,24 @@ def main():
     ap.add_argument("--student", default="same", choices=["same", "ssd1b"],
                     help="BASELINE config 4: a smaller student UNet (SSD-1B-shaped, own weights) under the SDXL teacher")
     ap.add_argument("--with-vae", action="store_true",
-                    help="also run the NEXT batch's VAE encode (train_sdxl_zh.py:306-309, 1024x1024 pixels) on a side "
-                         "HIP stream inside every step; not the default: BASELINE's metric starts from latents (SURVEY 8d)")
+                    help="also run a later batch's VAE encode (train_sdxl_zh.py:306-309, 1024x1024 pixels) on a side HIP "
+                         "stream, enqueued between training_step and optimizer_step so that it overlaps the gradient "
+                         "all-reduce; not the default: BASELINE's metric starts from latents (SURVEY 8d)")
     ap.add_argument("--single-stream", action="store_true", help="analysis only: teacher and student passes on ONE stream")
+    ap.add_argument("--launch-timeout", type=float, default=0.0,
+                    help="seconds the self-launched ranks (--gpus N without torch.distributed.run) may take in all; "
+                         "default 900 + 2 s per step")
     args = ap.parse_args()
     if args.cpu_baseline_worker:
-        cpu_baseline_worker(args.model, args.cpu_budget)
+        cpu_baseline_worker(args.model, args.cpu_budget, args.cpu_reference_faithful)
         return
 
     world_env = os.environ.get("WORLD_SIZE")
     if args.gpus > 1 and world_env is None:
         # `python bench.py --gpus N` without torch.distributed.run: start the N ranks here.  Nothing in this process has
         # touched the GPU (importing torch does not), and it never does: it only waits and relays rank 0's line.
-        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:],
+                              args.launch_timeout or 900.0 + 2.0 * (args.steps + args.warmup)))
     world = int(world_env or "1")
     if world != args.gpus:
         print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch `python -m torch.distributed.run --nproc-per-node "
@@ -345,59 +529,57 @@ def main():
         vae.init_random(seed=11)
         pixels = torch.randn(B, 3, hw * 8, hw * 8, device=dev).clamp_(-1, 1)
         side = torch.cuda.Stream(device=dev)
-        next_latents = [None]
+        encoded = []                         # (latents, event): encodes in flight, oldest first
 
-    def step():
-        if vae is not None:                   # next batch's latents on the side stream, overlapped with this step
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):
-                next_latents[0] = vae.encode_latents(pixels)
-        trainer.training_step(batch)          # ends by LAUNCHING the all-reduce of the flat adapter grad (comm stream)
+    def step(marks):
+        """one step in the order of INTEGRATION.md's data-parallel loop: KD step (ends by LAUNCHING the all-reduce on
+        the comm stream) -> enqueue a later batch's VAE encode on the side stream (starts when the gradients are
+        complete, i.e. beside the all-reduce, and runs on beside AdamW and the next step) -> join + fused AdamW."""
+        if vae is not None and len(encoded) >= 2:      # latents encoded while the PREVIOUS step ran
+            lat, ev = encoded.pop(0)
+            torch.cuda.current_stream().wait_event(ev)
+            batch["latents"] = lat
+        trainer.training_step(batch, async_allreduce=True)
         if args.force_collective and world == 1 and comm is None:
             dist.all_reduce(adapter.flat_grad)
-        trainer.optimizer_step()              # joins the all-reduce, then fused AdamW
         if vae is not None:
-            torch.cuda.current_stream().wait_stream(side)
-            batch["latents"] = next_latents[0]
+            side.wait_stream(torch.cuda.current_stream())        # = "adapter gradients complete"
+            with torch.cuda.stream(side):
+                lat = vae.encode_latents(pixels)
+                ev = torch.cuda.Event()
+                ev.record(side)
+            encoded.append((lat, ev))
+        trainer.optimizer_step()              # joins the all-reduce, then fused AdamW
+        if marks is not None:
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            marks.append(e)
 
     def barrier():
         if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
-    if args.single_stream:
-        lib().pea_trainer_set_option(trainer._h, b"two_stream", 0)
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    barrier()
-    dt = time.perf_counter() - t0
-    if use_dist:
-        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
-    ms = dt / args.steps * 1e3
-    ips = world * B * args.steps / dt
-    loss = float(trainer.losses[0])
-    allreduce_ms = None
-    if comm is not None:
-        allreduce_ms = round(comm.last_ms(), 4)      # device time of the last step's all-reduce + 1/world scale (comm stream)
-    rccl_ranks = dist.get_world_size() if use_dist else 1
+    def allreduce_max(dt):
+        if use_dist:
+            tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            return float(tmax.item())
+        return dt
 
-    roof = None
-    if not args.no_roofline and rank == 0:
+    def instrument(step_fn):
+        """per-launch HIP events on the launch stream over a single-stream replay of the step (every rank runs it: the
+        step contains the collective)"""
         L = lib()
+        nprof = min(args.steps, 3)
         L.pea_trainer_set_option(trainer._h, b"two_stream", 0)   # clean per-kernel durations (no cross-stream overlap)
         L.pea_prof_reset()
         L.pea_prof_enable(1)
-        for _ in range(min(args.steps, 3)):
-            step()
+        for _ in range(nprof):
+            step_fn(None)
         torch.cuda.synchronize()
         L.pea_prof_enable(0)
-        if args.dump_prof:
+        if args.dump_prof and rank == 0:
             L.pea_prof_dump(args.dump_prof.encode())
         L.pea_trainer_set_option(trainer._h, b"two_stream", 1)
         fams = []
@@ -407,7 +589,6 @@ def main():
             fams.append(dict(name=L.pea_prof_family_name(f).decode(), ms=t.value, flops=fl.value, bytes=by.value,
                              launches=n.value))
         L.pea_prof_reset()
-        nprof = min(args.steps, 3)
         gem = [fams[0], fams[1]]
         g_ms = sum(x["ms"] for x in gem)
         g_fl = sum(x["flops"] for x in gem)
@@ -417,28 +598,46 @@ def main():
                 "achieved": round(ach, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(ach / MFMA_PEAK_TFLOPS, 4), "traffic": pmc_traffic()[0],
                 "traffic_unit": "bytes per launch, TCC FETCH_SIZE x2 (gfx950) + WRITE_SIZE over the family's launches, from "
-                                f"two separate rocprofv3 --pmc passes of this command (profiles/{pmc_traffic()[1]})",
+                                f"two separate rocprofv3 --pmc passes of this command (profiles/{pmc_traffic()[1]}); not "
+                                "re-measured inside this run (PMC needs the profiler)",
                 "launches_per_step": g_n // nprof, "avg_launch_us": round(g_ms * 1e3 / max(g_n, 1), 2),
                 "gflop_per_launch": round(g_fl / max(g_n, 1) / 1e9, 3),
                 "ms_per_step_single_stream": round(g_ms / nprof, 2),
                 "method": "hip events around every launch on the launch stream; instrumented single-stream replay of the timed "
-                          "steps (the timed region overlaps teacher and student passes on two streams)"}
-        if args.breakdown:
+                          "steps (the timed region overlaps teacher and student passes on two streams)",
+                "families": family_rooflines(fams, nprof),
+                "tolerances": "fp32-stored outputs rtol 1e-3 / atol 1e-4 vs the fp32 oracle; bf16-stored outputs 1 bf16 ulp "
+                              "(2-4 ulp for multi-product attention gradients and folded LN->Linear) + rms-scaled atol "
+                              "(tests/test_ops_gpu.py)"}
+        if args.breakdown and rank == 0:
             tot = sum(x["ms"] for x in fams)
             for x in fams:
                 tf = x["flops"] / (x["ms"] * 1e-3) / 1e12 if x["ms"] > 0 else 0
                 gb = x["bytes"] / (x["ms"] * 1e-3) / 1e9 if x["ms"] > 0 else 0
                 print(f"  {x['name']:28s} {x['ms'] / nprof:9.2f} ms/step {x['launches'] // nprof:6d} launches "
                       f"{tf:8.1f} TFLOP/s {gb:8.0f} GB/s(alg)", file=sys.stderr)
-            print(f"  instrumented families total {tot / nprof:.2f} ms/step (single-stream replay) vs timed step {ms:.2f} ms",
-                  file=sys.stderr)
+            print(f"  instrumented families total {tot / nprof:.2f} ms/step (single-stream replay)", file=sys.stderr)
+        return roof
 
-    cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(args.model, args.cpu_budget)
+    if args.single_stream:
+        lib().pea_trainer_set_option(trainer._h, b"two_stream", 0)
+    sampler = GpuSampler(local_rank) if rank == 0 else None
+    dt, marks = run_protocol(args, rank, world, step, barrier, allreduce_max, sampler)
+    ms_mean = dt / args.steps * 1e3
+    ips = world * B * args.steps / dt
+    # per-step device times: distance between the events recorded behind each step's AdamW on the compute stream
+    per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(len(marks) - 1))
+    ms_median = per_step[len(per_step) // 2] if per_step else ms_mean
+    loss = float(trainer.losses[0])
+    allreduce_ms = allreduce_exposed_ms = None
+    if comm is not None:
+        allreduce_ms = round(comm.last_ms(), 4)      # device time of the last step's all-reduce + 1/world scale (comm stream)
+        allreduce_exposed_ms = round(comm.last_exposed_ms(), 4)   # how long AdamW's stream stood still for it
+    rccl_ranks = dist.get_world_size() if use_dist else 1
+
+    roof, cpu = after_timing(args, rank, world, step, instrument, barrier)
 
     if use_dist:
-        dist.barrier()
         if comm is not None:
             comm.close()
         dist.destroy_process_group()
@@ -447,7 +646,12 @@ def main():
         out = {
             "metric": "training images/sec (SDXL 1024px bf16, adapter-only bwd)", "value": round(ips, 4),
             "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": round(ms_median, 3), "ms_per_step_mean": round(ms_mean, 3),
+            "ms_per_step_min_max": [round(per_step[0], 3), round(per_step[-1], 3)] if per_step else None,
+            "timing": "value = global batch x K / wall time of the K steps between barrier+synchronize pairs, max over "
+                      "ranks (so value x ms_per_step_mean = 1000 x global batch); ms_per_step = median of the per-step "
+                      "device times (events behind each step's AdamW, SURVEY 8d)",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16", "data": "synthetic",
             "config": {"workload": f"{args.model.upper()} {hw * 8}x{hw * 8} KD training step (teacher fwd + student "
                                    f"fwd + student dgrad bwd + adapter fwd/bwd + AdamW), per-GPU batch {B}",
@@ -459,7 +663,8 @@ def main():
                                    "random init, SSD-1B student (per-position depths [2,2],[4,4] down / [4,4,10],[2,1,1] up, no mid "
                                    "block; 1 300 195 844 parameters) under the SDXL teacher"),
                        "loss": round(loss, 6),
-                       **({"vae_encode": f"next batch's {hw * 8}x{hw * 8} VAE encode on a side HIP stream inside every step"}
+                       **({"vae_encode": f"a later batch's {hw * 8}x{hw * 8} VAE encode on a side HIP stream, enqueued "
+                                         "between training_step and optimizer_step (beside the all-reduce), consumed two steps later"}
                           if args.with_vae else {})},
             "tflop_per_image": TFLOP_PER_IMAGE.get(args.model) if args.student == "same" else None,
             "achieved_tflops_per_gpu": (round(ips / world * TFLOP_PER_IMAGE[args.model], 1)
@@ -471,7 +676,9 @@ def main():
                        if lib().pea_trainer_get_option(trainer._h, b"merge_state") == 1 else
                        "teacher forward on a side HIP stream beside the student forward"),
             "rccl_ranks": rccl_ranks, "collective": collective, "allreduce_ms": allreduce_ms,
+            "allreduce_exposed_ms": allreduce_exposed_ms,
             "allreduce_bytes": int(adapter.flat_grad.numel() * 4) if use_dist else 0,
+            "gpu": sampler.summary() if sampler is not None else None,
             "roofline": roof, "cpu_baseline": cpu,
         }
         sys.stdout.flush()

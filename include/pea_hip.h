@@ -364,6 +364,8 @@ int pea_trainer_export(void* tr, int which, float* out, void* stream);
  *                        (the adapter wgrad), then all-reduces `grads` in place and scales by 1/world.
  *   pea_comm_join:      makes `stream` wait for the last all-reduce (call before the optimizer reads `grads`).
  *   pea_comm_last_ms:   BLOCKING; device time of the last all-reduce + scale in milliseconds.
+ *   pea_comm_last_exposed_ms: BLOCKING; how long the first stream that joined the last all-reduce stood still for it
+ *                       (0 when the collective had finished before the stream reached the join).
  *   pea_comm_broadcast: parameter broadcast from `root` (identical replicas at start), enqueued on `stream`.      */
 int pea_comm_unique_id(void* out128);
 int pea_comm_init(int rank, int world, const void* unique_id128, void** comm_out);
@@ -373,6 +375,7 @@ int pea_comm_rank(void* comm);
 int pea_allreduce_grads(void* comm, float* grads, long long n, void* compute_stream);
 int pea_comm_join(void* comm, void* stream);
 int pea_comm_last_ms(void* comm, float* ms);
+int pea_comm_last_exposed_ms(void* comm, float* ms);
 int pea_comm_broadcast(void* comm, float* buf, long long n, int root, void* stream);
 
 /* per-launch HIP-event timing by kernel family (bench.py roofline leg); families 0..7:

@@ -87,7 +87,7 @@ def depth_tables(cfg):
         mid = -1
     else:
         last = tl[-1]
-        mid = int(last) if isinstance(last, int) else int(last[-1])
+        mid = int(last) if isinstance(last, int) else int(last[0])     # diffusers: UNetMidBlock2DCrossAttn indexes [i], i < num_layers = 1
     return down, up, mid
 
 

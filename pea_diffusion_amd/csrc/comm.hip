@@ -10,6 +10,7 @@
 // one process never holds two copies; libpea_hip.so itself loads without RCCL.
 #include <dlfcn.h>
 #include <rccl/rccl.h>
+#include <stdint.h>
 #include <string.h>
 
 #include "../../include/pea_hip.h"
@@ -76,7 +77,8 @@ struct Comm {
   hipStream_t stream = nullptr;                    // the dedicated comm stream
   hipEvent_t ev_ready = nullptr;                   // compute stream -> comm stream (gradients complete)
   hipEvent_t ev_t0 = nullptr, ev_done = nullptr;   // around the collective (timing enabled) / result ready
-  bool pending = false;
+  hipEvent_t ev_j0 = nullptr, ev_j1 = nullptr;     // on the joining stream, either side of its wait (exposed time)
+  bool pending = false, joined = false;
 };
 
 __global__ void scale_kernel(float* __restrict__ p, long long n, float f) {
@@ -123,10 +125,18 @@ int pea_comm_init(int rank, int world, const void* unique_id128, void** out) {
     delete c;
     return PEA_E_HIP;
   }
-  HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-  HIPCHK(hipEventCreateWithFlags(&c->ev_ready, hipEventDisableTiming));
-  HIPCHK(hipEventCreate(&c->ev_t0));
-  HIPCHK(hipEventCreate(&c->ev_done));
+  // any failure past the rendezvous goes through pea_comm_destroy (communicator, stream and events released)
+  hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_ready, hipEventDisableTiming);
+  if (e == hipSuccess) e = hipEventCreate(&c->ev_t0);
+  if (e == hipSuccess) e = hipEventCreate(&c->ev_done);
+  if (e == hipSuccess) e = hipEventCreate(&c->ev_j0);
+  if (e == hipSuccess) e = hipEventCreate(&c->ev_j1);
+  if (e != hipSuccess) {
+    pea_set_error("pea_comm_init: stream / event creation failed: %s", hipGetErrorString(e));
+    (void)pea_comm_destroy(c);
+    return PEA_E_HIP;
+  }
   *out = c;
   return PEA_OK;
 }
@@ -139,6 +149,8 @@ int pea_comm_destroy(void* h) {
   if (c->ev_ready) (void)hipEventDestroy(c->ev_ready);
   if (c->ev_t0) (void)hipEventDestroy(c->ev_t0);
   if (c->ev_done) (void)hipEventDestroy(c->ev_done);
+  if (c->ev_j0) (void)hipEventDestroy(c->ev_j0);
+  if (c->ev_j1) (void)hipEventDestroy(c->ev_j1);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
   return PEA_OK;
@@ -151,6 +163,7 @@ int pea_allreduce_grads(void* h, float* grads, long long n, void* compute_stream
   if (!h || !grads) { pea_set_error("pea_allreduce_grads: null argument"); return PEA_E_INVALID; }
   Comm* c = (Comm*)h;
   SHAPECHK(n > 0, "pea_allreduce_grads: n=%lld", n);
+  SHAPECHK(((uintptr_t)grads & 15) == 0, "pea_allreduce_grads: grads must be 16-byte aligned (got %p)", (void*)grads);
   HIPCHK(hipEventRecord(c->ev_ready, (hipStream_t)compute_stream));
   HIPCHK(hipStreamWaitEvent(c->stream, c->ev_ready, 0));
   HIPCHK(hipEventRecord(c->ev_t0, c->stream));
@@ -163,13 +176,32 @@ int pea_allreduce_grads(void* h, float* grads, long long n, void* compute_stream
   }
   HIPCHK(hipEventRecord(c->ev_done, c->stream));
   c->pending = true;
+  c->joined = false;
   return PEA_OK;
 }
 
 int pea_comm_join(void* h, void* stream) {
   if (!h) { pea_set_error("pea_comm_join: null communicator"); return PEA_E_INVALID; }
   Comm* c = (Comm*)h;
-  if (c->pending) HIPCHK(hipStreamWaitEvent((hipStream_t)stream, c->ev_done, 0));
+  if (c->pending && !c->joined) {
+    // ev_j0 completes when `stream` has drained what was enqueued before the join, ev_j1 when the wait is satisfied:
+    // their distance is the time the joining stream stood still for the collective (pea_comm_last_exposed_ms)
+    HIPCHK(hipEventRecord(c->ev_j0, (hipStream_t)stream));
+    HIPCHK(hipStreamWaitEvent((hipStream_t)stream, c->ev_done, 0));
+    HIPCHK(hipEventRecord(c->ev_j1, (hipStream_t)stream));
+    c->joined = true;
+  } else if (c->pending) {
+    HIPCHK(hipStreamWaitEvent((hipStream_t)stream, c->ev_done, 0));
+  }
+  return PEA_OK;
+}
+
+int pea_comm_last_exposed_ms(void* h, float* ms) {
+  if (!h || !ms) { pea_set_error("pea_comm_last_exposed_ms: null argument"); return PEA_E_INVALID; }
+  Comm* c = (Comm*)h;
+  if (!c->pending || !c->joined) { *ms = 0.f; return PEA_OK; }
+  HIPCHK(hipEventSynchronize(c->ev_j1));
+  HIPCHK(hipEventElapsedTime(ms, c->ev_j0, c->ev_j1));
   return PEA_OK;
 }
 

@@ -127,6 +127,13 @@ class NativeComm:
         check(lib().pea_comm_last_ms(self._h, ctypes.byref(ms)))
         return float(ms.value)
 
+    def last_exposed_ms(self) -> float:
+        """how long the joining stream stood still for the last all-reduce (0: fully overlapped)"""
+        from ._lib import check, lib
+        ms = ctypes.c_float()
+        check(lib().pea_comm_last_exposed_ms(self._h, ctypes.byref(ms)))
+        return float(ms.value)
+
     def broadcast_(self, flat: torch.Tensor, root: int = 0):
         from ._lib import check, lib, ptr, stream_ptr
         check(lib().pea_comm_broadcast(self._h, ptr(flat), flat.numel(), root, stream_ptr()))

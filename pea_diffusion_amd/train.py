@@ -56,6 +56,7 @@ class PEATrainer:
         self._v = torch.zeros_like(adapter.flat_param)
         self.comm: Optional[pdist.NativeComm] = None      # RCCL communicator + comm stream inside libpea_hip.so
         self._pending = None                               # torch.distributed work handle (gloo / torch-NCCL path)
+        self._comm_inflight = False                        # an all-reduce launched on the native communicator, not joined yet
 
     def __del__(self):
         try:
@@ -68,11 +69,18 @@ class PEATrainer:
     def _dev(self, t, dtype):
         return t.detach().to(self.student.device, dtype).contiguous()
 
-    def training_step(self, batch: Dict[str, torch.Tensor], batch_idx: int = 0, sync: bool = False):
+    def training_step(self, batch: Dict[str, torch.Tensor], batch_idx: int = 0, sync: bool = False,
+                      async_allreduce: bool = False):
         """batch: the post-encoder form of the reference batch: latents, noise, timesteps, enc,
         enc_uncond, prompt_mask, zh_or_not, teacher_ehs, teacher_neg [, teacher_pooled, time_ids].
-        Leaves the adapter gradients in `adapter.flat_grad`; returns {"loss": device scalar, ...}."""
+        Leaves the adapter gradients in `adapter.flat_grad`; returns {"loss": device scalar, ...}.
+
+        Data parallel: by default the averaged gradient is complete (on the current stream) when this returns, so
+        `p.grad` can be clipped, logged or fed to any optimizer.  `async_allreduce=True` only LAUNCHES the collective
+        on the communicator's stream and leaves the join to `optimizer_step()` / `join_grads()`, so work enqueued
+        in between (the next batch's VAE encode) overlaps the xGMI transfer; `p.grad` must not be read before that."""
         f32, dev = torch.float32, self._dev
+        self.join_grads()                   # a collective still in flight reads and writes flat_grad in place
         self.adapter.prepare(2 * self.student.B, self.student.L)   # a stand-alone proj(x) call may have re-shaped it
         self.adapter._sync()
         b = {k: dev(batch[k], f32) for k in ("latents", "noise", "enc", "enc_uncond", "teacher_ehs", "teacher_neg")}
@@ -88,7 +96,9 @@ class PEATrainer:
                                    stream_ptr()))
         self._keep = (b, ts, pm, zh, tp, tid)
         if self.comm is not None or world > 1:
-            self.all_reduce_grads_async()   # launched right behind the adapter wgrad; joined in optimizer_step()
+            self.all_reduce_grads_async()   # launched right behind the adapter wgrad
+            if not async_allreduce:
+                self.join_grads()
         for p, o in zip(self.adapter._plist(), self.adapter._offsets):
             p.grad = self.adapter.flat_grad[o:o + p.numel()].view_as(p)
         snap = self.losses.clone()          # device-side snapshot: later steps overwrite self.losses
@@ -132,12 +142,16 @@ class PEATrainer:
         all-reduce (ProcessGroupNCCL runs it on its internal stream).  `join_grads()` must precede any read."""
         if self.comm is not None:
             self.comm.allreduce_mean_async(self.adapter.flat_grad)
+            self._comm_inflight = True
         else:
             self._pending = pdist.allreduce_mean_(self.adapter.flat_grad, async_op=True)
 
     def join_grads(self):
+        """make the current stream wait for the gradient all-reduce launched last (no-op when none is pending)"""
         if self.comm is not None:
-            self.comm.join()
+            if self._comm_inflight:
+                self.comm.join()
+                self._comm_inflight = False
         elif self._pending is not None:
             self._pending.wait()
             self.adapter.flat_grad.div_(self.world_size)
@@ -261,10 +275,12 @@ class BucketedTrainer(PEATrainer):
         for _, _, h in self._ctx.values():
             check(lib().pea_trainer_set_option(h, name.encode(), int(value)))
 
-    def training_step(self, batch: Dict[str, torch.Tensor], batch_idx: int = 0, sync: bool = False):
+    def training_step(self, batch: Dict[str, torch.Tensor], batch_idx: int = 0, sync: bool = False,
+                      async_allreduce: bool = False):
         h, w = batch["latents"].shape[-2:]
+        self.join_grads()
         self._select(h, w)
-        return super().training_step(batch, batch_idx, sync=sync)
+        return super().training_step(batch, batch_idx, sync=sync, async_allreduce=async_allreduce)
 
     def __del__(self):
         try:

@@ -66,13 +66,24 @@ def test_trainer_step_with_rccl_world1_matches_plain_step(gpu):
     g0 = ad_hip.flat_grad.clone()
     comm = pdist.NativeComm.from_env()
     tr.attach_comm(comm)
-    tr.training_step(batch, 0)
+    tr.training_step(batch, 0, async_allreduce=True)       # only LAUNCHED on the comm stream ...
+    assert tr._comm_inflight
+    tr.join_grads()                                        # ... the current stream waits for it here
+    torch.cuda.synchronize()
+    assert torch.equal(g0, ad_hip.flat_grad) and not tr._comm_inflight
+    tr.training_step(batch, 0)                             # default: gradient complete (joined) on return
+    assert not tr._comm_inflight
+    torch.cuda.synchronize()
+    assert torch.equal(g0, ad_hip.flat_grad)
+    tr.training_step(batch, 0, async_allreduce=True)
+    tr.training_step(batch, 0, async_allreduce=True)       # a second step joins the first collective before it rewrites flat_grad
     tr.join_grads()
     torch.cuda.synchronize()
     assert torch.equal(g0, ad_hip.flat_grad)
+    assert comm.last_ms() >= 0.0 and comm.last_exposed_ms() >= 0.0
     w0 = ad_hip.flat_param.clone()
     tr.lr, tr.warmup_steps = 1e-3, 0
-    tr.training_step(batch, 0)
+    tr.training_step(batch, 0, async_allreduce=True)
     tr.optimizer_step()                                    # joins the comm stream before AdamW reads the gradient
     torch.cuda.synchronize()
     assert not torch.equal(w0, ad_hip.flat_param)
@@ -95,3 +106,29 @@ def test_trainer_step_with_rccl_world1_matches_plain_step(gpu):
         dist.destroy_process_group()
         for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR"):
             os.environ.pop(k, None)
+
+
+def test_bench_subprocess_with_collective_and_side_stream_vae(gpu):
+    """`bench.py --gpus 1 --force-collective --with-vae --model tiny` as a subprocess: the N > 1 code path on one GPU --
+    RCCL communicator inside libpea_hip.so, all-reduce launched by training_step, a later batch's VAE encode enqueued
+    on the side stream between training_step and optimizer_step, the instrumented replay, one JSON line."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["MASTER_PORT"] = str(_free_port())
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--force-collective", "--with-vae",
+                        "--model", "tiny", "--steps", "6", "--warmup", "2", "--no-cpu-baseline"],
+                       capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["rccl_ranks"] == 1 and "libpea_hip.so" in out["collective"]
+    assert out["config"]["loss"] == out["config"]["loss"] and abs(out["config"]["loss"]) < 1e4      # finite
+    assert out["allreduce_ms"] is not None and out["allreduce_exposed_ms"] is not None
+    assert out["allreduce_bytes"] > 0 and "vae_encode" in out["config"]
+    fams = {f["family"]: f for f in out["roofline"]["families"]}
+    assert any(k.startswith("gemm") for k in fams) and "attn_bwd" in fams and "kd_loss" in fams
+    assert out["ms_per_step"] > 0 and out["ms_per_step_mean"] > 0

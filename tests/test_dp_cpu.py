@@ -138,6 +138,30 @@ def test_bench_launcher_spawns_two_ranks_over_gloo():
     out = json.loads(lines[0])
     assert out["ranks"] == 2 and out["n_gpus"] == 2 and out["per_gpu_batch"] == 8 and out["global_batch"] == 16
     assert out["allreduce_max_abs_err"] < 1e-5 and out["dry_run"] is True
+    # the whole control flow ran on BOTH ranks: warm-up + K timed steps + the instrumented replay (each step holds a
+    # collective, so a replay on rank 0 only would have left this subprocess hanging) + the closing barrier
+    assert out["steps_run_per_rank"] == 3 + 2 + 2 and out["replay"] == {"replayed_steps": 2}
+
+
+def test_bench_launcher_kills_hung_ranks_at_the_deadline(tmp_path):
+    """a rank that never exits (stuck in a collective) must not block the parent forever: launch_ranks() stops its own
+    children at the deadline, names the ranks that were still alive and returns non-zero"""
+    import subprocess
+    script = tmp_path / "hang.py"
+    script.write_text(
+        "import sys, time\n"
+        f"sys.path.insert(0, {ROOT!r})\n"
+        "import bench, os\n"
+        "if os.environ.get('RANK') is None:\n"
+        "    bench.__file__ = __file__\n"
+        "    sys.exit(bench.launch_ranks(2, [], 3.0))\n"
+        "if os.environ['RANK'] == '1':\n"
+        "    time.sleep(600)\n"
+        "print('{}')\n")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=120, env=env)
+    assert r.returncode == 124, (r.returncode, r.stderr[-1000:])
+    assert "ranks still running: [1]" in r.stderr and not r.stdout.strip()
 
 
 def test_bench_refuses_a_world_size_that_contradicts_gpus():

@@ -163,7 +163,8 @@ def test_adapter_module_matches_reference_golden(gpu, golden_dir):
     full-size seeded goldens are used here)."""
     import os
     from pea_diffusion_amd.adapter import PEAAdapter
-    for tag in ["sdxl_6M", "sdxl_11M", "sd15_full"]:
+    # sdxl_in2048 / sdxl_in768: the constructors of the other student encoders (train_sdxl_zh.py:113,124,134)
+    for tag in ["sdxl_6M", "sdxl_11M", "sdxl_in2048", "sdxl_in768", "sd15_full"]:
         g = np.load(os.path.join(golden_dir, f"mlp_{tag}.npz"))
         args = [int(a) for a in g["args"]]
         torch.manual_seed(int(g["seed"]))
@@ -601,10 +602,7 @@ def _fast_fill_(module, seed=0):
                 p.copy_(0.02 * buf[:p.numel()])
 
 
-def test_sdxl_full_model_step_vs_oracle_512(gpu):
-    """The full 2.57 B-parameter SDXL UNet (BASELINE configs[1] model, 512x512 so the fp32 CPU oracle finishes in about a
-    minute; batch 2 so both mask values occur): the whole KD step -- merged passes, since the teacher is the student
-    checkpoint -- against the oracle: eps, the four logged scalars, the flat adapter gradient."""
+def _sdxl_full_model_step_vs_oracle(hw, tag, eps_lim, grad_lim):
     import copy
     from oracle import unet_ref as ou
     from oracle.step_ref import AdapterRef, synthetic_batch, training_step_ref
@@ -614,7 +612,7 @@ def test_sdxl_full_model_step_vs_oracle_512(gpu):
     from pea_diffusion_amd.unet import HipUNet
     torch.set_num_threads(min(64, len(__import__("os").sched_getaffinity(0))))
     cfg = ou.sdxl_config()
-    B, L, hw = 2, 77, 64
+    B, L = 2, 77
     # build without the default init (torch.nn.init on 2.57 B parameters takes about a minute): allocate, then fill
     orig = torch.nn.init.kaiming_uniform_, torch.nn.init.uniform_
     torch.nn.init.kaiming_uniform_ = lambda t, *a, **k: t
@@ -639,17 +637,20 @@ def test_sdxl_full_model_step_vs_oracle_512(gpu):
     assert not missing and not unexpected
     ht = HipUNet(pc.sdxl_config(), B, hw, hw, L, share_weights_from=hs)
     batch = synthetic_batch(cfg, B, L=L, enc_dim=1024, seed=2, latent_hw=hw)
+    assert sorted(batch["zh_or_not"].tolist()) == [0, 1]          # both mask values occur
     tr = PEATrainer(ad, hs, ht)
     out = tr.training_step(batch, 0, sync=True)
     assert lib_merge_state(tr) == 1
     bq = dict(batch)
     for k in ("enc", "enc_uncond", "teacher_ehs", "teacher_neg", "teacher_pooled"):
         bq[k] = batch[k].to(torch.bfloat16).float()
+    import time
+    t0 = time.time()
     ref = training_step_ref(ad_ref, us, ut, bq, ou.cast_hook_ref)
     ref["loss"].backward()
     e_s, e_t = rel_l2(tr.export("eps_student"), ref["noise_pred"]), rel_l2(tr.export("eps_teacher"), ref["noise_pred_teacher"])
-    print(f"[sdxl full model 512x512 step] eps_student rel_l2={e_s:.3e} eps_teacher rel_l2={e_t:.3e}")
-    assert e_s < 1.5e-2 and e_t < 1.5e-2            # measured 7.0e-3
+    print(f"[sdxl full model {tag} step] eps_student rel_l2={e_s:.3e} eps_teacher rel_l2={e_t:.3e} (oracle {time.time() - t0:.0f} s)")
+    assert e_s < eps_lim and e_t < eps_lim
     total = abs(float(ref["loss"]))
     for k in tr.LOG_KEYS:
         h, r = float(out[k]), float(ref[k])
@@ -658,4 +659,18 @@ def test_sdxl_full_model_step_vs_oracle_512(gpu):
     g_ref = torch.cat([p.grad.reshape(-1) for p in ad_ref.parameters()])
     eg = rel_l2(ad.flat_grad, g_ref)
     print(f"   adapter grad rel_l2={eg:.3e} |ref|={g_ref.norm():.3e}")
-    assert eg < 2e-2                                # measured 8.1e-3
+    assert eg < grad_lim
+
+
+def test_sdxl_full_model_step_vs_oracle_512(gpu):
+    """The full 2.57 B-parameter SDXL UNet (BASELINE configs[1] model, 512x512 so the fp32 CPU oracle finishes in about a
+    minute; batch 2 so both mask values occur): the whole KD step -- merged passes, since the teacher is the student
+    checkpoint -- against the oracle: eps, the four logged scalars, the flat adapter gradient."""
+    _sdxl_full_model_step_vs_oracle(64, "512x512", 1.5e-2, 2e-2)       # measured 7.0e-3 / 8.1e-3
+
+
+def test_sdxl_full_model_step_vs_oracle_1024(gpu):
+    """The same comparison at the METRIC's resolution (train_sdxl_zh.py:397-441 on 1024x1024 images, latent 128x128):
+    the 4096-token x 10-head self-attention, the 128x128 convolutions (M = 32768 rows per sample) and the persistent
+    256x160 tile walk meet the fp32 oracle end to end, not only through properties (tests/test_configs_gpu.py)."""
+    _sdxl_full_model_step_vs_oracle(128, "1024x1024", 1.5e-2, 2e-2)

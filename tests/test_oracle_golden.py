@@ -176,6 +176,12 @@ def test_ssd1b_layout_known_answers_and_config_json():
     assert cc.per_layer_depth == 1 and cc.depth_mid == -1 and [cc.depth_up[0][j] for j in range(3)] == [4, 4, 10]
     # uniform configs: ints broadcast, the up path mirrors the down path, the mid block takes the last entry
     assert pc.depth_tables(pc.sdxl_config()) == ([[1, 1], [2, 2], [10, 10]], [[10, 10, 10], [2, 2, 2], [1, 1, 1]], 10)
+    # a nested last entry WITH a mid block: diffusers hands transformer_layers_per_block[-1] to UNetMidBlock2DCrossAttn,
+    # which reads element [0] for its single layer
+    import dataclasses
+    nested = dataclasses.replace(pc.sdxl_config(), transformer_layers_per_block=(1, 2, (4, 10)),
+                                 reverse_transformer_layers_per_block=((10, 4, 4), 2, 1))
+    assert pc.depth_tables(nested)[2] == 4 and pc.depth_tables(nested)[0][2] == [4, 10]
     sd = dict(js, transformer_layers_per_block=[1, 2, 10], reverse_transformer_layers_per_block=None,
               mid_block_type="UNetMidBlock2DCrossAttn")
     assert pc.depth_tables(pc.unet_config_from_diffusers(sd)) == pc.depth_tables(pc.sdxl_config())
