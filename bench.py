@@ -246,11 +246,18 @@ class GpuSampler:
     """sclk / board power of this rank's GPU, sampled from sysfs while the timed steps run (explains box-to-box spread of
     the same build; informational: the clock an MFMA loop holds in-kernel is up to 10 % under pp_dpm_sclk)."""
 
-    def __init__(self, index):
+    def __init__(self, index, pci=None):
         import glob
         import threading
         cards = sorted(d for d in glob.glob("/sys/class/drm/card[0-9]*/device") if os.path.exists(d + "/pp_dpm_sclk"))
-        self.dev = cards[index] if index < len(cards) else None
+        self.dev = None
+        if pci:                              # the card whose PCI address is this rank's device (a box exposes all its cards)
+            for d in cards:
+                if os.path.basename(os.path.realpath(d)).lower().endswith(pci.lower()):
+                    self.dev = d
+        if self.dev is None:
+            self.dev = cards[index] if index < len(cards) else None
+        self.matched = bool(pci) and self.dev is not None and os.path.basename(os.path.realpath(self.dev)).lower().endswith(pci.lower())
         self.sclk, self.power = [], []
         self._stop = threading.Event()
         self._t = threading.Thread(target=self._run, daemon=True)
@@ -289,7 +296,8 @@ class GpuSampler:
         med = lambda v: sorted(v)[len(v) // 2] if v else None
         return {"sclk_mhz_median": med(self.sclk), "sclk_mhz_min": min(self.sclk) if self.sclk else None,
                 "power_w_median": med(self.power), "power_w_max": max(self.power) if self.power else None,
-                "samples": len(self.sclk), "source": "sysfs pp_dpm_sclk / hwmon power1_average, 50 ms period, timed region only"}
+                "samples": len(self.sclk), "card_matched_by_pci": self.matched,
+                "source": "sysfs pp_dpm_sclk / hwmon power1_average, 50 ms period, timed region only"}
 
 
 def run_protocol(args, rank, world, step, barrier, allreduce_max, sampler=None):
@@ -621,7 +629,13 @@ def main():
 
     if args.single_stream:
         lib().pea_trainer_set_option(trainer._h, b"two_stream", 0)
-    sampler = GpuSampler(local_rank) if rank == 0 else None
+    pci = None
+    try:
+        pr = torch.cuda.get_device_properties(dev)
+        pci = f"{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0"
+    except Exception:
+        pass
+    sampler = GpuSampler(local_rank, pci) if rank == 0 else None
     dt, marks = run_protocol(args, rank, world, step, barrier, allreduce_max, sampler)
     ms_mean = dt / args.steps * 1e3
     ips = world * B * args.steps / dt

@@ -47,13 +47,26 @@ int pea_op_gemm(const void* A, int lda, const void* W, int ldw, void* C, int ldc
                 const float* bias, const void* rowvec, int ldrv, int rows_per_batch, int act, void* preact,
                 int ldpre, const void* res, int ldres, int out_f32, int accum_f32, void* stream);
 
+/* C = A . W^T + bias with columns n < qscale_cols multiplied by qscale (qscale_cols % 16 == 0): the fused Q|K|V projection
+ * of an attention layer, whose Q block leaves multiplied by softmax_scale * log2(e) (diffusers Attention.to_q/to_k/to_v).   */
+int pea_op_gemm_qscale(const void* A, int lda, const void* W, int ldw, void* C, int ldc, int M, int N, int K, const float* bias,
+                       int qscale_cols, float qscale, void* stream);
+
+/* The FF projection with GEGLU in its epilogue (diffusers GEGLU.forward: hidden, gate = proj(x).chunk(2); hidden *
+ * gelu(gate); W rows interleaved (h_i, gate_i)):  y[m][n] = h * gelu(gate)  (bf16 [M][N/2]); stash (optional, bf16 [M][N],
+ * rows < stash_rows when stash_rows > 0): stash_grad 0: the pre-activation pair (h, gate); 1: the pair the BACKWARD
+ * multiplies by, (gelu(gate), h * gelu'(gate)) -- no weight gradients exist on this path, so nothing else reads it.  */
+int pea_op_gemm_geglu(const void* A, int lda, const void* W, int ldw, const float* bias, void* y, void* stash, int M, int N,
+                      int K, int stash_grad, int stash_rows, void* stream);
+
 /* The data-gradient GEMM of the FF output projection with the GEGLU backward in its epilogue (diffusers GEGLU:
  * y = h * gelu(gate); train_sdxl_zh.py's student backward runs it in every transformer block):
- *   dy = A[M][K] . W[N][K]^T;  pre[m][2n] = h, pre[m][2n+1] = gate (the stash of the forward);
+ *   dy = A[M][K] . W[N][K]^T;  form 0: pre[m][2n] = h, pre[m][2n+1] = gate (the pre-activation stash of the forward);
+ *   form 1: pre[m][2n] = gelu(gate), pre[m][2n+1] = h * gelu'(gate) (a stash_grad forward);
  *   C[m][2n] = dy * gelu(gate),  C[m][2n+1] = dy * h * gelu'(gate)      (C: bf16 [M][2N], ldc >= 2N)
  * dy itself is never stored.  K % 64 == 0, N % 16 == 0, ldc % 8 == 0, ldpre % 8 == 0.                              */
 int pea_op_gemm_geglu_bwd(const void* A, int lda, const void* W, int ldw, const void* pre, int ldpre, void* C, int ldc,
-                          int M, int N, int K, void* stream);
+                          int M, int N, int K, int form, void* stream);
 
 /* LayerNorm folded into the Linear that consumes it (UNet transformer blocks: norm1 -> to_q|k|v, norm2 -> attn2.to_q,
  * norm3 -> ff.net.0.proj):  y = LN(x; gamma, beta, eps) . W^T + bias  computed as  rstd (x . W'^T - mean s) + t  with
@@ -104,6 +117,10 @@ int pea_op_layernorm_bwd(const void* x, const void* dy, const float* gamma, cons
  * 64*nd is zero padded (SD1.5: 40 -> 64, 80 -> 128, 160 -> 192) and `scale` stays head_dim^-0.5.  lse fp32 [B][H][Sq]. */
 int pea_op_attention_fwd(const void* Q, int ldq, const void* K, int ldk, const void* V, int ldv, void* O, int ldo,
                          float* lse, int B, int H, int Sq, int Skv, float scale, int nd, void* stream);
+/* ... on a Q that already carries scale * log2(e) (the product path: the Q|K|V / to_q projection applies the factor to its fp32
+ * accumulator, pea_op_gemm_qscale, so nothing is rounded twice); `scale` is still the softmax scale */
+int pea_op_attention_fwd_prescaled(const void* Q, int ldq, const void* K, int ldk, const void* V, int ldv, void* O, int ldo,
+                                   float* lse, int B, int H, int Sq, int Skv, float scale, int nd, void* stream);
 /* text-encoder attention (head_dim 64, forward only): `causal` = key index <= query index (CLIP text model), kv_len =
  * device int[B] of valid key counts (BERT right padding) or NULL */
 int pea_op_attention_fwd_masked(const void* Q, int ldq, const void* K, int ldk, const void* V, int ldv, void* O, int ldo,
@@ -117,6 +134,13 @@ int pea_op_attention_bwd(const void* Q, int ldq, const void* K, int ldk, const v
                          int ldo, const void* dO, int lddo, const float* lse, float* delta, void* dQ, int lddq,
                          void* dK, int lddk, void* dV, int lddv, int B, int H, int Sq, int Skv, float scale,
                          int accum_dq, int accum_dkv, int nd, void* scratch, void* stream);
+
+/* the backward on a prescaled Q (see pea_op_attention_fwd_prescaled); dQ is the gradient w.r.t. the UNSCALED q, so the
+ * projection's data-gradient GEMM needs no factor */
+int pea_op_attention_bwd_prescaled(const void* Q, int ldq, const void* K, int ldk, const void* V, int ldv, const void* O,
+                                   int ldo, const void* dO, int lddo, const float* lse, float* delta, void* dQ, int lddq,
+                                   void* dK, int lddk, void* dV, int lddv, int B, int H, int Sq, int Skv, float scale,
+                                   int accum_dq, int accum_dkv, int nd, void* scratch, void* stream);
 
 int pea_op_geglu_fwd(const void* hg, void* y, long long rows, int inner, void* stream);
 int pea_op_geglu_bwd(const void* hg, const void* dy, void* dhg, long long rows, int inner, void* stream);

@@ -23,6 +23,8 @@ int pea_zero_page(const bf16** out) {
   return PEA_OK;
 }
 
+static int g_api_q_prescaled = 0;      // set around a call by the *_prescaled entry points
+
 extern "C" {
 
 const char* pea_last_error(void) { return g_err; }
@@ -47,13 +49,33 @@ int pea_op_gemm(const void* A, int lda, const void* W, int ldw, void* C, int ldc
   return launch_gemm(p, (hipStream_t)stream);
 }
 
+int pea_op_gemm_qscale(const void* A, int lda, const void* W, int ldw, void* C, int ldc, int M, int N, int K, const float* bias,
+                       int qscale_cols, float qscale, void* stream) {
+  GemmP p;
+  memset(&p, 0, sizeof(p));
+  p.A = (const bf16*)A; p.lda = lda; p.W = (const bf16*)W; p.ldw = ldw; p.C = C; p.ldc = ldc;
+  p.M = M; p.N = N; p.K = K; p.alpha = 1.f; p.bias = bias; p.rows_per_batch = 1;
+  p.qscale_cols = qscale_cols; p.qscale = qscale;
+  return launch_gemm(p, (hipStream_t)stream);
+}
+
 int pea_op_gemm_geglu_bwd(const void* A, int lda, const void* W, int ldw, const void* pre, int ldpre, void* C, int ldc,
-                          int M, int N, int K, void* stream) {
+                          int M, int N, int K, int form, void* stream) {
   GemmP p;
   memset(&p, 0, sizeof(p));
   p.A = (const bf16*)A; p.lda = lda; p.W = (const bf16*)W; p.ldw = ldw; p.C = C; p.ldc = ldc;
   p.M = M; p.N = N; p.K = K; p.alpha = 1.f; p.rows_per_batch = 1;
-  p.gbwd_pre = (const bf16*)pre; p.ldgp = ldpre;
+  p.gbwd_pre = (const bf16*)pre; p.ldgp = ldpre; p.gbwd_form = form;
+  return launch_gemm(p, (hipStream_t)stream);
+}
+
+int pea_op_gemm_geglu(const void* A, int lda, const void* W, int ldw, const float* bias, void* y, void* stash, int M, int N,
+                      int K, int stash_grad, int stash_rows, void* stream) {
+  GemmP p;
+  memset(&p, 0, sizeof(p));
+  p.A = (const bf16*)A; p.lda = lda; p.W = (const bf16*)W; p.ldw = ldw; p.bias = bias;
+  p.M = M; p.N = N; p.K = K; p.alpha = 1.f; p.rows_per_batch = 1;
+  p.geglu_y = (bf16*)y; p.ldy = N / 2; p.C = stash; p.ldc = N; p.stash_grad = stash_grad; p.stash_rows = stash_rows;
   return launch_gemm(p, (hipStream_t)stream);
 }
 
@@ -143,7 +165,17 @@ int pea_op_attention_fwd(const void* Q, int ldq, const void* K, int ldk, const v
   memset(&p, 0, sizeof(p));
   p.Q = (const bf16*)Q; p.K = (const bf16*)K; p.V = (const bf16*)V; p.ldq = ldq; p.ldk = ldk; p.ldv = ldv;
   p.O = (bf16*)O; p.ldo = ldo; p.lse = lse; p.B = B; p.H = H; p.Sq = Sq; p.Skv = Skv; p.scale = scale; p.nd = nd;
+  p.q_prescaled = g_api_q_prescaled;
   return launch_attention_fwd(p, (hipStream_t)stream);
+}
+/* the same two operators on a Q that already carries scale * log2(e) (what the model's Q|K|V / to_q projections hand over:
+ * pea_op_gemm_qscale); `scale` is still the softmax scale: dQ comes back as the gradient w.r.t. the UNSCALED q */
+int pea_op_attention_fwd_prescaled(const void* Q, int ldq, const void* K, int ldk, const void* V, int ldv, void* O, int ldo,
+                                   float* lse, int B, int H, int Sq, int Skv, float scale, int nd, void* stream) {
+  g_api_q_prescaled = 1;
+  const int rc = pea_op_attention_fwd(Q, ldq, K, ldk, V, ldv, O, ldo, lse, B, H, Sq, Skv, scale, nd, stream);
+  g_api_q_prescaled = 0;
+  return rc;
 }
 int pea_op_attention_fwd_masked(const void* Q, int ldq, const void* K, int ldk, const void* V, int ldv, void* O, int ldo,
                                 float* lse, int B, int H, int Sq, int Skv, float scale, int causal, const int* kv_len,
@@ -166,7 +198,18 @@ int pea_op_attention_bwd(const void* Q, int ldq, const void* K, int ldk, const v
   p.dO = (const bf16*)dO; p.lddo = lddo; p.delta = delta;
   p.dQ = (bf16*)dQ; p.lddq = lddq; p.dK = (bf16*)dK; p.lddk = lddk; p.dV = (bf16*)dV; p.lddv = lddv;
   p.accum_dq = accum_dq; p.accum_dkv = accum_dkv; p.dkv_part = (float*)scratch; p.nd = nd;
+  p.q_prescaled = g_api_q_prescaled;
   return launch_attention_bwd(p, (hipStream_t)stream);
+}
+int pea_op_attention_bwd_prescaled(const void* Q, int ldq, const void* K, int ldk, const void* V, int ldv, const void* O,
+                                   int ldo, const void* dO, int lddo, const float* lse, float* delta, void* dQ, int lddq,
+                                   void* dK, int lddk, void* dV, int lddv, int B, int H, int Sq, int Skv, float scale,
+                                   int accum_dq, int accum_dkv, int nd, void* scratch, void* stream) {
+  g_api_q_prescaled = 1;
+  const int rc = pea_op_attention_bwd(Q, ldq, K, ldk, V, ldv, O, ldo, dO, lddo, lse, delta, dQ, lddq, dK, lddk, dV, lddv, B, H,
+                                      Sq, Skv, scale, accum_dq, accum_dkv, nd, scratch, stream);
+  g_api_q_prescaled = 0;
+  return rc;
 }
 
 int pea_op_geglu_fwd(const void* hg, void* y, long long rows, int inner, void* stream) {

@@ -20,6 +20,15 @@
 #include "pea_kernels.h"
 
 #define TILE_BYTES 8192   // 64 rows x 128 bytes
+// Issue priority of a wave while it streams MFMAs (experiment switch, profiles/EXPERIMENTS.md round 3): on one SIMD the
+// matrix-busy cycles and the vector-issue cycles of the two resident waves add up instead of overlapping (PMC: 51 % + 45 % of
+// the SIMD's time in the backward); with the MFMA phases at a higher priority the partner's exponentials should fill the
+// 24 free issue cycles of each 32-cycle MFMA instead of delaying it.
+#ifndef PEA_ATTN_PRIO
+#define PEA_ATTN_PRIO 0
+#endif
+#define MFMA_PRIO_ON()  do { if (PEA_ATTN_PRIO) __builtin_amdgcn_s_setprio(PEA_ATTN_PRIO); } while (0)
+#define MFMA_PRIO_OFF() do { if (PEA_ATTN_PRIO) __builtin_amdgcn_s_setprio(0); } while (0)
 // raw v_exp_f32: exp2f() expands to a denormal-safe 5-instruction sequence; every argument here is <= 0 (scores
 // minus a running max / the log-sum-exp), so a flushed denormal result is an exact zero after bf16 rounding anyway
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
@@ -33,6 +42,29 @@ __device__ __forceinline__ float xhalf_max(float x) {
   asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
   return fmaxf(a, b);
 }
+
+// The softmax scale rides in the RESIDENT operand: the fragments a workgroup keeps in registers for its whole life (the
+// queries of the forward / dQ role, the keys of the dK/dV role) are multiplied once by scale * log2(e), so every score
+// leaves the MFMA already in the log2 domain and the row constant (running max, log-sum-exp) is the MFMA's C operand:
+// p = exp2(acc) with no per-score FMA.  These loops are bound by vector issue (profiles/EXPERIMENTS.md, attention): the
+// forward goes from fma + exp + add + 3/4 max + 1/2 cvt per score to exp + add + 1/2 max + 1/2 cvt.
+// AttnP::q_prescaled (the product path: the Q|K|V / to_q projection's epilogue applies the factor to its fp32 accumulator,
+// GemmP::qscale): Q arrives scaled, nothing is rounded twice, and the dK/dV role -- which streams Q -- needs no scaled K
+// (dK = ln2 * dS^T Q').  Otherwise (operator-level calls with a plain Q) the resident fragments are scaled here, which
+// rounds them to bf16 once more: relative 2^-9 per element, i.e. a log2-score error of about 1e-3 for unit-variance scores
+// and proportionally more for large logits.
+__device__ __forceinline__ bf16x8 scale_frag(bf16x8 f, float c) {
+  bf16x8 o;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) o[j] = (bf16)((float)f[j] * c);
+  return o;
+}
+// Running-max threshold of the forward (log2 units): the accumulated offset m_run of a query only moves when a tile's
+// scores exceed it by more than this, so p <= 2^8 per score (fp32 sums and bf16's 8-bit mantissa keep their RELATIVE
+// precision at any magnitude; nothing overflows) and the rescale branch -- subtract, rescale O and l, rebuild the C operand
+// -- runs in the first tile and then almost never.  The result is exact for any threshold: O / l and lse do not depend on
+// the offset used.  tests/test_ops_gpu.py forces the branch in a late tile (spiked key).
+#define ATTN_MOVE_THR 8.0f
 
 // XOR term of a tile row: the bits of (row >> 1) & 7 rotated so that rows r and r + 2 differ in bit 2.  Any bijection of
 // (row >> 1) & 7 keeps the 16-byte row reads (ds_read_b128) conflict free; with this one the transposed reads
@@ -205,7 +237,10 @@ __device__ __forceinline__ void attn_q_body(const AttnP& p, char* smem, int blk_
 #pragma unroll
   for (int nd = 0; nd < ND; ++nd)
 #pragma unroll
-    for (int s = 0; s < 4; ++s) qf[nd][s] = *(const bf16x8*)(Qb + (long long)qrow * p.ldq + nd * 64 + 16 * s + 8 * fh);
+    for (int s = 0; s < 4; ++s) {
+      qf[nd][s] = *(const bf16x8*)(Qb + (long long)qrow * p.ldq + nd * 64 + 16 * s + 8 * fh);
+      if (!p.q_prescaled) qf[nd][s] = scale_frag(qf[nd][s], c);
+    }
   float lse2 = 0.f, dlt = 0.f;
   if (MODE == 1) {
     const bf16* dOb = p.dO + (long long)b * p.Sq * p.lddo + head * 64 * ND;
@@ -239,16 +274,18 @@ __device__ __forceinline__ void attn_q_body(const AttnP& p, char* smem, int blk_
   // every key tile), so dS^T = P^T (dP^T - delta) costs one multiply per score; the softmax scale is applied once, to the
   // finished dQ^T.  The backward loops are VALU-issue-bound (a probe with a 4-cycle stand-in for the 8-cycle v_exp_f32 ran
   // 11 % faster): per score fma + exp + mul + half a conversion instead of fma + exp + sub + mul + mul + conversion.
-  f32x16 negd;
+  // rowc: the C operand of the S^T products -- forward: -m_run (the accumulated offset of this lane's query, 0 before the
+  // first tile); dQ role: -lse2 (so that P^T = exp2(S^T) directly)
+  f32x16 negd, rowc;
 #pragma unroll
-  for (int r = 0; r < 16; ++r) negd[r] = -dlt;
+  for (int r = 0; r < 16; ++r) { negd[r] = -dlt; rowc[r] = MODE == 1 ? -lse2 : 0.f; }
 
   f32x16 oacc[2 * NO];
 #pragma unroll
   for (int i = 0; i < 2 * NO; ++i)
 #pragma unroll
     for (int r = 0; r < 16; ++r) oacc[i][r] = 0.f;
-  float m_run = -INFINITY, l_run = 0.f;
+  float m_run = 0.f, l_run = 0.f;            // m_run: log2-domain offset the P values of this query are relative to
 
   TileSrc ksrc[ND], vsrc[ND];
 #pragma unroll
@@ -307,10 +344,10 @@ __device__ __forceinline__ void attn_q_body(const AttnP& p, char* smem, int blk_
     // before the first MFMA: read-wait-MFMA per fragment (what the compiler emits for the fused loop under a 128-register
     // budget) exposes one LDS latency per MFMA, i.e. the matrix pipe runs at a quarter of its rate in this phase.
     f32x16 sacc[2];
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) sacc[kb][r] = 0.f;
+    // dQ role: the V fragments of the dP product are requested BEFORE the S MFMAs and the transposed K fragments of the dQ
+    // product before the exponentials, so each batch of LDS reads lands under the work in front of it (two waves per SIMD
+    // do not cover an LDS round trip per batch; the forward's three do, and it has no registers to spare)
+    bf16x8 vfr0[2][4];
 #pragma unroll
     for (int nd = 0; nd < ND; ++nd) {
       bf16x8 kfr[2][4];
@@ -318,28 +355,33 @@ __device__ __forceinline__ void attn_q_body(const AttnP& p, char* smem, int blk_
       for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
         for (int s = 0; s < 4; ++s) kfr[kb][s] = *(const bf16x8*)(smem + rfc[s] + (nd * TILE_BYTES + kb * 4096));
+      if (MODE == 1 && nd == ND - 1) {
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+          for (int s = 0; s < 4; ++s) vfr0[kb][s] = *(const bf16x8*)(smem + rfc[s] + (ND * TILE_BYTES + kb * 4096));
+      }
       __builtin_amdgcn_sched_barrier(0);
+      MFMA_PRIO_ON();
 #pragma unroll
       for (int s = 0; s < 4; ++s)
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
-          sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr[kb][s], qf[nd][s], sacc[kb], 0, 0, 0);
+          sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr[kb][s], qf[nd][s], (nd == 0 && s == 0) ? rowc : sacc[kb], 0, 0, 0);
+      MFMA_PRIO_OFF();
     }
     const int kv0 = t * 64;
     bf16x8 pf[4];   // P^T (fwd) or dS^T (dQ) as B-operand fragments, k-permuted
+    bf16x8 tfr1[MODE == 1 ? 4 : 1][2];   // dQ role: transposed K fragments, requested early
     if (MODE == 0) {
-      // online softmax in the log2 domain: p = exp2(c*s - c*m); the scale rides in the FMA, the running max is kept
-      // on the RAW scores (c > 0), keys beyond Skv are masked only in the tile that contains them, and the O rescale
-      // is skipped when no lane's running max moved (exact: alpha == 1 for every lane).
+      // keys beyond Skv are masked only in the tile that contains them.
       // TXT (text encoders, inference): causal mask and / or a per-sample key count (padding) -- a separate instance
       // so the UNet's kernel keeps its register budget
       int skv_b = p.Skv;
       if constexpr (TXT) skv_b = skv_all;
-      float cc = c;                     // factor between the values in sacc and the log2 domain
       if constexpr (TXT) {
         if (p.bias) {
-          // additive score bias (T5 relative positions), given in the log2 domain with a row pitch of 64 * ceil(Skv / 64):
-          // scores move to the log2 domain here (t = c s + bias), the softmax below then runs with a factor of 1
+          // additive score bias (T5 relative positions), given in the log2 domain with a row pitch of 64 * ceil(Skv / 64)
           const int pitch = ((p.Skv + 63) >> 6) << 6;
           const float* brow = p.bias + ((long long)head * p.Sq + qrow) * pitch + kv0 + 4 * fh;
 #pragma unroll
@@ -348,9 +390,8 @@ __device__ __forceinline__ void attn_q_body(const AttnP& p, char* smem, int blk_
             for (int g = 0; g < 4; ++g) {
               const f32x4 bv = *(const f32x4*)(brow + kb * 32 + 8 * g);
 #pragma unroll
-              for (int j = 0; j < 4; ++j) sacc[kb][4 * g + j] = fmaf(sacc[kb][4 * g + j], c, bv[j]);
+              for (int j = 0; j < 4; ++j) sacc[kb][4 * g + j] += bv[j];
             }
-          cc = 1.0f;
         }
       }
       const bool boundary = (TXT && p.causal) || kv0 + 64 > skv_b;   // wave-uniform
@@ -365,34 +406,42 @@ __device__ __forceinline__ void attn_q_body(const AttnP& p, char* smem, int blk_
             sacc[kb][r] = key < kmax ? sacc[kb][r] : -INFINITY;
           }
       }
+      // online softmax in the log2 domain.  sacc holds (scaled score - m_run): the offset came in through the MFMA's C
+      // operand, so p = exp2(sacc) as it stands.  Only when some query's tile maximum exceeds its offset by more than
+      // ATTN_MOVE_THR (always in the first tile) does the wave take the rescale branch (exact for any threshold).
       float mx = fmaxf(sacc[0][0], sacc[1][0]);
 #pragma unroll
       for (int r = 1; r < 16; ++r) mx = fmaxf(fmaxf(mx, sacc[0][r]), sacc[1][r]);     // one v_max3 per pair of scores
       mx = xhalf_max(mx);
-      const float m_new = fmaxf(m_run, mx);
-      const bool moved = m_new != m_run;
-      const float mc = m_new * cc;
-      float ls = 0.f;
-#pragma unroll
-      for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const float e = fast_exp2(fmaf(sacc[kb][r], cc, -mc));
-          sacc[kb][r] = e;
-          ls += e;
-        }
+      const bool moved = t == 0 || mx > ATTN_MOVE_THR;
       if (__any(moved)) {
-        const float alpha = fast_exp2((m_run - m_new) * cc);   // m_run = -inf on the first tile -> 0
+        const float mrel = moved ? fmaxf(mx, -1e30f) : 0.f;      // (a fully masked first tile keeps a finite offset)
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) sacc[kb][r] -= mrel;
+        const float alpha = t == 0 ? 0.f : fast_exp2(-mrel);     // O and l are still zero in the first tile
         l_run *= alpha;
 #pragma unroll
         for (int i = 0; i < 2 * NO; ++i)
 #pragma unroll
           for (int r = 0; r < 16; ++r) oacc[i][r] *= alpha;
+        m_run += mrel;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) rowc[r] = -m_run;
       }
+      float ls = 0.f;
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float e = fast_exp2(sacc[kb][r]);
+          sacc[kb][r] = e;
+          ls += e;
+        }
       l_run += ls;
-      m_run = m_new;
     } else {
-      // P^T = exp2(c S^T - lse2[q]);  dP^T = V . dO^T;  dS^T = P^T (dP^T - delta[q]) scale
+      // P^T = exp2(S^T) (scale in Q, -lse2[q] in the C operand);  dP^T = V . dO^T;  dS^T = P^T (dP^T - delta[q]) scale
       const int skv_b = skv_all;                                 // per-sample valid keys (padded contexts)
       f32x16 dpacc[2];
 #pragma unroll
@@ -401,22 +450,45 @@ __device__ __forceinline__ void attn_q_body(const AttnP& p, char* smem, int blk_
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-          for (int s = 0; s < 4; ++s) vfr[kb][s] = *(const bf16x8*)(smem + rfc[s] + ((ND + nd) * TILE_BYTES + kb * 4096));
+          for (int s = 0; s < 4; ++s) {
+            if (nd == 0) vfr[kb][s] = vfr0[kb][s];            // requested before the S products
+            else vfr[kb][s] = *(const bf16x8*)(smem + rfc[s] + ((ND + nd) * TILE_BYTES + kb * 4096));
+          }
+        if (nd == ND - 1) {                                    // the dQ product's transposed K fragments: under dP and the exponentials
+#pragma unroll
+          for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int db = 0; db < 2; ++db) {
+              if constexpr (USE_TR)
+                tfr1[ks][db] = read_transposed_frag_at(smem + trc[db][0] + ks * 2048, smem + trc[db][1] + ks * 2048);
+              else tfr1[ks][db] = read_transposed_frag<false>(Ks + chunk * TILE_BYTES, ks * 16, db * 32, lane);
+            }
+        }
         __builtin_amdgcn_sched_barrier(0);
+        MFMA_PRIO_ON();
 #pragma unroll
         for (int s = 0; s < 4; ++s)
 #pragma unroll
           for (int kb = 0; kb < 2; ++kb)
             dpacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfr[kb][s], dof[MODE == 1 ? nd : 0][s],
                                                                 (nd == 0 && s == 0) ? negd : dpacc[kb], 0, 0, 0);
+        MFMA_PRIO_OFF();
+      }
+      if (kv0 + 64 > skv_b) {                                    // uniform: only the tile that holds masked keys
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int key = kv0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+            sacc[kb][r] = key < skv_b ? sacc[kb][r] : -INFINITY;   // P = exp2(-inf) = 0
+          }
+        __builtin_amdgcn_sched_barrier(0);                         // (keeps the compiler from if-converting the block into 64 selects per tile)
       }
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const int key = kv0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
-          float pr = fast_exp2(fmaf(sacc[kb][r], c, -lse2));
-          if (kv0 + 64 > skv_b) pr = key < skv_b ? pr : 0.f;      // uniform branch: only tiles holding masked keys
+          const float pr = fast_exp2(sacc[kb][r]);                 // S^T came out of the MFMA as c s - lse2 (C operand)
           sacc[kb][r] = pr * dpacc[kb][r];                         // = P (dP - delta); x scale in the epilogue
         }
     }
@@ -434,17 +506,20 @@ __device__ __forceinline__ void attn_q_body(const AttnP& p, char* smem, int blk_
       for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
         for (int db = 0; db < 2; ++db) {
+          if constexpr (MODE == 1) { tfr[ks][db] = tfr1[ks][db]; continue; }
           if constexpr (USE_TR)
             tfr[ks][db] = read_transposed_frag_at(smem + trc[db][0] + (no * TILE_BYTES + ks * 2048),
                                                   smem + trc[db][1] + (no * TILE_BYTES + ks * 2048));
           else tfr[ks][db] = read_transposed_frag<false>(Ts, ks * 16, db * 32, lane);
         }
       __builtin_amdgcn_sched_barrier(0);
+      MFMA_PRIO_ON();
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
         for (int db = 0; db < 2; ++db)
           oacc[2 * no + db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tfr[ks][db], pf[ks], oacc[2 * no + db], 0, 0, 0);
+      MFMA_PRIO_OFF();
     }
     WAIT_VM0();
     __syncthreads();
@@ -456,7 +531,7 @@ __device__ __forceinline__ void attn_q_body(const AttnP& p, char* smem, int blk_
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
     inv = 1.f / l_tot;
     if (p.lse && qvalid && fh == 0)
-      p.lse[((long long)b * p.H + head) * p.Sq + qrow] = m_run * p.scale + log2f(l_tot) * 0.6931471805599453f;
+      p.lse[((long long)b * p.H + head) * p.Sq + qrow] = (m_run + log2f(l_tot)) * 0.6931471805599453f;
   }
   // The accumulator layout has a query row per lane: written straight out that is eight 8-byte stores per lane, each
   // touching 32 different 128-byte lines.  The wave's 32 x 64 block goes through an LDS image instead (its own 4.5 KiB of
@@ -552,7 +627,9 @@ __device__ __forceinline__ void attn_dkv_body(const AttnP& p, char* smem, int bl
   for (int nd = 0; nd < ND; ++nd)
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
+      // K is only the operand of S here (dK^T = Q^T dS uses the staged Q tiles): it carries scale * log2(e)
       kf[nd][s] = *(const bf16x8*)(Kb + (long long)krow * p.ldk + nd * 64 + 16 * s + 8 * fh);
+      if (!p.q_prescaled) kf[nd][s] = scale_frag(kf[nd][s], c);        // (a prescaled Q tile already carries the factor)
       vf[nd][s] = *(const bf16x8*)(Vb + (long long)krow * p.ldv + nd * 64 + 16 * s + 8 * fh);
     }
   f32x16 dk[2], dv[2];
@@ -560,9 +637,7 @@ __device__ __forceinline__ void attn_dkv_body(const AttnP& p, char* smem, int bl
   for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int r = 0; r < 16; ++r) dk[i][r] = dv[i][r] = 0.f;
-  f32x16 kmask;                                // C operand of the S products: 0, or -inf on the lane of a padding key
-#pragma unroll
-  for (int r = 0; r < 16; ++r) kmask[r] = kvalid ? 0.f : -INFINITY;
+  const bool all_valid = __all(kvalid);        // wave-uniform: no padding key among this wave's 32
 
   TileSrc qsrc[ND], dosrc[ND];
 #pragma unroll
@@ -604,37 +679,74 @@ __device__ __forceinline__ void attn_dkv_body(const AttnP& p, char* smem, int bl
     }
     if (wave_active) {
       // S[q][key] = Q . K^T ; dP[q][key] = dO . V^T   (rows q in registers, key on the lane).  Both accumulations start
-      // from a C operand instead of zero: S from kmask (0, or -inf for a padding key: P = 0 without a select per score), dP
-      // from the staged -delta[q] (row q = register index: the four 16-byte LDS loads ARE the MFMA's C operand)
+      // from a C operand instead of zero -- the staged row constants (row q = register index: the four 16-byte LDS loads ARE
+      // the MFMA's C operand): S from -lse[q] * log2(e) (-inf on the lane of a padding key: P = 0 without a select per
+      // score), dP from -delta[q].  With scale * log2(e) in the K fragments, P = exp2(S) as the MFMA leaves it.
+      // LDS reads run one step ahead of the MFMAs that consume them (registers: two buffers of row fragments, two of
+      // transposed fragments): as read -> wait -> MFMA pairs (what the fused loop compiled to) every pair of MFMAs stood
+      // behind an LDS round trip, and with two waves per SIMD nothing covers it -- a key tile took 2.6 k cycles of its SIMD
+      // for 1 k cycles of matrix work.
       f32x16 sacc[2], dpacc[2];
-#pragma unroll
-      for (int qb = 0; qb < 2; ++qb) {
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const f32x4 d4 = *(const f32x4*)(rc + 64 + qb * 32 + 8 * g + 4 * fh);
-#pragma unroll
-          for (int j = 0; j < 4; ++j) dpacc[qb][4 * g + j] = d4[j];
-        }
+      bf16x8 rq[2][ND * 4], rd[2][ND * 4];
+      auto load_rows = [&](int buf, int qb) {
 #pragma unroll
         for (int nd = 0; nd < ND; ++nd)
 #pragma unroll
           for (int s = 0; s < 4; ++s) {
-            const bf16x8 qfr = read_row_frag(Qs + nd * TILE_BYTES, qb * 32 + frow, s, fh);
-            sacc[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qfr, kf[nd][s], (nd == 0 && s == 0) ? kmask : sacc[qb], 0, 0, 0);
-            const bf16x8 dfr = read_row_frag(dOs + nd * TILE_BYTES, qb * 32 + frow, s, fh);
-            dpacc[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dfr, vf[nd][s], dpacc[qb], 0, 0, 0);
+            rq[buf][nd * 4 + s] = read_row_frag(Qs + nd * TILE_BYTES, qb * 32 + frow, s, fh);
+            rd[buf][nd * 4 + s] = read_row_frag(dOs + nd * TILE_BYTES, qb * 32 + frow, s, fh);
           }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const f32x4 d4 = *(const f32x4*)(rc + 64 + qb * 32 + 8 * g + 4 * fh);
+          const f32x4 l4 = *(const f32x4*)(rc + qb * 32 + 8 * g + 4 * fh);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            dpacc[qb][4 * g + j] = d4[j];
+            sacc[qb][4 * g + j] = l4[j];
+          }
+        }
+      };
+      bf16x8 dot[2][2][2], qt[2][2][2];          // [k-slice pair][kk][db]
+      auto load_tr = [&](int bt) {
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+          for (int db = 0; db < 2; ++db) {
+            dot[bt][kk][db] = read_transposed_frag<USE_TR>(dOs + chunk * TILE_BYTES, (2 * bt + kk) * 16, db * 32, lane);
+            qt[bt][kk][db] = read_transposed_frag<USE_TR>(Qs + chunk * TILE_BYTES, (2 * bt + kk) * 16, db * 32, lane);
+          }
+      };
+      load_rows(0, 0);
+#pragma unroll
+      for (int qb = 0; qb < 2; ++qb) {
+        if (qb == 0) load_rows(1, 1);
+        else load_tr(0);                          // lands under the second block's MFMAs and the exponentials
+        __builtin_amdgcn_sched_barrier(0);
+        if (!all_valid) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) sacc[qb][r] = kvalid ? sacc[qb][r] : -INFINITY;
+        }
+        MFMA_PRIO_ON();
+#pragma unroll
+        for (int nd = 0; nd < ND; ++nd)
+#pragma unroll
+          for (int s = 0; s < 4; ++s) {
+            sacc[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rq[qb][nd * 4 + s], kf[nd][s], sacc[qb], 0, 0, 0);
+            dpacc[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rd[qb][nd * 4 + s], vf[nd][s], dpacc[qb], 0, 0, 0);
+          }
+        MFMA_PRIO_OFF();
+        __builtin_amdgcn_sched_barrier(0);
       }
       bf16x8 pfr[4], dsfr[4];
 #pragma unroll
       for (int qb = 0; qb < 2; ++qb)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-          const f32x4 l4 = *(const f32x4*)(rc + qb * 32 + 8 * g + 4 * fh);      // -lse * log2(e) of 4 consecutive query rows
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
             const int r = 4 * g + j;
-            const float pr = fast_exp2(fmaf(sacc[qb][r], c, l4[j]));
+            const float pr = fast_exp2(sacc[qb][r]);
             const float ds = pr * dpacc[qb][r];                // P (dP - delta); x scale on the finished dK
             const int ks = qb * 2 + (g >> 1), e = (g & 1) * 4 + j;
             pfr[ks][e] = (bf16)pr;
@@ -642,26 +754,24 @@ __device__ __forceinline__ void attn_dkv_body(const AttnP& p, char* smem, int bl
           }
         }
       // dV^T[d][key] += dO^T[d][q] P[q][key] ;  dK^T[d][key] += Q^T[d][q] dS[q][key]   (d in this block's chunk)
-      // two k-slices (8 transposed fragments = 32 registers, the score registers are free by now) per batch of 8 MFMAs
+      // two k-slices (8 transposed fragments = 32 registers) per batch of 8 MFMAs; the second batch's fragments are read
+      // while the first batch's MFMAs run
+      __builtin_amdgcn_sched_barrier(0);
+      load_tr(1);
+      __builtin_amdgcn_sched_barrier(0);
+      MFMA_PRIO_ON();
 #pragma unroll
-      for (int k2 = 0; k2 < 4; k2 += 2) {
-        bf16x8 dot[2][2], qt[2][2];
+      for (int bt = 0; bt < 2; ++bt) {
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
           for (int db = 0; db < 2; ++db) {
-            dot[kk][db] = read_transposed_frag<USE_TR>(dOs + chunk * TILE_BYTES, (k2 + kk) * 16, db * 32, lane);
-            qt[kk][db] = read_transposed_frag<USE_TR>(Qs + chunk * TILE_BYTES, (k2 + kk) * 16, db * 32, lane);
+            dv[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dot[bt][kk][db], pfr[2 * bt + kk], dv[db], 0, 0, 0);
+            dk[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qt[bt][kk][db], dsfr[2 * bt + kk], dk[db], 0, 0, 0);
           }
         __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-          for (int db = 0; db < 2; ++db) {
-            dv[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dot[kk][db], pfr[k2 + kk], dv[db], 0, 0, 0);
-            dk[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qt[kk][db], dsfr[k2 + kk], dk[db], 0, 0, 0);
-          }
       }
+      MFMA_PRIO_OFF();
     }
     WAIT_VM0();
     __syncthreads();
@@ -670,7 +780,7 @@ __device__ __forceinline__ void attn_dkv_body(const AttnP& p, char* smem, int bl
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) dk[i][r] *= p.scale;
+    for (int r = 0; r < 16; ++r) dk[i][r] *= p.q_prescaled ? 0.6931471805599453f : p.scale;   // dS^T Q' = scale log2(e) dS^T Q
   const int D = 64 * ND;
   if (p.nsplit > 1) {
     float* pr = p.dkv_part + ((((long long)split * p.B + b) * p.H + head) * p.Skv + krow) * 2 * D + chunk * 64;
@@ -766,7 +876,7 @@ __global__ __launch_bounds__(256, 3) void xattn_fwd_kernel(const AttnP p, int up
   attn_block_coords(p.xcd_remap, split, head, b);
   const int nu = (p.Sq + 127) >> 7;
   const int u_begin = split * upw, u_end = min(nu, u_begin + upw);
-  const float c = p.scale * LOG2E;
+  const float c = p.q_prescaled ? 1.f : p.scale * LOG2E;         // prescaled Q: the scores are in the log2 domain already
   const bf16* Qb = p.Q + (long long)b * p.Sq * p.ldq + head * 64;
   const bf16* Kb = p.K + (long long)b * p.Skv * p.ldk + head * 64;
   const bf16* Vb = p.V + (long long)b * p.Skv * p.ldv + head * 64;
@@ -866,7 +976,8 @@ __global__ __launch_bounds__(256, 3) void xattn_fwd_kernel(const AttnP p, int up
       }
     }
     const float inv = 1.f / l_tot;
-    if (qvalid && p.lse && fh == 0) p.lse[((long long)b * p.H + head) * p.Sq + qrow] = mx * p.scale + log2f(l_tot) * 0.6931471805599453f;
+    if (qvalid && p.lse && fh == 0)
+      p.lse[((long long)b * p.H + head) * p.Sq + qrow] = mx * (p.q_prescaled ? 0.6931471805599453f : p.scale) + log2f(l_tot) * 0.6931471805599453f;
     // O leaves through a per-wave LDS image (32 rows x 128 bytes, 144-byte pitch): the accumulator layout has a query row
     // per lane, i.e. eight 8-byte stores per lane that each touch 32 different 128-byte lines; from the image every store
     // instruction writes eight whole rows (16 bytes per lane).  With 77 keys the output is most of this kernel's traffic.
@@ -922,7 +1033,7 @@ __global__ __launch_bounds__(256, 2) void xattn_bwd_kernel(const AttnP p, int up
   attn_block_coords(p.xcd_remap, split, head, b);
   const int nu = (p.Sq + 127) >> 7;
   const int u_begin = split * upw, u_end = min(nu, u_begin + upw);
-  const float c = p.scale * LOG2E;
+  const float c = p.q_prescaled ? 1.f : p.scale * LOG2E;         // prescaled Q: the scores are in the log2 domain already
   const bf16* Qb = p.Q + (long long)b * p.Sq * p.ldq + head * 64;
   const bf16* dOb = p.dO + (long long)b * p.Sq * p.lddo + head * 64;
   const bf16* Ob = p.O + (long long)b * p.Sq * p.ldo + head * 64;
@@ -1160,7 +1271,7 @@ __global__ __launch_bounds__(256, 2) void xattn_bwd_kernel(const AttnP p, int up
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) dk[i][r] *= p.scale;
+    for (int r = 0; r < 16; ++r) dk[i][r] *= p.q_prescaled ? 0.6931471805599453f : p.scale;
   if (p.nsplit > 1) {
     float* pr = p.dkv_part + ((((long long)split * p.B + b) * p.H + head) * p.Skv + krow) * 128;
 #pragma unroll

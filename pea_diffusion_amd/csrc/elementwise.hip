@@ -652,7 +652,7 @@ int launch_pad_gather(const float* src, int N_t, int K_t, int mode, int d, int d
 
 // ---- GEGLU on the INTERLEAVED pre-activation layout hg[r][2i] = h_i, hg[r][2i+1] = gate_i (fused FF-proj epilogue)
 __global__ void geglu_il_kernel(const bf16* __restrict__ hg, const bf16* __restrict__ dy, bf16* __restrict__ out,
-                                long long rows, int inner, int bwd) {
+                                long long rows, int inner, int bwd, int form) {
   const int ck = inner / 4;                       // 4 (h, gate) pairs = one 16-byte chunk of hg
   EW_LOOP(i, rows * ck) {
     const long long r = i / ck;
@@ -669,8 +669,13 @@ __global__ void geglu_il_kernel(const bf16* __restrict__ hg, const bf16* __restr
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const float hf = (float)v[2 * j], gf = (float)v[2 * j + 1], df = (float)d[j];
-        o[2 * j] = (bf16)(df * gelu_erf(gf));
-        o[2 * j + 1] = (bf16)(df * hf * gelu_erf_grad(gf));
+        if (form) {                  // hg holds (gelu(gate), h * gelu'(gate)) (GemmP::stash_grad)
+          o[2 * j] = (bf16)(df * hf);
+          o[2 * j + 1] = (bf16)(df * gf);
+        } else {
+          o[2 * j] = (bf16)(df * gelu_erf(gf));
+          o[2 * j + 1] = (bf16)(df * hf * gelu_erf_grad(gf));
+        }
       }
       *(bf16x8*)(out + r * 2 * inner + 2 * c) = o;
     }
@@ -679,15 +684,15 @@ __global__ void geglu_il_kernel(const bf16* __restrict__ hg, const bf16* __restr
 int launch_geglu_fwd_il(const bf16* hg, bf16* y, long long rows, int inner, hipStream_t s) {
   SHAPECHK(inner % 4 == 0, "geglu: inner %% 4");
   PROF_BEGIN(6, 0.0, 2.0 * 3.0 * rows * inner, s);
-  hipLaunchKernelGGL(geglu_il_kernel, dim3(EW_GRID(rows * (inner / 4))), dim3(256), 0, s, hg, nullptr, y, rows, inner, 0);
+  hipLaunchKernelGGL(geglu_il_kernel, dim3(EW_GRID(rows * (inner / 4))), dim3(256), 0, s, hg, nullptr, y, rows, inner, 0, 0);
   PROF_END(s);
   HIPCHK(hipGetLastError());
   return PEA_OK;
 }
-int launch_geglu_bwd_il(const bf16* hg, const bf16* dy, bf16* dhg, long long rows, int inner, hipStream_t s) {
+int launch_geglu_bwd_il(const bf16* hg, const bf16* dy, bf16* dhg, long long rows, int inner, hipStream_t s, int form) {
   SHAPECHK(inner % 4 == 0, "geglu: inner %% 4");
   PROF_BEGIN(6, 0.0, 2.0 * 5.0 * rows * inner, s);
-  hipLaunchKernelGGL(geglu_il_kernel, dim3(EW_GRID(rows * (inner / 4))), dim3(256), 0, s, hg, dy, dhg, rows, inner, 1);
+  hipLaunchKernelGGL(geglu_il_kernel, dim3(EW_GRID(rows * (inner / 4))), dim3(256), 0, s, hg, dy, dhg, rows, inner, 1, form);
   PROF_END(s);
   HIPCHK(hipGetLastError());
   return PEA_OK;

@@ -15,6 +15,8 @@
 // operand panels).  DESIGN.md section 4 has the measured variant table and what was tried and dropped.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "pea_kernels.h"
 #ifndef PEA_GEMM_BUFFER_DMA
 #define PEA_GEMM_BUFFER_DMA 1
@@ -67,10 +69,23 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x16 (&acc)[NI][
 #pragma unroll
           for (int j = 0; j < 4; ++j) v[j] += (float)rv[j];
         }
+        if (n < p.qscale_cols) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] *= p.qscale;
+        }
         if (p.geglu_y) {            // v = (h_a, gate_a, h_b, gate_b) after bias
           bf16x2 y;
-          y[0] = (bf16)(v[0] * (p.geglu_tanh ? gelu_tanh(v[1]) : gelu_erf(v[1])));
-          y[1] = (bf16)(v[2] * (p.geglu_tanh ? gelu_tanh(v[3]) : gelu_erf(v[3])));
+          if (p.stash_grad) {       // stash (gelu(gate), h * gelu'(gate)): what the backward multiplies d y by
+            float ga, gb, da, db;
+            gelu_val_grad(v[1], ga, da);
+            gelu_val_grad(v[3], gb, db);
+            y[0] = (bf16)(v[0] * ga);
+            y[1] = (bf16)(v[2] * gb);
+            v[1] = v[0] * da; v[0] = ga; v[3] = v[2] * db; v[2] = gb;
+          } else {
+            y[0] = (bf16)(v[0] * (p.geglu_tanh ? gelu_tanh(v[1]) : gelu_erf(v[1])));
+            y[1] = (bf16)(v[2] * (p.geglu_tanh ? gelu_tanh(v[3]) : gelu_erf(v[3])));
+          }
           *(bf16x2*)(p.geglu_y + (long long)m * p.ldy + (n >> 1)) = y;
           if (!p.C || (p.stash_rows > 0 && m >= p.stash_rows)) continue;
         }
@@ -152,10 +167,23 @@ __device__ __forceinline__ void gemm_epilogue16(const GemmP& p, f32x4 (&acc)[NT]
 #pragma unroll
       for (int j = 0; j < 4; ++j) v[j] += (float)rv[j];
     }
+    if (n < p.qscale_cols) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] *= p.qscale;
+    }
     if (p.geglu_y) {            // v = (h_a, gate_a, h_b, gate_b) after bias
       bf16x2 y;
-      y[0] = (bf16)(v[0] * (p.geglu_tanh ? gelu_tanh(v[1]) : gelu_erf(v[1])));
-      y[1] = (bf16)(v[2] * (p.geglu_tanh ? gelu_tanh(v[3]) : gelu_erf(v[3])));
+      if (p.stash_grad) {       // stash (gelu(gate), h * gelu'(gate)): what the backward multiplies d y by
+        float ga, gb, da, db;
+        gelu_val_grad(v[1], ga, da);
+        gelu_val_grad(v[3], gb, db);
+        y[0] = (bf16)(v[0] * ga);
+        y[1] = (bf16)(v[2] * gb);
+        v[1] = v[0] * da; v[0] = ga; v[3] = v[2] * db; v[2] = gb;
+      } else {
+        y[0] = (bf16)(v[0] * (p.geglu_tanh ? gelu_tanh(v[1]) : gelu_erf(v[1])));
+        y[1] = (bf16)(v[2] * (p.geglu_tanh ? gelu_tanh(v[3]) : gelu_erf(v[3])));
+      }
       *(bf16x2*)(p.geglu_y + (long long)m * p.ldy + (n >> 1)) = y;
       if (!p.C || (p.stash_rows > 0 && m >= p.stash_rows)) return false;
     }
@@ -282,7 +310,18 @@ __device__ __forceinline__ void gemm_epilogue16_fast(const GemmP& p, f32x4 (&acc
       for (int j = 0; j < 4; ++j) bq[nt][j] += (float)rvq[nt][j];
   }
   const bool has_res = !LNF && p.res != nullptr;
-  const float alpha = p.alpha;
+  // per-n-tile factors (wave-uniform -> scalar registers): alpha, times qscale for the n-tiles left of qscale_cols; the bias
+  // (+ row vector) quads take the same factor here, once per tile, so the per-value arithmetic stays ONE fma
+  float al[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const float f = (n_base + nt * 16 < p.qscale_cols) ? p.qscale : 1.f;
+    al[nt] = p.alpha * f;
+    if (p.qscale_cols > 0) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) bq[nt][j] *= f;
+    }
+  }
   // folded LayerNorm: per row (c1, c2) = (rstd, -rstd * mean); v = c1 * acc + (c2 * s[n] + t[n])
   f32x4 sq[LNF ? NT : 1];
   float2 st[LNF ? MT : 1];
@@ -294,8 +333,8 @@ __device__ __forceinline__ void gemm_epilogue16_fast(const GemmP& p, f32x4 (&acc
     __builtin_amdgcn_sched_barrier(0);
   }
   auto val = [&](int nt, int mt, int j) -> float {
-    if constexpr (LNF) return st[mt].y * (acc[nt][mt][j] - st[mt].x * sq[nt][j]) + bq[nt][j];
-    else return acc[nt][mt][j] * alpha + bq[nt][j];
+    if constexpr (LNF) return (st[mt].y * (acc[nt][mt][j] - st[mt].x * sq[nt][j])) * al[nt] + bq[nt][j];
+    else return acc[nt][mt][j] * al[nt] + bq[nt][j];
   };
   if (p.geglu_y) {
     // v = (h_a, gate_a, h_b, gate_b) after bias: y = h * gelu(gate) -> geglu_y[m][n / 2]; the pre-activation goes to C
@@ -316,13 +355,26 @@ __device__ __forceinline__ void gemm_epilogue16_fast(const GemmP& p, f32x4 (&acc
 #pragma unroll
         for (int j = 0; j < 4; ++j) v0[j] = val(nt, mt, j);
         union { bf16x2 h; unsigned u; } y0, y1;
-        y0.h[0] = (bf16)(v0[0] * gelu_erf(v0[1]));
-        y0.h[1] = (bf16)(v0[2] * gelu_erf(v0[3]));
+        // y = h * gelu(gate); with stash_grad the stashed pair becomes (gelu(gate), h * gelu'(gate)) -- the two factors the
+        // backward multiplies d y by (one erf for both; only for rows that are stashed)
+        auto geglu2 = [&](float (&v)[4], bf16x2& y) {
+          if (stash && p.stash_grad) {
+            float ga, gb, da, db;
+            gelu_val_grad(v[1], ga, da);
+            gelu_val_grad(v[3], gb, db);
+            y[0] = (bf16)(v[0] * ga);
+            y[1] = (bf16)(v[2] * gb);
+            v[1] = v[0] * da; v[0] = ga; v[3] = v[2] * db; v[2] = gb;
+          } else {
+            y[0] = (bf16)(v[0] * gelu_erf(v[1]));
+            y[1] = (bf16)(v[2] * gelu_erf(v[3]));
+          }
+        };
+        geglu2(v0, y0.h);
         if (paired) {
 #pragma unroll
           for (int j = 0; j < 4; ++j) v1[j] = val(nt + 1, mt, j);
-          y1.h[0] = (bf16)(v1[0] * gelu_erf(v1[1]));
-          y1.h[1] = (bf16)(v1[2] * gelu_erf(v1[3]));
+          geglu2(v1, y1.h);
           // lane row q4 receives the words of lane rows (q4 & ~1) and (q4 | 1) of n-tile nt + (q4 & 1): 8 contiguous bytes
           const auto w = __builtin_amdgcn_permlane16_swap(y0.u, y1.u, false, false);
           const u32x2 o = {w[0], w[1]};
@@ -374,7 +426,13 @@ __device__ __forceinline__ void gemm_epilogue16_fast(const GemmP& p, f32x4 (&acc
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
             float dh, dg;
-            geglu_pair_bwd((float)pq[mt & 1][nt][2 * j], (float)pq[mt & 1][nt][2 * j + 1], val(nt, mt, j), dh, dg);
+            if (p.gbwd_form) {        // the stash holds (gelu(gate), h * gelu'(gate)): two multiplies
+              const float d = val(nt, mt, j);
+              dh = d * (float)pq[mt & 1][nt][2 * j];
+              dg = d * (float)pq[mt & 1][nt][2 * j + 1];
+            } else {
+              geglu_pair_bwd((float)pq[mt & 1][nt][2 * j], (float)pq[mt & 1][nt][2 * j + 1], val(nt, mt, j), dh, dg);
+            }
             o[2 * j] = (bf16)dh;
             o[2 * j + 1] = (bf16)dg;
           }
@@ -385,54 +443,90 @@ __device__ __forceinline__ void gemm_epilogue16_fast(const GemmP& p, f32x4 (&acc
       return;
     }
   }
-  // residual quads one 16-row block ahead of the arithmetic (two buffers of NT quads): the loads of block mt + 1 are issued
-  // before the stores of block mt, so the wait for them leaves those stores in flight; holding the whole tile's quads
+  // Residual one 16-row block ahead of the arithmetic (two register buffers): the loads of block mt + 1 are issued before
+  // the stores of block mt, so the wait for them leaves those stores in flight; holding the whole tile's residual
   // (MT x NT x 8 bytes per lane) beside the accumulators would not fit the 168-register budget of three waves per SIMD.
-  // res may alias C: a block's quads are read before its own stores are issued and blocks do not overlap.
-  bf16x4 rq[2][NT];
-  auto load_res = [&](int buf, int mt) {
-    const long long mo = (long long)min(m_base + mt * 16 + r16, p.M - 1) * p.ldres;
+  // res may alias C: a block's values are read before its own stores are issued and blocks do not overlap.
+  // The residual is read in the STORE layout -- 16 bytes per lane at the lane's final columns, a row's four lanes covering
+  // 64 contiguous bytes -- and added after the lane exchange, on fp32 values (one rounding, as before): as 8-byte quads in
+  // the accumulator layout a 256 x 160 tile's residual took 20 load instructions per wave and 11.4 k cycles of a CU's load
+  // path when every CU reads its tile at once, in the 16-byte form 12 instructions and 7.6 k (profiles/r03_mem_patterns.log).
+  // nv = the wave tile's n-tiles inside N (a prefix; N % 16 == 0): pairs (0,1), (2,3), ... and, for odd nv, one single tile.
+  const int nv = max(0, min(NT, (p.N - n_base) >> 4));                  // wave-uniform
+  auto body = [&](auto has_res_t) {
+    constexpr bool HR = decltype(has_res_t)::value;
+    constexpr int NP = (NT + 1) / 2;
+    bf16x8 rp[2][HR ? NP : 1];
+    bf16x4 rs[2];
+    auto load_res = [&](int buf, int mt) {
+      const long long mo = (long long)min(m_base + mt * 16 + r16, p.M - 1) * p.ldres;
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) rq[buf][nt] = *(const bf16x4*)(p.res + mo + min(n_base + nt * 16 + 4 * q4, p.N - 4));
-  };
-  if (has_res) load_res(0, 0);
+      for (int pr = 0; pr < NT / 2; ++pr)
+        if (2 * pr + 1 < nv) rp[buf][pr] = *(const bf16x8*)(p.res + mo + n_base + (2 * pr + (q4 & 1)) * 16 + 8 * (q4 >> 1));
+      if (nv & 1) rs[buf] = *(const bf16x4*)(p.res + mo + n_base + (nv - 1) * 16 + 4 * q4);
+    };
+    if (HR) load_res(0, 0);
 #pragma unroll
-  for (int mt = 0; mt < MT; ++mt) {
-    if (has_res && mt + 1 < MT) load_res((mt + 1) & 1, mt + 1);
-    __builtin_amdgcn_sched_barrier(0);
-    const int m = m_base + mt * 16 + r16;
-    if (m < p.M) {                                                     // r16 only: swap partners agree
-      bf16* crow = (bf16*)p.C + (long long)m * p.ldc;
+    for (int mt = 0; mt < MT; ++mt) {
+      if (HR && mt + 1 < MT) load_res((mt + 1) & 1, mt + 1);
+      __builtin_amdgcn_sched_barrier(0);
+      const int m = m_base + mt * 16 + r16;
+      if (m < p.M) {                                                   // r16 only: swap partners agree
+        bf16* crow = (bf16*)p.C + (long long)m * p.ldc;
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt) {
-        const bool paired = (nt & 1) == 0 && nt + 1 < NT && n_base + (nt + 2) * 16 <= p.N;
-        if ((nt & 1) == 1 && n_base + (nt + 1) * 16 <= p.N) continue;                 // stored with its left neighbour
-        if (n_base + nt * 16 >= p.N) continue;
-        union { bf16x4 h; unsigned u[2]; } a, b;
+        for (int nt = 0; nt < NT; ++nt) {
+          if (nt >= nv) continue;
+          const bool paired = (nt & 1) == 0 && nt + 1 < nv;
+          if ((nt & 1) == 1) continue;                                 // an odd tile inside N is stored with its left neighbour
+          if (paired) {
+            if constexpr (HR) {
+              // exchange the fp32 values: element j of lane rows (q4 & ~1) and (q4 | 1) of n-tile nt + (q4 & 1) -> this lane's 8 columns
+              // (inline assembly: with fp32 operands bit-cast in and out of __builtin_amdgcn_permlane16_swap, hipcc 7.2 folds the
+              // second result onto the first -- scripts/ubench/swap_test.hip; the s_nops are the swap's VALU-write hazard)
+              float lo[4], hi[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          float v = val(nt, mt, j);
-          if (has_res) v += (float)rq[mt & 1][nt][j];
-          a.h[j] = (bf16)v;
-        }
-        if (paired) {
+              for (int j = 0; j < 4; ++j) {
+                lo[j] = val(nt, mt, j);
+                hi[j] = val(nt + 1 < NT ? nt + 1 : nt, mt, j);
+                asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(lo[j]), "+v"(hi[j]));
+              }
+              const bf16x8 r8 = rp[mt & 1][nt >> 1];
+              bf16x8 o;
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            float v = val(nt + 1, mt, j);
-            if (has_res) v += (float)rq[mt & 1][nt + 1][j];
-            b.h[j] = (bf16)v;
+              for (int j = 0; j < 4; ++j) {
+                o[j] = (bf16)(lo[j] + (float)r8[j]);
+                o[4 + j] = (bf16)(hi[j] + (float)r8[4 + j]);
+              }
+              *(bf16x8*)(crow + n_base + (nt + (q4 & 1)) * 16 + 8 * (q4 >> 1)) = o;
+            } else {
+              union { bf16x4 h; unsigned u[2]; } a, b;
+#pragma unroll
+              for (int j = 0; j < 4; ++j) {
+                a.h[j] = (bf16)val(nt, mt, j);
+                b.h[j] = (bf16)val(nt + 1 < NT ? nt + 1 : nt, mt, j);
+              }
+              const auto lo = __builtin_amdgcn_permlane16_swap(a.u[0], b.u[0], false, false);
+              const auto hi = __builtin_amdgcn_permlane16_swap(a.u[1], b.u[1], false, false);
+              const u32x4 o = {lo[0], hi[0], lo[1], hi[1]};
+              *(u32x4*)(crow + n_base + (nt + (q4 & 1)) * 16 + 8 * (q4 >> 1)) = o;
+            }
+          } else {                                                     // the single last tile of an odd nv
+            bf16x4 o;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              float v = val(nt, mt, j);
+              if constexpr (HR) v += (float)rs[mt & 1][j];
+              o[j] = (bf16)v;
+            }
+            *(bf16x4*)(crow + n_base + nt * 16 + 4 * q4) = o;
           }
-          const auto lo = __builtin_amdgcn_permlane16_swap(a.u[0], b.u[0], false, false);
-          const auto hi = __builtin_amdgcn_permlane16_swap(a.u[1], b.u[1], false, false);
-          const u32x4 o = {lo[0], hi[0], lo[1], hi[1]};
-          *(u32x4*)(crow + n_base + (nt + (q4 & 1)) * 16 + 8 * (q4 >> 1)) = o;
-        } else {
-          *(bf16x4*)(crow + n_base + nt * 16 + 4 * q4) = a.h;
         }
       }
+      __builtin_amdgcn_sched_barrier(0);
     }
-    __builtin_amdgcn_sched_barrier(0);
-  }
+  };
+  if (has_res) body(std::true_type{});
+  else body(std::false_type{});
 }
 
 // lean slice epilogue for the deferred form: alpha, optional bias, bf16 output (ldc % 8 == 0, C 16-byte aligned: the
@@ -1343,7 +1437,7 @@ static int pick_variant(const GemmP& p) {
   // measured (in-run A/B, profiles/r01_gemm_variants.log): +4..11 % in the hot microbenchmark, nothing in situ -> off
   // unless PEA_GEMM_DEFER is set
   static const bool defer = getenv("PEA_GEMM_DEFER") != nullptr;
-  const bool lean = defer && !p.out_f32 && !p.res && !p.rowvec && !p.act && !p.geglu_y && !p.gbwd_pre && !p.preact && p.ksplit <= 1 &&
+  const bool lean = defer && !p.out_f32 && !p.res && !p.rowvec && !p.act && !p.geglu_y && !p.gbwd_pre && !p.preact && !p.qscale_cols && p.ksplit <= 1 &&
                     p.ldc % 8 == 0 && (((unsigned long long)p.C & 15) == 0);
   if (t128 <= 256) return lean ? 35 : 25;            // exactly one 128x160 tile per CU
   if (t256 <= 256) return t256 > 192 ? 24 : (lean ? 35 : 28);
@@ -1387,7 +1481,10 @@ int launch_gemm(const GemmP& p_in, hipStream_t stream) {
   }
   GemmP p = p_in;
   p.debug = g_gemm_debug;
+  SHAPECHK(p.qscale_cols % 16 == 0 && p.qscale_cols >= 0 && p.qscale_cols <= p.N && (!p.qscale_cols || (!p.act && !p.geglu_y && !p.gbwd_pre && p.ksplit <= 1)),
+           "gemm: qscale_cols=%d must be a multiple of 16 within N, on a plain (no activation / GEGLU / split-K) epilogue", p.qscale_cols);
   int v = pick_variant(p);
+  if (p.qscale_cols && (v == 34 || v == 35)) v = 28;        // the staged / deferred forms carry no column scale
   {
     // wave-tile rows of the 16x16x32 kernels are 32 or 64: a per-sample row vector must not change inside them
     static const bool slow_epi = getenv("PEA_GEMM_SLOW_EPILOGUE") != nullptr;     // A/B switch
@@ -1396,7 +1493,7 @@ int launch_gemm(const GemmP& p_in, hipStream_t stream) {
     p.epi_fast = !slow_epi && !p.out_f32 && p.act == 0 && !p.preact && p.ksplit <= 1 && p.N % 16 == 0 && rv_ok && gg_ok &&
                  (p.geglu_y ? (!p.C || (p.ldc % 8 == 0 && (((unsigned long long)p.C & 15) == 0)))
                             : (p.ldc % 8 == 0 && (((unsigned long long)p.C & 15) == 0))) &&
-                 (!p.res || (p.ldres % 4 == 0 && (((unsigned long long)p.res & 7) == 0)));
+                 (!p.res || (p.ldres % 8 == 0 && (((unsigned long long)p.res & 15) == 0)));      // residual read as 16-byte pieces
   }
   if (p.ksplit > 1) {
     SHAPECHK(p.out_f32 && !p.accum_f32 && !p.bias && !p.res && !p.rowvec && !p.preact && p.act == 0 && p.mode == 0,

@@ -120,6 +120,8 @@ struct Op {
   int src = 0;                    // OP_TEMB: 0 = timesteps, 1 = time_ids
   int mask = 0;                   // OP_ATTN: 1 causal, 2 per-sample key count (text encoders), 4 additive T5 position bias
   int fold = -1;                  // OP_LN / OP_LINEAR: index into Tape::folds (LayerNorm folded into the consuming Linear)
+  int qs_cols = 0; float qs = 1.f; // OP_LINEAR: output columns [0, qs_cols) leave multiplied by qs (the Q block of an attention's projection)
+  int pre = 0;                    // OP_ATTN: Q arrives multiplied by scale * log2(e) (Tape::tag_q_prescale)
 };
 
 // The static op tape: tensors, weight slots and ops of ONE graph, built once per (config, batch, size).  graph selects the
@@ -186,6 +188,7 @@ struct Tape {
   int* cross_kvlen = nullptr;        // graph 0: per-sample valid context tokens of the cross-attention (merged passes with a shorter
                                      // student context; rows beyond it in t_ehs are zero padding), null = all L
   int exec_ops(size_t begin, size_t end, bool skip_cached, hipStream_t s);
+  void tag_q_prescale();
   int ensure_acts();                 // lazy allocation of the activation / gradient arenas and scratch
   int alloc();
   int load_weight(const char* name, const float* dev_ptr, long long numel, hipStream_t s);

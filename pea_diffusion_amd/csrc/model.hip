@@ -718,7 +718,38 @@ int Tape::build() {
   return PEA_OK;
 }
 
+// Every flash-attention op takes its Q from the projection right in front of it (fused Q|K|V: columns [0, C); to_q: the
+// whole output) and nothing else reads that block: the projection's epilogue multiplies it by softmax_scale * log2(e)
+// (GemmP::qscale: one rounding, from the fp32 accumulator) and the attention kernels run in the log2 domain without a
+// per-score multiply (AttnP::q_prescaled).  The attention backward returns the gradient w.r.t. the unscaled q, so the
+// projection's data-gradient GEMM is unchanged.
+void Tape::tag_q_prescale() {
+  static const bool off = getenv("PEA_ATTN_NO_PRESCALE") != nullptr;          // A/B switch
+  if (off) return;
+  for (size_t i = 0; i < ops.size(); ++i) {
+    Op& a = ops[i];
+    if (a.kind != OP_ATTN || a.pre || a.acol != 0) continue;
+    int prod = -1, readers = 0;
+    for (size_t j = 0; j < ops.size(); ++j) {
+      const Op& o = ops[j];
+      if (o.out == a.a && j < i) prod = (int)j;
+      if (j != i && (o.a == a.a || o.res == a.a || o.rv == a.a || (o.kind != OP_LINEAR && (o.b == a.a || o.c == a.a)))) {
+        // the attention itself may read K / V from the same tensor (fused Q|K|V): other columns, not a reader of the Q block
+        ++readers;
+      }
+    }
+    if (prod < 0 || readers) continue;
+    Op& l = ops[prod];
+    const int qcols = 64 * a.p3 * a.p0;                                       // heads x padded head width
+    if (l.kind != OP_LINEAR || l.p2 != 0 || l.p3 == 3 || l.p3 == 2 || l.res >= 0 || l.qs_cols || qcols % 16 || qcols > tn[l.out].cols) continue;
+    l.qs_cols = qcols;
+    l.qs = a.f0 * 1.4426950408889634f;
+    a.pre = 1;
+  }
+}
+
 int Tape::alloc() {
+  tag_q_prescale();
   // ---- weights
   size_t off = 0;
   size_t max_numel = 0;
@@ -1013,6 +1044,13 @@ int Tape::all_loaded(std::string* missing) const {
 
 // ============================================================================ forward
 static void fill_gemm(GemmP& p) { memset(&p, 0, sizeof(p)); p.alpha = 1.f; p.rows_per_batch = 1; }
+// What a fused-GEGLU projection (op.p3 == 3 with a stash tensor op.c) leaves in its stash: 1 = (gelu(gate), h * gelu'(gate)),
+// the two factors of the backward (GemmP::stash_grad); 0 = the raw (h, gate) pre-activation -- the tanh form (no backward
+// exists for it) and the PEA_GEGLU_UNFUSED experiment, whose separate GEGLU kernel reads the pre-activation.
+static bool g_geglu_unfused = getenv("PEA_GEGLU_UNFUSED") != nullptr;
+static int geglu_stash_form(const Op& o) {
+  return (o.p3 == 3 && o.c >= 0 && o.p1 == 0 && !(g_geglu_unfused && o.fold < 0)) ? 1 : 0;
+}
 
 int Tape::forward(const float* x, const float* t, const void* ehs, int ehs_dtype, const void* text, int text_dtype,
                   const float* time_ids, float* eps, hipStream_t s) {
@@ -1066,10 +1104,12 @@ int Tape::exec_ops(size_t begin, size_t end, bool skip_cached, hipStream_t s) {
         if (o.fused >= 0) { FusedMat& f = fused[o.fused]; p.W = f.w; p.ldw = f.K; p.bias = f.bias; }
         else { WSlot& w = slots[o.w]; p.W = w.w; p.ldw = w.ldw; p.bias = o.bias >= 0 ? slots[o.bias].f32 : nullptr; }
         p.C = out.d; p.ldc = out.cols; p.act = o.p2;
+        p.qscale_cols = o.qs_cols; p.qscale = o.qs;
         if (o.p3 == 3) {                  // fused GEGLU: N = 8C interleaved, y -> out, pre-activation -> op.c (student only)
           p.N = 2 * out.cols; p.geglu_y = out.d; p.ldy = out.cols; p.geglu_tanh = o.p1;
           p.C = o.c >= 0 ? tn[o.c].d : nullptr; p.ldc = 2 * out.cols;
           if (bwd_batch > 0) p.stash_rows = (int)(out.rows / B * bwd_batch);   // only the differentiated samples are stashed
+          p.stash_grad = geglu_stash_form(o);
         }
         if (o.res >= 0) { p.res = tn[o.res].d; p.ldres = tn[o.res].cols; }
         if (o.fold >= 0) {                // folded LayerNorm: the GEMM reads the un-normalised rows
@@ -1077,8 +1117,7 @@ int Tape::exec_ops(size_t begin, size_t end, bool skip_cached, hipStream_t s) {
           p.A = tn[ops[f.ln_op].a].d; p.W = f.wf; p.ldw = f.K; p.bias = f.t;
           p.ln_stats = ops[f.ln_op].aux; p.ln_s = f.s;
         }
-        static const bool geglu_unfused = getenv("PEA_GEGLU_UNFUSED") != nullptr;   // A/B switch for experiments
-        if (o.p3 == 3 && geglu_unfused && o.c >= 0 && o.fold < 0) {
+        if (o.p3 == 3 && g_geglu_unfused && o.c >= 0 && o.fold < 0) {      // A/B switch for experiments
           p.geglu_y = nullptr; p.stash_rows = 0;
           RC(launch_gemm(p, s));
           RC(launch_geglu_fwd_il(tn[o.c].d, out.d, out.rows, out.cols, s));
@@ -1172,6 +1211,7 @@ int Tape::exec_ops(size_t begin, size_t end, bool skip_cached, hipStream_t s) {
         p.V = tn[o.c].d + o.ccol; p.ldv = tn[o.c].cols; p.O = tn[o.out].d; p.ldo = tn[o.out].cols; p.lse = o.aux;
         p.B = B; p.H = o.p0; p.Sq = o.p1; p.Skv = o.p2; p.scale = o.f0; p.nd = o.p3;
         p.causal = o.mask & 1; p.kv_len = (o.mask & 2) ? kvlen : nullptr;
+        p.q_prescaled = o.pre;
         if (o.mask & 4) p.bias = rel_bias;
         if (cross_kvlen && o.b == t_kvall) p.kv_len = cross_kvlen;
         RC(launch_attention_fwd(p, s));
@@ -1268,7 +1308,7 @@ int Tape::backward(const float* deps, hipStream_t s) {
         }
         if (a.rg && o.p3 == 3) {          // fused GEGLU: d(pre-activation) into scratch, then the dgrad GEMM over K = 8C
           Tn& hg = tn[o.c];
-          if (dpre_of != o.out) RC(launch_geglu_bwd_il(hg.d, out.g, geglu_tmp, rb(out), out.cols, s));
+          if (dpre_of != o.out) RC(launch_geglu_bwd_il(hg.d, out.g, geglu_tmp, rb(out), out.cols, s, geglu_stash_form(o)));
           dpre_of = -1;
           WSlot& w = slots[o.w];
           GemmP p; fill_gemm(p);
@@ -1293,7 +1333,7 @@ int Tape::backward(const float* deps, hipStream_t s) {
           if (g_geglu_bwd_fused && prev && prev->kind == OP_LINEAR && prev->p3 == 3 && prev->out == o.a && prev->c >= 0 &&
               tn[prev->a].rg && !a.gw && !a.gpend && geglu_tmp && a.cols % 16 == 0) {
             Tn& hg = tn[prev->c];
-            p.gbwd_pre = hg.d; p.ldgp = hg.cols;
+            p.gbwd_pre = hg.d; p.ldgp = hg.cols; p.gbwd_form = geglu_stash_form(*prev);
             p.C = geglu_tmp; p.ldc = hg.cols;
             RC(launch_gemm(p, s));
             a.gw = true;
@@ -1380,7 +1420,7 @@ int Tape::backward(const float* deps, hipStream_t s) {
         AttnP p; memset(&p, 0, sizeof(p));
         p.Q = q.d + o.acol; p.ldq = q.cols; p.K = k.d + o.bcol; p.ldk = k.cols; p.V = v.d + o.ccol; p.ldv = v.cols;
         p.O = out.d; p.ldo = out.cols; p.lse = o.aux; p.B = Bb; p.H = o.p0; p.Sq = o.p1; p.Skv = o.p2; p.scale = o.f0;
-        p.nd = o.p3;
+        p.nd = o.p3; p.q_prescaled = o.pre;
         p.dO = out.g; p.lddo = out.cols; p.delta = delta; p.dkv_part = attn_part;
         if (cross_kvlen && o.b == t_kvall) p.kv_len = cross_kvlen;
         SHAPECHK(!q.gw && !q.gpend && !k.gpend && (!k.gw || o.b == t_kvall), "unet: attention operand gradient written twice");

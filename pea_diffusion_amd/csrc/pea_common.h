@@ -72,6 +72,13 @@ __device__ __forceinline__ float gelu_erf_grad(float x) {
   const float er = erf_fast(x * 0.70710678118654752f, &e);
   return 0.5f * (1.0f + er) + x * 0.39894228040143268f * e;
 }
+// gelu(g) and gelu'(g) from one erf evaluation (the forward's stash_grad form)
+__device__ __forceinline__ void gelu_val_grad(float g, float& val, float& grad) {
+  float e;
+  const float phi = 0.5f * (1.0f + erf_fast(g * 0.70710678118654752f, &e));
+  val = g * phi;
+  grad = phi + g * 0.39894228040143268f * e;
+}
 // backward of y = h * gelu(gate) for one pair, one erf for both factors: dh = d * gelu(gate), dgate = d * h * gelu'(gate)
 __device__ __forceinline__ void geglu_pair_bwd(float h, float g, float d, float& dh, float& dg) {
   float e;

@@ -33,6 +33,9 @@ struct GemmP {
   bf16* geglu_y; int ldy;
   int geglu_tanh;                  // GEGLU gate activation: 0 = GELU(erf) (diffusers GEGLU), 1 = gelu_new / tanh form (T5 v1.1 gated-gelu)
   int stash_rows;                  // GEGLU with a stash: rows >= stash_rows (> 0) skip the C store (merged passes: teacher rows)
+  int stash_grad;                  // 1: the stash holds what the BACKWARD multiplies by, (gelu(gate), h * gelu'(gate)), instead of (h, gate):
+                                   // nothing else ever reads it (no weight gradients), the forward has erf and exp(-g^2/2) at hand
+                                   // anyway, and the backward epilogue becomes two multiplies per pair instead of an erf evaluation
   int ksplit; long long split_stride;   // split-K: fp32 partial s is written at C + s*split_stride (then launch_splitk_reduce)
   int epi_fast;                    // set by launch_gemm: the batched-load epilogue (gemm_epilogue16_fast) applies
   // folded LayerNorm on the A operand (A = the UN-normalised rows, W = W' = W.gamma, bias = t):
@@ -42,6 +45,11 @@ struct GemmP {
   // the stashed (h, gate); C becomes [M][2N] (ldc >= 2N): C[m][2n] = dy * gelu(gate), C[m][2n+1] = dy * h * gelu'(gate).
   // Needs epi_fast (bf16 output, no activation / residual / row vector).
   const bf16* gbwd_pre; int ldgp;
+  // Column-range output scale: columns n < qscale_cols are multiplied by qscale after alpha, bias and the row vector (n-tile
+  // granular: qscale_cols % 16 == 0).  The fused Q|K|V (or to_q) projection hands the attention kernels Q already multiplied by
+  // softmax_scale * log2(e) -- ONE rounding from the fp32 accumulator -- so their scores leave the MFMA in the log2 domain.
+  int qscale_cols; float qscale;
+  int gbwd_form;                   // 0: gbwd_pre = (h, gate);  1: gbwd_pre = (gelu(gate), h * gelu'(gate))  (a stash_grad forward)
 };
 int launch_splitk_reduce(const float* part, int nsplit, long long stride, bf16* out, int ldo, int M, int N, int accum,
                          hipStream_t s);
@@ -97,6 +105,8 @@ struct AttnP {
   int xcd_remap;                   // set by the launchers: XCD-aware workgroup order
   int causal;                      // forward only: key index <= query index (text encoders)
   const int* kv_len;               // per-sample number of valid keys (key padding mask; forward and backward), may be null
+  int q_prescaled;                 // Q already holds q * scale * log2(e) (GemmP::qscale in the producing projection): scores leave the
+                                   // MFMA in the log2 domain with no further rounding; dQ is still the gradient w.r.t. the UNSCALED q
   const float* bias;               // forward, masked instance only: additive score bias [H][Sq][Skv] in the LOG2 domain (T5 relative positions), may be null
 };
 int attention_bwd_nsplit(int B, int H, int Sq, int Skv);
@@ -194,7 +204,7 @@ void prof_end_impl(hipStream_t s);
 int launch_prefetch(const void* p, long long bytes, int* sink, hipStream_t s);
 int launch_pad_gather(const float* src, int N_t, int K_t, int mode, int d, int dp, bf16* w, int ldw, bf16* wt, int ldwt,
                       int st_n, int st_k, hipStream_t s);
-int launch_geglu_bwd_il(const bf16* hg, const bf16* dy, bf16* dhg, long long rows, int inner, hipStream_t s);
+int launch_geglu_bwd_il(const bf16* hg, const bf16* dy, bf16* dhg, long long rows, int inner, hipStream_t s, int form = 0);
 int launch_geglu_fwd_il(const bf16* hg, bf16* y, long long rows, int inner, hipStream_t s);
 int launch_permute_geglu_vec(const float* src, float* dst, int inner, hipStream_t s);
 // sampler.hip: inference denoise-loop glue

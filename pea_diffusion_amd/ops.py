@@ -34,14 +34,27 @@ def gemm(a, w, bias=None, rowvec=None, rows_per_batch=1, act=0, res=None, want_p
     return (out, pre) if want_preact else out
 
 
-def gemm_geglu_bwd(a, w, pre):
+def gemm_geglu(a, w, bias=None, want_stash=True, stash_grad=True, stash_rows=0):
+    """FF projection with GEGLU in its epilogue (pea_op_gemm_geglu): w [N,K] rows interleaved (h_i, gate_i);
+    returns (h * gelu(gate) [M,N/2], stash [M,N] or None).  stash_grad: the stash holds (gelu(gate), h * gelu'(gate))."""
+    M, K = a.shape
+    N = w.shape[0]
+    y = torch.empty(M, N // 2, device=a.device, dtype=BF)
+    st = torch.zeros(M, N, device=a.device, dtype=BF) if want_stash else None
+    check(lib().pea_op_gemm_geglu(ptr(a), a.stride(0), ptr(w), w.stride(0), ptr(bias), ptr(y), ptr(st), M, N, K,
+                                  int(stash_grad), stash_rows, stream_ptr()))
+    return y, st
+
+
+def gemm_geglu_bwd(a, w, pre, form=0):
     """dgrad GEMM of the FF output projection with the GEGLU backward in its epilogue (pea_op_gemm_geglu_bwd):
-    dy = a @ w.T ([M,N], never stored); pre [M,2N] interleaved (h, gate) -> d(pre) [M,2N] interleaved (dh, dgate)."""
+    dy = a @ w.T ([M,N], never stored); pre [M,2N] interleaved (h, gate) [form 0] or (gelu(gate), h gelu'(gate)) [form 1]
+    -> d(pre) [M,2N] interleaved (dh, dgate)."""
     M, K = a.shape
     N = w.shape[0]
     out = torch.empty(M, 2 * N, device=a.device, dtype=BF)
     check(lib().pea_op_gemm_geglu_bwd(ptr(a), a.stride(0), ptr(w), w.stride(0), ptr(pre), pre.stride(0), ptr(out), out.stride(0),
-                                      M, N, K, stream_ptr()))
+                                      M, N, K, form, stream_ptr()))
     return out
 
 
@@ -149,15 +162,27 @@ def layernorm_bwd(x, dy, gamma, stats, want_param_grads=False, accum_into=None):
     return (dx, dg, db) if want_param_grads else dx
 
 
-def attention_fwd(q, k, v, heads, scale=None):
-    """q [B,Sq,H*D], k/v [B,Skv,H*D] bf16 (D = 64, 128 or 192: zero-padded heads) -> (o, lse [B,H,Sq])."""
+def gemm_qscale(a, w, bias=None, qscale_cols=0, qscale=1.0):
+    """a @ w.T + bias with the first qscale_cols output columns multiplied by qscale (the Q block of a fused Q|K|V projection)"""
+    M, K = a.shape
+    N = w.shape[0]
+    out = torch.empty(M, N, device=a.device, dtype=BF)
+    check(lib().pea_op_gemm_qscale(ptr(a), a.stride(0), ptr(w), w.stride(0), ptr(out), out.stride(0), M, N, K, ptr(bias),
+                                   qscale_cols, qscale, stream_ptr()))
+    return out
+
+
+def attention_fwd(q, k, v, heads, scale=None, q_prescaled=False):
+    """q [B,Sq,H*D], k/v [B,Skv,H*D] bf16 (D = 64, 128 or 192: zero-padded heads) -> (o, lse [B,H,Sq]).
+    q_prescaled: q already holds (unscaled q) * scale * log2(e)."""
     B, Sq, C = q.shape
     Skv = k.shape[1]
     nd = C // heads // 64
     scale = scale if scale is not None else (C // heads) ** -0.5
     o = torch.empty(B, Sq, C, device=q.device, dtype=BF)
     lse = torch.empty(B, heads, Sq, device=q.device, dtype=torch.float32)
-    check(lib().pea_op_attention_fwd(ptr(q), q.stride(1), ptr(k), k.stride(1), ptr(v), v.stride(1), ptr(o), C, ptr(lse),
+    fn = lib().pea_op_attention_fwd_prescaled if q_prescaled else lib().pea_op_attention_fwd
+    check(fn(ptr(q), q.stride(1), ptr(k), k.stride(1), ptr(v), v.stride(1), ptr(o), C, ptr(lse),
                                      B, heads, Sq, Skv, scale, nd, stream_ptr()))
     return o, lse
 
@@ -173,7 +198,8 @@ def attention_fwd_masked(q, k, v, heads, causal=False, kv_len=None, scale=None):
     return o
 
 
-def attention_bwd(q, k, v, o, do, lse, heads, scale=None):
+def attention_bwd(q, k, v, o, do, lse, heads, scale=None, q_prescaled=False):
+    """-> (dq, dk, dv); with q_prescaled dq is still the gradient w.r.t. the UNSCALED q"""
     B, Sq, C = q.shape
     Skv = k.shape[1]
     nd = C // heads // 64
@@ -182,7 +208,8 @@ def attention_bwd(q, k, v, o, do, lse, heads, scale=None):
     delta = torch.empty(2, B, heads, Sq, device=q.device, dtype=torch.float32)     # scratch: -delta and -lse*log2(e) per row
     nb = lib().pea_op_attention_bwd_scratch_bytes(B, heads, Sq, Skv, nd)
     scratch = torch.empty(nb, device=q.device, dtype=torch.uint8) if nb else None
-    check(lib().pea_op_attention_bwd(ptr(q), q.stride(1), ptr(k), k.stride(1), ptr(v), v.stride(1), ptr(o), C, ptr(do),
+    fn = lib().pea_op_attention_bwd_prescaled if q_prescaled else lib().pea_op_attention_bwd
+    check(fn(ptr(q), q.stride(1), ptr(k), k.stride(1), ptr(v), v.stride(1), ptr(o), C, ptr(do),
                                      C, ptr(lse), ptr(delta), ptr(dq), C, ptr(dk), C, ptr(dv), C, B, heads, Sq, Skv,
                                      scale, 0, 0, nd, ptr(scratch), stream_ptr()))
     return dq, dk, dv

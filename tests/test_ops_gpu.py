@@ -226,22 +226,58 @@ def test_conv_in_out(ops):
     close_bf16("conv_out dgrad", ops.conv_out_dgrad(dy.cuda(), wp, C), _nhwc(hh.grad))
 
 
+def _geglu_factors(pre):
+    """(h, gate) interleaved fp32 -> gelu(gate), h * gelu'(gate)"""
+    h, gate = pre[:, 0::2], pre[:, 1::2]
+    phi = 0.5 * (1.0 + torch.erf(gate / 2 ** 0.5))
+    return gate * phi, h * (phi + gate * torch.exp(-0.5 * gate * gate) / (2 * torch.pi) ** 0.5)
+
+
+@pytest.mark.parametrize("form", [0, 1])
 @pytest.mark.parametrize("M,N,K", [(4096, 5120, 1280), (2048, 2560, 640), (384, 1280, 320), (1000, 5120, 1280)])
-def test_gemm_with_geglu_backward_epilogue(ops, M, N, K):
+def test_gemm_with_geglu_backward_epilogue(ops, M, N, K, form):
     """The FF output projection's dgrad with the GEGLU backward in its epilogue (d y never stored) against fp32 torch:
-    the three tile instantiations (256x160 persistent at 512 tiles, 128x160, 64x160) and a ragged row count."""
+    the three tile instantiations (256x160 persistent at 512 tiles, 128x160, 64x160) and a ragged row count; both stash
+    forms -- 0: the pre-activation (h, gate), 1: the backward's own factors (gelu(gate), h gelu'(gate))."""
     g = torch.Generator().manual_seed(M + N)
     a = (torch.randn(M, K, generator=g) * 0.5).to(BF)
     w = (torch.randn(N, K, generator=g) / K ** 0.5).to(BF)
     pre = (torch.randn(M, 2 * N, generator=g) * 1.2).to(BF)
-    got = ops.gemm_geglu_bwd(a.cuda(), w.cuda(), pre.cuda())
     dy = a.float() @ w.float().t()
-    h, gate = pre.float()[:, 0::2], pre.float()[:, 1::2]
-    phi = 0.5 * (1.0 + torch.erf(gate / 2 ** 0.5))
-    dh = dy * gate * phi
-    dg = dy * h * (phi + gate * torch.exp(-0.5 * gate * gate) / (2 * torch.pi) ** 0.5)
-    ref = torch.stack([dh, dg], -1).reshape(M, 2 * N)
-    close_bf16(f"gemm + geglu bwd {M}x{N}x{K}", got, ref)
+    fa, fb = _geglu_factors(pre.float())
+    if form == 1:                                # the forward stored the two factors, rounded to bf16
+        stash = torch.stack([fa, fb], -1).reshape(M, 2 * N).to(BF)
+        fa, fb = stash.float()[:, 0::2], stash.float()[:, 1::2]
+        got = ops.gemm_geglu_bwd(a.cuda(), w.cuda(), stash.cuda(), form=1)
+    else:
+        got = ops.gemm_geglu_bwd(a.cuda(), w.cuda(), pre.cuda())
+    ref = torch.stack([dy * fa, dy * fb], -1).reshape(M, 2 * N)
+    close_bf16(f"gemm + geglu bwd form {form} {M}x{N}x{K}", got, ref)
+
+
+@pytest.mark.parametrize("stash_grad", [1, 0])
+@pytest.mark.parametrize("M,N,K", [(8192, 10240, 1280), (1000, 2560, 320), (256, 1280, 640)])
+def test_gemm_geglu_forward_and_stash_forms(ops, M, N, K, stash_grad):
+    """GEGLU in the FF projection's epilogue (diffusers GEGLU.forward) and what it leaves for the backward: the
+    pre-activation (h, gate), or -- stash_grad -- the backward's factors (gelu(gate), h gelu'(gate)); rows >= stash_rows
+    (the teacher half of a merged pass) are not stashed."""
+    g = torch.Generator().manual_seed(M + K)
+    a = (torch.randn(M, K, generator=g)).to(BF)
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).to(BF)
+    bias = torch.randn(N, generator=g) * 0.1
+    rows = M // 2 if M % 128 == 0 else 0
+    y, st = ops.gemm_geglu(a.cuda(), w.cuda(), bias.cuda(), stash_grad=bool(stash_grad), stash_rows=rows)
+    pre = a.float() @ w.float().t() + bias
+    close_bf16(f"gemm geglu y {M}x{N}x{K}", y, pre[:, 0::2] * F.gelu(pre[:, 1::2]), ulps=2.0)
+    if stash_grad:
+        fa, fb = _geglu_factors(pre)
+        ref = torch.stack([fa, fb], -1).reshape(M, N)
+    else:
+        ref = pre
+    n = rows if rows else M
+    close_bf16(f"gemm geglu stash (grad form {stash_grad}) {M}x{N}x{K}", st[:n], ref[:n], ulps=2.0)
+    if rows:
+        assert float(st[rows:].float().abs().max()) == 0.0          # teacher rows: never written
 
 
 @pytest.mark.parametrize("B,H,W,C,Cout", [(2, 32, 32, 320, 4), (1, 12, 20, 128, 3), (3, 8, 24, 512, 8), (1, 40, 40, 64, 4),
@@ -322,26 +358,38 @@ def _attn_ref(q, k, v, H):
     return o, torch.logsumexp(s, -1)
 
 
+ALPHA = 0.125 * math.log2(math.e)        # softmax scale x log2(e): what a prescaled Q carries (head_dim 64)
+
+
+@pytest.mark.parametrize("prescaled", [True, False])
 @pytest.mark.parametrize("use_tr", [1, 0])
 @pytest.mark.parametrize("B,H,Sq,Skv", [(2, 2, 256, 256), (1, 3, 128, 77), (2, 2, 16, 16), (1, 2, 1024, 200),
                                         (1, 1, 64, 7), (2, 2, 1024, 77), (1, 2, 576, 77),
                                         # one-pass cross-attention backward (<= 128 keys): ragged query counts of the aspect-ratio
                                         # buckets (14x26, 28x52 tokens), 1..4 key blocks, several query splits
                                         (1, 2, 364, 77), (2, 3, 1456, 77), (1, 2, 640, 128), (1, 2, 512, 100), (1, 2, 260, 33)])
-def test_attention_fwd_bwd(ops, use_tr, B, H, Sq, Skv):
+def test_attention_fwd_bwd(ops, use_tr, B, H, Sq, Skv, prescaled):
+    """prescaled (the product path): the Q handed over already holds q * scale * log2(e) -- exact inputs for the fp32
+    reference, whose q is Q' / (scale log2 e); dQ comes back as the gradient w.r.t. that unscaled q.  Not prescaled: the
+    kernels scale their resident operand themselves (one more bf16 rounding, same tolerances at these logit sizes)."""
     from pea_diffusion_amd._lib import lib
+    if prescaled and use_tr == 0:
+        pytest.skip("the scalar-read debug variant is covered with a plain Q")
     lib().pea_debug_set_attn_tr(use_tr)
     try:
         q, k, v = bfr(B, Sq, H * 64, seed=1), bfr(B, Skv, H * 64, seed=2), bfr(B, Skv, H * 64, seed=3)
-        qr, kr, vr = [t.float().requires_grad_(True) for t in (q, k, v)]
+        if prescaled:
+            q = (q.float() * ALPHA).to(BF)                 # any bf16 tensor is a valid Q'; this one has the usual score sizes
+        qr = (q.float() / ALPHA if prescaled else q.float()).requires_grad_(True)
+        kr, vr = [t.float().requires_grad_(True) for t in (k, v)]
         oref, lref = _attn_ref(qr, kr, vr, H)
-        o, lse = ops.attention_fwd(q.cuda(), k.cuda(), v.cuda(), H)
-        tag = f"attn tr{use_tr} B{B} H{H} Sq{Sq} Skv{Skv}"
+        o, lse = ops.attention_fwd(q.cuda(), k.cuda(), v.cuda(), H, q_prescaled=prescaled)
+        tag = f"attn tr{use_tr} pre{int(prescaled)} B{B} H{H} Sq{Sq} Skv{Skv}"
         close_bf16(tag + " O", o, oref, ulps=2.0)
         close_f32(tag + " lse", lse, lref, rtol=1e-3, atol=2e-3)
         do = bfr(B, Sq, H * 64, seed=4)
         oref.backward(do.float())
-        dq, dk, dv = ops.attention_bwd(q.cuda(), k.cuda(), v.cuda(), o, do.cuda(), lse, H)
+        dq, dk, dv = ops.attention_bwd(q.cuda(), k.cuda(), v.cuda(), o, do.cuda(), lse, H, q_prescaled=prescaled)
         close_bf16(tag + " dQ", dq, qr.grad, ulps=4.0)
         close_bf16(tag + " dK", dk, kr.grad, ulps=4.0)
         close_bf16(tag + " dV", dv, vr.grad, ulps=4.0)
@@ -349,18 +397,47 @@ def test_attention_fwd_bwd(ops, use_tr, B, H, Sq, Skv):
         lib().pea_debug_set_attn_tr(1)
 
 
-def test_attention_softmax_spike(ops):
-    """forces a late running-max jump (online-softmax rescale path)"""
-    B, H, Sq, Skv = 1, 1, 64, 256
+@pytest.mark.parametrize("prescaled", [True, False])
+@pytest.mark.parametrize("spike,tile_key", [(4.0, 200), (4.0, 70), (0.6, 200), (1.0, 1000)])
+def test_attention_softmax_spike(ops, prescaled, spike, tile_key):
+    """Forces (spike 4: +46 in log2 units) or just avoids (0.6: below ATTN_MOVE_THR) a late jump of one query's score offset --
+    the forward's rescale branch runs for ONE row of a wave in a late tile while the other rows keep their offset -- and
+    checks forward and backward against fp32 on the full tensors.  With a plain Q the kernels round Q * scale * log2(e) to
+    bf16 themselves, a relative 2^-9 on every logit: at a logit of 32 that is 0.02 in lse, hence the wider lse tolerance of
+    that mode (the product path hands Q over prescaled by the projection's epilogue: exact inputs, tight tolerance)."""
+    B, H, Sq, Skv = 1, 1, 64, 1024 if tile_key >= 256 else 256
     q, k, v = bfr(B, Sq, 64, seed=1), bfr(B, Skv, 64, seed=2), bfr(B, Skv, 64, seed=3)
-    k[0, 200] = (q[0, 5].float() * 4).to(BF)
-    oref, lref = _attn_ref(q.float(), k.float(), v.float(), H)
-    o, lse = ops.attention_fwd(q.cuda(), k.cuda(), v.cuda(), H)
+    k[0, tile_key] = (q[0, 5].float() * spike).to(BF)
+    if prescaled:
+        q = (q.float() * ALPHA).to(BF)
+    qr = (q.float() / ALPHA if prescaled else q.float()).requires_grad_(True)
+    kr, vr = [t.float().requires_grad_(True) for t in (k, v)]
+    oref, lref = _attn_ref(qr, kr, vr, H)
+    o, lse = ops.attention_fwd(q.cuda(), k.cuda(), v.cuda(), H, q_prescaled=prescaled)
     close_bf16("attn spike O", o, oref, ulps=2.0)
-    close_f32("attn spike lse", lse, lref, rtol=1e-3, atol=2e-3)
+    close_f32("attn spike lse", lse, lref, rtol=1e-3, atol=2e-3 if prescaled else 2.5e-2)
+    if not prescaled and spike > 1.0:
+        return          # (a plain Q with logits of 30+: the kernels' own rounding of the scaled operand dominates the gradients)
+    do = bfr(B, Sq, 64, seed=4)
+    oref.backward(do.float())
+    dq, dk, dv = ops.attention_bwd(q.cuda(), k.cuda(), v.cuda(), o, do.cuda(), lse, H, q_prescaled=prescaled)
+    close_bf16("attn spike dQ", dq, qr.grad, ulps=4.0)
+    close_bf16("attn spike dK", dk, kr.grad, ulps=4.0)
+    close_bf16("attn spike dV", dv, vr.grad, ulps=4.0)
 
 
-# ------------------------------------------------------------------------------------ glue
+def test_gemm_qscale_columns(ops):
+    """the fused Q|K|V projection's epilogue: columns [0, C) (the Q block) leave multiplied by scale * log2(e) -- one rounding,
+    from the fp32 accumulator -- the K and V blocks unchanged; all tile forms the shape rule picks for these sizes"""
+    for M, C, K, with_bias in [(8192, 1280, 1280, False), (4096, 640, 640, True), (616, 768, 768, True), (300, 320, 320, False)]:
+        a, w = bfr(M, K, seed=M), bfr(3 * C, K, seed=C, scale=K ** -0.5)
+        bias = torch.randn(3 * C) * 0.1 if with_bias else None
+        got = ops.gemm_qscale(a.cuda(), w.cuda(), bias.cuda() if with_bias else None, qscale_cols=C, qscale=ALPHA)
+        ref = a.float() @ w.float().t() + (bias if with_bias else 0.0)
+        ref[:, :C] *= ALPHA
+        close_bf16(f"gemm qscale {M}x{3 * C}x{K}", got, ref)
+
+
 def test_geglu(ops):
     hg = bfr(96, 2 * 320, seed=1)
     hr = hg.float().requires_grad_(True)
