@@ -420,7 +420,6 @@ void pea_debug_set_attn_fused_bwd(int v);
 void pea_debug_set_attn_xattn(int v);
 /* A/B aid: 1 = GEGLU backward inside the FF output projection's dgrad GEMM (default), 0 = its own kernel */
 void pea_debug_set_geglu_bwd_fused(int v);
-void pea_debug_set_attn_fwd_pipe(int v);   /* 0: the one-tile-at-a-time attention forward (A/B); default 1 */
 /* benchmark aid: force GEMM tile variant (>= 0) or restore the shape-based choice (-1) */
 void pea_debug_set_gemm_variant(int v);
 /* timing-only probes of the loader/consumer GEMM (results are wrong while set): 1 no DMA, 2 no barriers, 4 no ds_reads */

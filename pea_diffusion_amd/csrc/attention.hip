@@ -20,21 +20,9 @@
 #include "pea_kernels.h"
 
 #define TILE_BYTES 8192   // 64 rows x 128 bytes
-// Issue priority of a wave while it streams MFMAs (experiment switch, profiles/EXPERIMENTS.md round 3): on one SIMD the
-// matrix-busy cycles and the vector-issue cycles of the two resident waves add up instead of overlapping (PMC: 51 % + 45 % of
-// the SIMD's time in the backward); with the MFMA phases at a higher priority the partner's exponentials should fill the
-// 24 free issue cycles of each 32-cycle MFMA instead of delaying it.
-#ifndef PEA_ATTN_FWD_WPS
-#define PEA_ATTN_FWD_WPS 1          // waves per SIMD the pipelined forward is compiled for
+#ifndef PEA_ATTN_BWD_PREFETCH
+#define PEA_ATTN_BWD_PREFETCH 0   // 1: backward roles request each batch of LDS fragments one phase ahead of its MFMAs (A/B: 1 % slower, +40 registers)
 #endif
-#ifndef PEA_ATTN_FWD_PATTERN
-#define PEA_ATTN_FWD_PATTERN 0      // 1: explicit MFMA / exp / VALU / LDS interleave groups in the pipelined forward's region
-#endif
-#ifndef PEA_ATTN_PRIO
-#define PEA_ATTN_PRIO 0
-#endif
-#define MFMA_PRIO_ON()  do { if (PEA_ATTN_PRIO) __builtin_amdgcn_s_setprio(PEA_ATTN_PRIO); } while (0)
-#define MFMA_PRIO_OFF() do { if (PEA_ATTN_PRIO) __builtin_amdgcn_s_setprio(0); } while (0)
 // raw v_exp_f32: exp2f() expands to a denormal-safe 5-instruction sequence; every argument here is <= 0 (scores
 // minus a running max / the log-sum-exp), so a flushed denormal result is an exact zero after bf16 rounding anyway
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
@@ -361,20 +349,18 @@ __device__ __forceinline__ void attn_q_body(const AttnP& p, char* smem, int blk_
       for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
         for (int s = 0; s < 4; ++s) kfr[kb][s] = *(const bf16x8*)(smem + rfc[s] + (nd * TILE_BYTES + kb * 4096));
-      if (MODE == 1 && nd == ND - 1) {
+      if (MODE == 1 && nd == ND - 1 && PEA_ATTN_BWD_PREFETCH) {
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
           for (int s = 0; s < 4; ++s) vfr0[kb][s] = *(const bf16x8*)(smem + rfc[s] + (ND * TILE_BYTES + kb * 4096));
       }
       __builtin_amdgcn_sched_barrier(0);
-      MFMA_PRIO_ON();
 #pragma unroll
       for (int s = 0; s < 4; ++s)
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
           sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr[kb][s], qf[nd][s], (nd == 0 && s == 0) ? rowc : sacc[kb], 0, 0, 0);
-      MFMA_PRIO_OFF();
     }
     const int kv0 = t * 64;
     bf16x8 pf[4];   // P^T (fwd) or dS^T (dQ) as B-operand fragments, k-permuted
@@ -457,10 +443,10 @@ __device__ __forceinline__ void attn_q_body(const AttnP& p, char* smem, int blk_
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
           for (int s = 0; s < 4; ++s) {
-            if (nd == 0) vfr[kb][s] = vfr0[kb][s];            // requested before the S products
+            if (nd == 0 && PEA_ATTN_BWD_PREFETCH) vfr[kb][s] = vfr0[kb][s];            // requested before the S products
             else vfr[kb][s] = *(const bf16x8*)(smem + rfc[s] + ((ND + nd) * TILE_BYTES + kb * 4096));
           }
-        if (nd == ND - 1) {                                    // the dQ product's transposed K fragments: under dP and the exponentials
+        if (nd == ND - 1 && PEA_ATTN_BWD_PREFETCH) {           // the dQ product's transposed K fragments: under dP and the exponentials
 #pragma unroll
           for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
@@ -471,14 +457,12 @@ __device__ __forceinline__ void attn_q_body(const AttnP& p, char* smem, int blk_
             }
         }
         __builtin_amdgcn_sched_barrier(0);
-        MFMA_PRIO_ON();
 #pragma unroll
         for (int s = 0; s < 4; ++s)
 #pragma unroll
           for (int kb = 0; kb < 2; ++kb)
             dpacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfr[kb][s], dof[MODE == 1 ? nd : 0][s],
                                                                 (nd == 0 && s == 0) ? negd : dpacc[kb], 0, 0, 0);
-        MFMA_PRIO_OFF();
       }
       if (kv0 + 64 > skv_b) {                                    // uniform: only the tile that holds masked keys
 #pragma unroll
@@ -512,20 +496,18 @@ __device__ __forceinline__ void attn_q_body(const AttnP& p, char* smem, int blk_
       for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
         for (int db = 0; db < 2; ++db) {
-          if constexpr (MODE == 1) { tfr[ks][db] = tfr1[ks][db]; continue; }
+          if constexpr (MODE == 1 && PEA_ATTN_BWD_PREFETCH) { tfr[ks][db] = tfr1[ks][db]; continue; }
           if constexpr (USE_TR)
             tfr[ks][db] = read_transposed_frag_at(smem + trc[db][0] + (no * TILE_BYTES + ks * 2048),
                                                   smem + trc[db][1] + (no * TILE_BYTES + ks * 2048));
           else tfr[ks][db] = read_transposed_frag<false>(Ts, ks * 16, db * 32, lane);
         }
       __builtin_amdgcn_sched_barrier(0);
-      MFMA_PRIO_ON();
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
         for (int db = 0; db < 2; ++db)
           oacc[2 * no + db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tfr[ks][db], pf[ks], oacc[2 * no + db], 0, 0, 0);
-      MFMA_PRIO_OFF();
     }
     WAIT_VM0();
     __syncthreads();
@@ -583,262 +565,6 @@ __global__ __launch_bounds__(256, (ND == 1 ? (MODE == 0 ? 3 : 2) : 1)) void attn
   int blk_x, head, b;
   attn_block_coords(p.xcd_remap, blk_x, head, b);
   attn_q_body<MODE, USE_TR, ND, TXT, true>(p, smem, blk_x, head, b);
-}
-
-// ============================================================================= forward, software-pipelined over key tiles
-// head_dim 64, no text masks.  Measured on this chip (scripts/ubench/mfma_valu_overlap.hip, profiles/r03_mfma_valu_overlap.log):
-// vector instructions placed between a wave's OWN MFMAs are nearly free -- 8 x { MFMA 32x32x16 ; 2 v_exp + 2 v_add } takes
-// 276 cycles against 256 for the MFMAs alone, also with two such waves on the SIMD (530 against 512) -- whereas MFMA phases
-// and vector phases of DIFFERENT waves add up (PMC: matrix-busy 51 % + vector-issue 45 % of the SIMD's time in the backward;
-// the one-tile-at-a-time forward's tile time = its MFMA time + its VALU issue time; priorities change nothing).  So a wave
-// keeps TWO score tiles alive and every iteration is one straight-line region of 16 MFMAs with the whole softmax in their
-// issue gaps:  S(t+1) = K(t+1) Q^T  ||  exp / row-sum / bf16 conversion of tile t,  then  O += V(t)^T P(t)^T  ||  the rest of
-// the exponentials and the row maximum of tile t+1.  The offset of a tile is known BEFORE its scores exist (it is the C
-// operand of their MFMAs), so the only data-dependent branch -- "some query's maximum ran more than ATTN_MOVE_THR ahead of
-// its offset": rescale O, l, the pending scores and the C operand -- sits at the end of the iteration, outside the region.
-// LDS: 4 ring slots of (K | V) tiles; tile t+3 is in flight while K(t+2) fragments are read for the NEXT iteration's MFMAs
-// and V(t) for this one's, so no read is issued less than half an iteration before its use; one barrier per tile.
-template <typename StageFn>
-struct FwdPipeCtx {
-  const AttnP& p;
-  char* smem;
-  StageFn& stage_kv;
-  int nt, fh;
-  int rf_off[4], tr_off[2][2];
-  bf16x8 qf[4];
-  bf16x8 kfr[2][4];                 // row fragments of the K tile whose scores the next S product computes
-  f32x16 oacc[2], rowc;
-  float m_run, l_run;
-};
-
-// The arithmetic of the region as volatile asm statements: their order in the source IS the issue order (hipcc's own
-// scheduling of this region put all 32 exponentials in front of the first MFMA and spilled 115 registers; with the S
-// accumulators in AGPRs at one wave per SIMD it added 90 v_accvgpr moves per tile).  Register allocation, the LDS reads and
-// their waits stay with the compiler.  Hazards the compiler would pad and an asm statement does not: an MFMA's result read by
-// anything but the next MFMA of its chain (here only far later: the schedule's distances; s_nops in front of the rare
-// rescale branch and the epilogue), a transcendental's result used by the very next instruction, a freshly converted
-// fragment read by an MFMA (at least two statements apart: scripts/gen_attn_fwd_schedule.py checks all of them).
-#define A_MFMA(acc, a, b) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b) : "memory")
-#define A_MFMA_C(dst, a, b, cc) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %3" : "=&v"(dst) : "v"(a), "v"(b), "v"(cc) : "memory")
-#ifndef PEA_PIPE_PROBE
-#define PEA_PIPE_PROBE 0            // timing probes of the pipelined forward (results are wrong when set): 1 no barrier / DMA wait,
-#endif                              // 2 no LDS fragment reads, 4 no vector arithmetic, 8 no DMA staging
-#if PEA_PIPE_PROBE & 4
-#define A_EXP(d, x) d = x
-#define A_ADD(acc, x) do { } while (0)
-#define A_CVT(d, lo, hi) d = __builtin_bit_cast(unsigned, lo)
-#define A_MAX3(m, a, b) do { } while (0)
-#else
-#define A_EXP(d, x) asm volatile("v_exp_f32 %0, %1" : "=v"(d) : "v"(x))
-#define A_ADD(acc, x) asm volatile("v_add_f32 %0, %0, %1" : "+v"(acc) : "v"(x))
-#define A_CVT(d, lo, hi) asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(d) : "v"(lo), "v"(hi))
-#define A_MAX3(m, a, b) asm volatile("v_max3_f32 %0, %0, %1, %2" : "+v"(m) : "v"(a), "v"(b))
-#endif
-
-template <bool LAST, bool PREF, typename Ctx>
-__device__ __forceinline__ void attn_fwd_pipe_tile(Ctx& c, int t, f32x16 (&cur)[2], f32x16 (&nxt)[2]) {
-  const AttnP& p = c.p;
-  char* const smem = c.smem;
-  constexpr int STG = 2 * TILE_BYTES;
-  if (t + 3 < c.nt && !(PEA_PIPE_PROBE & 8)) c.stage_kv(smem + ((t + 3) & 3) * STG, (t + 3) * 64);
-  bf16x8 tfr[4][2];                 // V(t), transposed
-  const char* const Vs = smem + (t & 3) * STG + TILE_BYTES;
-  const char* const Kn = smem + ((t + 2) & 3) * STG;
-#define LOAD_TFR(ks)                                                                                                       \
-  do {                                                                                                                     \
-    if ((PEA_PIPE_PROBE & 2) && t > 0) break;                                                                              \
-    tfr[ks][0] = read_transposed_frag_at(Vs + c.tr_off[0][0] + (ks) * 2048, Vs + c.tr_off[0][1] + (ks) * 2048);           \
-    tfr[ks][1] = read_transposed_frag_at(Vs + c.tr_off[1][0] + (ks) * 2048, Vs + c.tr_off[1][1] + (ks) * 2048);           \
-  } while (0)
-#define LOAD_KFR(kb)                                                                                                       \
-  do {                                                                                                                     \
-    if (PEA_PIPE_PROBE & 2) break;                                                                                         \
-    _Pragma("unroll") for (int s_ = 0; s_ < 4; ++s_) c.kfr[kb][s_] = *(const bf16x8*)(Kn + c.rf_off[s_] + (kb) * 4096);    \
-  } while (0)
-  LOAD_TFR(0);
-  LOAD_TFR(1);
-  if (LAST) {
-    const int kv0 = t * 64;
-    if (kv0 + 64 > p.Skv) {                                      // the ragged tile is the last one
-#pragma unroll
-      for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int key = kv0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * c.fh;
-          cur[kb][r] = key < p.Skv ? cur[kb][r] : -INFINITY;
-        }
-    }
-  }
-  typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
-  u32x4_t pw0, pw1, pw2, pw3;       // P(t)^T as MFMA B fragments (bf16 pairs), one per k-slice
-  float ls0 = 0.f, ls1 = 0.f, mx0 = 0.f, mx1 = 0.f;
-  __builtin_amdgcn_sched_barrier(0);
-#include "attn_fwd_sched.inc"
-  __builtin_amdgcn_sched_barrier(0);
-#undef LOAD_TFR
-#undef LOAD_KFR
-  c.l_run += ls0 + ls1;
-  if (!LAST) {
-    const float mx = xhalf_max(fmaxf(mx0, mx1));                 // (>= 0: only "more than THR above the offset" matters)
-    const bool moved = mx > ATTN_MOVE_THR;
-    if (__any(moved)) {             // rare: bring everything accumulated so far, and the pending scores, to the new offset
-      asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");       // the last MFMAs' results (oacc) are read below
-      const float mrel = moved ? mx : 0.f;
-#pragma unroll
-      for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) nxt[kb][r] -= mrel;
-      const float alpha = fast_exp2(-mrel);
-      c.l_run *= alpha;
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) c.oacc[i][r] *= alpha;
-      c.m_run += mrel;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) c.rowc[r] = -c.m_run;
-    }
-  } else {
-    asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");         // the epilogue reads oacc
-  }
-  if (!(PEA_PIPE_PROBE & 1)) {
-    WAIT_VM0();
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __syncthreads();
-  }
-}
-
-template <bool USE_TR>
-__device__ __forceinline__ void attn_fwd_pipe_body(const AttnP& p, char* smem, int blk_x, int head, int b) {
-  constexpr int STG = 2 * TILE_BYTES;
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int q0 = blk_x * 128 + wave * 32;
-  const int frow = lane & 31, fh = lane >> 5;
-  const bf16* Qb = p.Q + (long long)b * p.Sq * p.ldq + head * 64;
-  const bf16* Kb = p.K + (long long)b * p.Skv * p.ldk + head * 64;
-  const bf16* Vb = p.V + (long long)b * p.Skv * p.ldv + head * 64;
-  int qrow = q0 + frow;
-  const bool qvalid = qrow < p.Sq;
-  qrow = qvalid ? qrow : p.Sq - 1;
-  const TileSrc ksrc = tile_src(Kb, p.ldk, p.Skv, wave, lane), vsrc = tile_src(Vb, p.ldv, p.Skv, wave, lane);
-  auto stage_kv = [&](char* dst, int r0) {
-    stage_tile(ksrc, r0, dst, wave);
-    stage_tile(vsrc, r0, dst + TILE_BYTES, wave);
-  };
-  FwdPipeCtx<decltype(stage_kv)> c{p, smem, stage_kv};
-  c.nt = (p.Skv + 63) / 64;
-  c.fh = fh;
-  const float cq = p.scale * LOG2E;
-#pragma unroll
-  for (int s = 0; s < 4; ++s) {
-    c.qf[s] = *(const bf16x8*)(Qb + (long long)qrow * p.ldq + 16 * s + 8 * fh);
-    if (!p.q_prescaled) c.qf[s] = scale_frag(c.qf[s], cq);
-  }
-#pragma unroll
-  for (int r = 0; r < 16; ++r) { c.rowc[r] = 0.f; c.oacc[0][r] = 0.f; c.oacc[1][r] = 0.f; }
-  c.l_run = 0.f;
-#pragma unroll
-  for (int s4 = 0; s4 < 4; ++s4) c.rf_off[s4] = frow * 128 + (((2 * s4 + fh) ^ swz_x(frow)) << 4);
-  {
-    const int i16 = lane & 15, rr = 4 * fh + (i16 >> 2), cc = 16 * ((lane >> 4) & 1) + 4 * (i16 & 3);
-#pragma unroll
-    for (int db = 0; db < 2; ++db)
-#pragma unroll
-      for (int hl = 0; hl < 2; ++hl) c.tr_off[db][hl] = swz_rc(rr + 8 * hl, db * 32 + cc);
-  }
-#pragma unroll
-  for (int i = 0; i < 3; ++i)
-    if (i < c.nt) stage_kv(smem + i * STG, i * 64);
-  WAIT_VM0();
-  __syncthreads();
-  // prologue: S(0) with a zero offset, its row maximum becomes the first offset; K(1) fragments for the first iteration
-  f32x16 sA[2], sB[2];
-  {
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-      for (int s = 0; s < 4; ++s) c.kfr[kb][s] = *(const bf16x8*)(smem + c.rf_off[s] + kb * 4096);
-#pragma unroll
-    for (int s = 0; s < 4; ++s)
-#pragma unroll
-      for (int kb = 0; kb < 2; ++kb)
-        sA[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(c.kfr[kb][s], c.qf[s], s == 0 ? c.rowc : sA[kb], 0, 0, 0);
-    if (c.nt > 1) {
-#pragma unroll
-      for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-        for (int s = 0; s < 4; ++s) c.kfr[kb][s] = *(const bf16x8*)(smem + STG + c.rf_off[s] + kb * 4096);
-    }
-    if (64 > p.Skv) {                                              // a single ragged tile: mask before taking the maximum
-#pragma unroll
-      for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int key = kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
-          sA[kb][r] = key < p.Skv ? sA[kb][r] : -INFINITY;
-        }
-    }
-    float mx = fmaxf(sA[0][0], sA[1][0]);
-#pragma unroll
-    for (int r = 1; r < 16; ++r) mx = fmaxf(fmaxf(mx, sA[0][r]), sA[1][r]);
-    mx = fmaxf(xhalf_max(mx), -1e30f);
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) sA[kb][r] -= mx;
-    c.m_run = mx;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) c.rowc[r] = -mx;
-  }
-  int t = 0;
-  // two tiles per trip: the two score tiles swap roles without copies and without a parity branch (with one, register
-  // allocation across the merge needed 340 registers instead of 238); the last one to three tiles are straight-line tails
-  for (; t + 3 < c.nt; t += 2) {
-    attn_fwd_pipe_tile<false, true>(c, t, sA, sB);
-    attn_fwd_pipe_tile<false, true>(c, t + 1, sB, sA);
-  }
-  const int left = c.nt - t;                                       // 1, 2 or 3
-  if (left == 3) {
-    attn_fwd_pipe_tile<false, true>(c, t, sA, sB);
-    attn_fwd_pipe_tile<false, false>(c, t + 1, sB, sA);            // second to last: no further K fragments to fetch
-    attn_fwd_pipe_tile<true, false>(c, t + 2, sA, sB);
-  } else if (left == 2) {
-    attn_fwd_pipe_tile<false, false>(c, t, sA, sB);
-    attn_fwd_pipe_tile<true, false>(c, t + 1, sB, sA);
-  } else {
-    attn_fwd_pipe_tile<true, false>(c, t, sA, sB);
-  }
-  // epilogue (as attn_q_body's forward)
-  const float l_tot = c.l_run + __shfl_xor(c.l_run, 32, 64);
-  const float inv = 1.f / l_tot;
-  if (p.lse && qvalid && fh == 0)
-    p.lse[((long long)b * p.H + head) * p.Sq + qrow] = (c.m_run + log2f(l_tot)) * 0.6931471805599453f;
-  char* const ost = smem + wave * (32 * 144);
-  const int r8 = lane >> 3, ch = lane & 7;
-#pragma unroll
-  for (int db = 0; db < 2; ++db)
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      bf16x4 o;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) o[j] = (bf16)(c.oacc[db][4 * g + j] * inv);
-      *(bf16x4*)(ost + frow * 144 + (db * 32 + 8 * g + 4 * fh) * 2) = o;
-    }
-  bf16* Ob = p.O + (long long)b * p.Sq * p.ldo + head * 64 + ch * 8;
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int row = i * 8 + r8;
-    if (q0 + row < p.Sq) *(bf16x8*)(Ob + (long long)(q0 + row) * p.ldo) = *(const bf16x8*)(ost + row * 144 + ch * 16);
-  }
-}
-
-template <bool USE_TR>
-__global__ __launch_bounds__(256, PEA_ATTN_FWD_WPS) void attn_fwd_pipe_kernel(const AttnP p) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  int blk_x, head, b;
-  attn_block_coords(p.xcd_remap, blk_x, head, b);
-  attn_fwd_pipe_body<USE_TR>(p, smem, blk_x, head, b);
 }
 
 // per-row constants of a 64-query tile (lse, delta) -> LDS, 4 bytes per lane, issued by wave 0 only
@@ -982,14 +708,17 @@ __device__ __forceinline__ void attn_dkv_body(const AttnP& p, char* smem, int bl
       load_rows(0, 0);
 #pragma unroll
       for (int qb = 0; qb < 2; ++qb) {
-        if (qb == 0) load_rows(1, 1);
-        else load_tr(0);                          // lands under the second block's MFMAs and the exponentials
+        if (PEA_ATTN_BWD_PREFETCH) {
+          if (qb == 0) load_rows(1, 1);
+          else load_tr(0);                        // lands under the second block's MFMAs and the exponentials
+        } else if (qb == 1) {
+          load_rows(1, 1);
+        }
         __builtin_amdgcn_sched_barrier(0);
         if (!all_valid) {
 #pragma unroll
           for (int r = 0; r < 16; ++r) sacc[qb][r] = kvalid ? sacc[qb][r] : -INFINITY;
         }
-        MFMA_PRIO_ON();
 #pragma unroll
         for (int nd = 0; nd < ND; ++nd)
 #pragma unroll
@@ -997,7 +726,6 @@ __device__ __forceinline__ void attn_dkv_body(const AttnP& p, char* smem, int bl
             sacc[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rq[qb][nd * 4 + s], kf[nd][s], sacc[qb], 0, 0, 0);
             dpacc[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rd[qb][nd * 4 + s], vf[nd][s], dpacc[qb], 0, 0, 0);
           }
-        MFMA_PRIO_OFF();
         __builtin_amdgcn_sched_barrier(0);
       }
       bf16x8 pfr[4], dsfr[4];
@@ -1019,9 +747,9 @@ __device__ __forceinline__ void attn_dkv_body(const AttnP& p, char* smem, int bl
       // two k-slices (8 transposed fragments = 32 registers) per batch of 8 MFMAs; the second batch's fragments are read
       // while the first batch's MFMAs run
       __builtin_amdgcn_sched_barrier(0);
+      if (!PEA_ATTN_BWD_PREFETCH) load_tr(0);
       load_tr(1);
       __builtin_amdgcn_sched_barrier(0);
-      MFMA_PRIO_ON();
 #pragma unroll
       for (int bt = 0; bt < 2; ++bt) {
 #pragma unroll
@@ -1033,7 +761,6 @@ __device__ __forceinline__ void attn_dkv_body(const AttnP& p, char* smem, int bl
           }
         __builtin_amdgcn_sched_barrier(0);
       }
-      MFMA_PRIO_OFF();
     }
     WAIT_VM0();
     __syncthreads();
@@ -1658,8 +1385,6 @@ static int g_attn_use_tr = 1;
 static int g_attn_xattn = getenv("PEA_XATTN_OFF") ? 0 : 1;               // PEA_XATTN_OFF=1: cross-attention on the general kernels (A/B)
 extern "C" void pea_debug_set_attn_xattn(int v) { g_attn_xattn = v; }
 static int g_attn_xcd = getenv("PEA_ATTN_NO_XCD") ? 0 : 1;
-static int g_attn_fwd_pipe = getenv("PEA_ATTN_FWD_PIPE") ? 1 : 0;         // PEA_ATTN_FWD_PIPE=1: the software-pipelined forward (experiment: slower, profiles/EXPERIMENTS.md round 3)
-extern "C" void pea_debug_set_attn_fwd_pipe(int v) { g_attn_fwd_pipe = v; }
 extern "C" void pea_debug_set_attn_tr(int v) { g_attn_use_tr = v; }
 
 static int attn_check(const AttnP& p) {
@@ -1723,19 +1448,6 @@ static int attn_fwd_nd(const AttnP& p, hipStream_t s) {
       hipLaunchKernelGGL((attn_q_kernel<0, true, 1, true>), grid, dim3(256), 2 * 2 * TILE_BYTES, s, p);
     }
     return PEA_OK;
-  }
-  if constexpr (ND == 1) {
-    if (g_attn_fwd_pipe && g_attn_use_tr) {     // software-pipelined forward (head_dim 64): four ring slots
-      static bool attr = false;
-      if (!attr) {
-        HIPCHK(hipFuncSetAttribute((const void*)attn_fwd_pipe_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 2 * TILE_BYTES));
-        attr = true;
-      }
-      AttnP q = p;
-      q.xcd_remap = g_attn_xcd;
-      hipLaunchKernelGGL((attn_fwd_pipe_kernel<true>), grid, dim3(256), 4 * 2 * TILE_BYTES, s, q);
-      return PEA_OK;
-    }
   }
   ATTN_DISPATCH((attn_q_kernel<0, true, ND>), (attn_q_kernel<0, false, ND>), grid, 2 * 2 * ND * TILE_BYTES);
   return PEA_OK;

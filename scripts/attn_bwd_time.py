@@ -16,14 +16,6 @@ for (B, H, Sq, Skv) in [(4, 10, 4096, 4096), (4, 20, 1024, 1024)]:
     q = torch.randn(B, Sq, C, device="cuda").to(BF); k = torch.randn(B, Skv, C, device="cuda").to(BF); v = torch.randn(B, Skv, C, device="cuda").to(BF)
     o, lse = ops.attention_fwd(q, k, v, H)
     do = torch.randn_like(o)
-    from pea_diffusion_amd._lib import lib
-    tfs = {}
-    for rnd in range(3):
-        for mode in (1, 0):
-            lib().pea_debug_set_attn_fwd_pipe(mode)
-            tfs[mode] = min(tfs.get(mode, 1e9), timeit(lambda: ops.attention_fwd(q, k, v, H)))
-    lib().pea_debug_set_attn_fwd_pipe(1)
-    tf = tfs[1]
-    print(f"S{Sq}: fwd pipelined {tfs[1]:7.1f} us | one tile at a time {tfs[0]:7.1f} us")
+    tf = min(timeit(lambda: ops.attention_fwd(q, k, v, H)) for _ in range(3))
     tb = min(timeit(lambda: ops.attention_bwd(q, k, v, o, do, lse, H)) for _ in range(3))
     print(f"S{Sq}: fwd {tf:7.1f} us  bwd {tb:7.1f} us", flush=True)
