@@ -8,7 +8,7 @@ f = (glob.glob(d + "/**/*counter_collection.csv", recursive=True))[0]
 busy, gui, n = collections.Counter(), collections.Counter(), collections.Counter()
 for r in csv.DictReader(open(f)):
     k = r["Kernel_Name"].split("(")[0]
-    fam = ("gemm" if "gemm_" in k else "attn_fwd" if "attn_q_kernel<0" in k else "attn_bwd" if "attn_" in k else None)
+    fam = ("gemm" if "gemm_" in k else "attn_fwd" if ("attn_q_kernel<0" in k or "xattn_fwd" in k) else "attn_bwd" if "attn_" in k else None)
     if fam is None: continue
     if r["Counter_Name"] == "SQ_VALU_MFMA_BUSY_CYCLES": busy[fam] += float(r["Counter_Value"]); n[fam] += 1
     elif r["Counter_Name"] == "GRBM_GUI_ACTIVE": gui[fam] += float(r["Counter_Value"])
