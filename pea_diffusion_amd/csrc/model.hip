@@ -1048,8 +1048,9 @@ static void fill_gemm(GemmP& p) { memset(&p, 0, sizeof(p)); p.alpha = 1.f; p.row
 // the two factors of the backward (GemmP::stash_grad); 0 = the raw (h, gate) pre-activation -- the tanh form (no backward
 // exists for it) and the PEA_GEGLU_UNFUSED experiment, whose separate GEGLU kernel reads the pre-activation.
 static bool g_geglu_unfused = getenv("PEA_GEGLU_UNFUSED") != nullptr;
+static bool g_geglu_stash_raw = getenv("PEA_GEGLU_STASH_RAW") != nullptr;      // A/B switch: stash (h, gate) as in round 2
 static int geglu_stash_form(const Op& o) {
-  return (o.p3 == 3 && o.c >= 0 && o.p1 == 0 && !(g_geglu_unfused && o.fold < 0)) ? 1 : 0;
+  return (o.p3 == 3 && o.c >= 0 && o.p1 == 0 && !g_geglu_stash_raw && !(g_geglu_unfused && o.fold < 0)) ? 1 : 0;
 }
 
 int Tape::forward(const float* x, const float* t, const void* ehs, int ehs_dtype, const void* text, int text_dtype,
