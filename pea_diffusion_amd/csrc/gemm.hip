@@ -1431,7 +1431,9 @@ static int pick_variant(const GemmP& p) {
     if (t256 >= 256) return 27;                      // 128^2- and 64^2-level convs (N = 320 / 640)
     return 29;                                       // 32^2-level convs (M = 4096, N = 1280)
   }
-  if (p.M < 1024 || t128 <= 160) return 31;          // embeddings, adapter, stacked K|V projection (tall-skinny)
+  if (p.M < 1024 && t128 > 512)                      // stacked cross-attention K|V projection (M = 2B*77, N = 166400): many
+    return p.M * 100 >= cdiv(p.M, 256) * 256 * 78 ? 27 : 29;   // tiles per CU, so the large wave tile pays (profiles/r03_kv_stack.log)
+  if (p.M < 1024 || t128 <= 160) return 31;          // embeddings, adapter (tall-skinny, few tiles)
   // 35 = 28 with the deferred (lean: alpha / bias / bf16) epilogue: the finished tile leaves in 16-row slices during
   // the next tile's K-steps, the two MFMA waves of a SIMD taking turns
   // measured (in-run A/B, profiles/r01_gemm_variants.log): +4..11 % in the hot microbenchmark, nothing in situ -> off

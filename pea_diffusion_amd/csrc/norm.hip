@@ -207,6 +207,266 @@ __global__ void gn_bwd_apply_kernel(const bf16* __restrict__ x, const bf16* __re
   }
 }
 
+// ---- one-kernel GroupNorm for slabs that fit on chip.  A workgroup owns one (sample, group) slab -- or GW = 2 adjacent
+// groups when a group's channel run is not a whole number of VEC-element vectors (10 or 30 channels per group) -- and
+// keeps it in registers: NPIX vectors per thread (thread -> vector vk of the slab's channel run, pixel lane pl; pixels
+// pl, pl + ppb, ...).  Forward: mean, then the centred second moment (two-pass: the data is resident), normalise +
+// affine (+ SiLU), store: one read + one write instead of the three launches / two reads of the general path.
+// Backward: the two sums of the input gradient, then the apply, both from the resident (x, dy).  Reductions are
+// fixed-order (wave butterfly, then the waves in index order in fp64).  Workgroups are numbered so that an XCD's L2
+// sees whole samples (neighbouring groups share cache lines: a group's run is 20-160 bytes of each pixel row).
+template <int K>
+__device__ __forceinline__ void gn_block_sum(float* v, double (*red)[4], double* out) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+#pragma unroll
+  for (int k = 0; k < K; ++k) v[k] = wave_sum(v[k]);
+  if (lane == 0) {
+#pragma unroll
+    for (int k = 0; k < K; ++k) red[wave][k] = (double)v[k];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    double a = 0.0;
+    for (int w = 0; w < nw; ++w) a += red[w][k];
+    out[k] = a;
+  }
+  __syncthreads();
+}
+
+// The slab is held as packed bf16 pairs (32-bit registers) and widened at each use; an empty asm between the phases keeps
+// hipcc from carrying the widened fp32 copies of the whole slab across them (that spilled every instantiation).
+__device__ __forceinline__ float gn_lo(uint32_t r) { return __builtin_bit_cast(float, r << 16); }
+__device__ __forceinline__ float gn_hi(uint32_t r) { return __builtin_bit_cast(float, r & 0xffff0000u); }
+__device__ __forceinline__ uint32_t gn_pack(float a, float b) {
+  bf16x2 v;
+  v[0] = (bf16)a; v[1] = (bf16)b;
+  return __builtin_bit_cast(uint32_t, v);
+}
+template <int W> struct GnRaw;
+template <> struct GnRaw<4> { typedef uint4 T; };
+template <> struct GnRaw<2> { typedef uint2 T; };
+template <int W>
+__device__ __forceinline__ void gn_load(uint32_t (&r)[W], const bf16* p) {
+  const typename GnRaw<W>::T v = *(const typename GnRaw<W>::T*)p;
+  r[0] = v.x; r[1] = v.y;
+  if constexpr (W == 4) { r[2] = v.z; r[3] = v.w; }
+}
+template <int W>
+__device__ __forceinline__ void gn_store(bf16* p, const uint32_t (&r)[W]) {
+  typename GnRaw<W>::T v;
+  v.x = r[0]; v.y = r[1];
+  if constexpr (W == 4) { v.z = r[2]; v.w = r[3]; }
+  *(typename GnRaw<W>::T*)p = v;
+}
+template <int N, int W>
+__device__ __forceinline__ void gn_pin(uint32_t (&r)[N][W]) {
+#pragma unroll
+  for (int i = 0; i < N; ++i)
+#pragma unroll
+    for (int w = 0; w < W; ++w) asm volatile("" : "+v"(r[i][w]));
+}
+
+// orders the unrolled pixel iterations of the backward phases: the next pixel's registers become "new" values only once
+// `dep` (a result of the current pixel) exists, so hipcc cannot widen / evaluate all pixels at once (register pressure)
+template <int W>
+__device__ __forceinline__ void gn_chain(float& dep, uint32_t (&a)[W], uint32_t (&b)[W]) {
+  if constexpr (W == 4) asm volatile("" : "+v"(dep), "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]));
+  else asm volatile("" : "+v"(dep), "+v"(a[0]), "+v"(a[1]), "+v"(b[0]), "+v"(b[1]));
+}
+
+template <int VEC, int NPIX, int BWD, int GW, int SILU>
+__global__ __launch_bounds__((NPIX * VEC * (1 + BWD) > 128) ? 640 : 1024) void gn_fused_kernel(
+    const bf16* __restrict__ x, const bf16* __restrict__ dy, const float* __restrict__ gamma,
+    const float* __restrict__ beta, float* __restrict__ stats, bf16* out, const bf16* add, int HW, int C, int groups,
+    int ppb, float eps) {
+  constexpr int W = VEC / 2;
+  __shared__ double red[16][4];
+  const int cpg = C / groups, nset = groups / GW, span = GW * cpg, nvec = span / VEC;
+  const int total = gridDim.x, bid = blockIdx.x;
+  const int idx = (total % 8 == 0) ? (bid % 8) * (total / 8) + bid / 8 : bid;       // XCD x owns a contiguous range of slabs
+  const int b = idx / nset, gs = idx - b * nset;
+  const int tid = threadIdx.x, vk = tid % nvec, pl0 = tid / nvec;
+  const bool act = pl0 < ppb;                 // threads of the rounded-up last wave: read pixel lane 0, contribute nothing, store nothing
+  const int pl = act ? pl0 : 0;
+  const int c0 = gs * span + vk * VEC;                                              // first channel of this thread's vector
+  // addresses = wave-uniform 64-bit base of (sample, pixel step i) + a per-thread 32-bit element offset: the per-pixel
+  // addresses live in scalar registers (as 64-bit per-thread values they were CSE'd across the phases and spilled)
+  const long long sbase = (long long)b * HW * C;
+  const long long istep = (long long)ppb * C;
+  const unsigned toff = (unsigned)pl * (unsigned)C + (unsigned)c0;
+  bool hi[VEC];                                                                     // element belongs to the second group of the pair
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) hi[j] = GW == 2 && (vk * VEC + j) >= cpg;
+  uint32_t xr[NPIX][W];
+  uint32_t dr[BWD ? NPIX : 1][W];
+#pragma unroll
+  for (int i = 0; i < NPIX; ++i) {
+    gn_load<W>(xr[i], x + sbase + i * istep + toff);
+    if (BWD) gn_load<W>(dr[i], dy + sbase + i * istep + toff);
+  }
+#define GN_X(i, j) (((j) & 1) ? gn_hi(xr[i][(j) >> 1]) : gn_lo(xr[i][(j) >> 1]))
+#define GN_D(i, j) (((j) & 1) ? gn_hi(dr[i][(j) >> 1]) : gn_lo(dr[i][(j) >> 1]))
+#define GN_SEL(j, a0, a1) ((GW == 2 && hi[j]) ? (a1) : (a0))
+  const double count = (double)HW * cpg;
+  const long long sg = (long long)b * groups + gs * GW;
+  if (!BWD) {
+    float s[2] = {0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < NPIX; ++i)
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) {
+        const float v = GN_X(i, j);
+        if (GW == 2 && hi[j]) s[1] += v; else s[0] += v;
+      }
+    if (!act) s[0] = s[1] = 0.f;
+    double m[2];
+    gn_block_sum<GW>(s, red, m);
+    gn_pin(xr);
+    const float mean0 = (float)(m[0] / count), mean1 = GW == 2 ? (float)(m[1] / count) : 0.f;
+    s[0] = s[1] = 0.f;
+#pragma unroll
+    for (int i = 0; i < NPIX; ++i)
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) {
+        const float d = GN_X(i, j) - GN_SEL(j, mean0, mean1);
+        if (GW == 2 && hi[j]) s[1] += d * d; else s[0] += d * d;
+      }
+    if (!act) s[0] = s[1] = 0.f;
+    double q[2];
+    gn_block_sum<GW>(s, red, q);
+    gn_pin(xr);
+    const float rstd0 = (float)(1.0 / sqrt(q[0] / count + (double)eps));
+    const float rstd1 = GW == 2 ? (float)(1.0 / sqrt(q[1] / count + (double)eps)) : 0.f;
+    if (tid == 0) {
+      stats[sg * 2] = mean0; stats[sg * 2 + 1] = rstd0;
+      if (GW == 2) { stats[sg * 2 + 2] = mean1; stats[sg * 2 + 3] = rstd1; }
+    }
+    if (!act) return;
+    float sc[VEC], sh[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      sc[j] = GN_SEL(j, rstd0, rstd1) * gamma[c0 + j];
+      sh[j] = beta[c0 + j] - GN_SEL(j, mean0, mean1) * sc[j];
+    }
+#pragma unroll
+    for (int i = 0; i < NPIX; ++i) {
+      uint32_t o[W];
+#pragma unroll
+      for (int w = 0; w < W; ++w) {
+        float v0 = GN_X(i, 2 * w) * sc[2 * w] + sh[2 * w], v1 = GN_X(i, 2 * w + 1) * sc[2 * w + 1] + sh[2 * w + 1];
+        if (SILU) { v0 = siluf_(v0); v1 = siluf_(v1); }
+        o[w] = gn_pack(v0, v1);
+      }
+      gn_store<W>(out + sbase + i * istep + toff, o);
+    }
+  } else {
+    const float mean0 = stats[sg * 2], rstd0 = stats[sg * 2 + 1];
+    const float mean1 = GW == 2 ? stats[sg * 2 + 2] : 0.f, rstd1 = GW == 2 ? stats[sg * 2 + 3] : 0.f;
+    float gm[VEC], bt[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) { gm[j] = gamma[c0 + j]; bt[j] = beta[c0 + j]; }
+    float s[2 * GW];
+#pragma unroll
+    for (int k = 0; k < 2 * GW; ++k) s[k] = 0.f;
+#pragma unroll
+    for (int i = 0; i < NPIX; ++i) {
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) {
+        const float xh = (GN_X(i, j) - GN_SEL(j, mean0, mean1)) * GN_SEL(j, rstd0, rstd1);
+        float d = GN_D(i, j);
+        if (SILU) d *= silu_grad(xh * gm[j] + bt[j]);
+        d *= gm[j];
+        if (GW == 2 && hi[j]) { s[1] += d; s[3] += d * xh; } else { s[0] += d; s[GW] += d * xh; }
+      }
+      if (i + 1 < NPIX) gn_chain<W>(s[GW], xr[i + 1], dr[i + 1]);
+    }
+    if (!act) {
+#pragma unroll
+      for (int k = 0; k < 2 * GW; ++k) s[k] = 0.f;
+    }
+    double r[2 * GW];
+    gn_block_sum<2 * GW>(s, red, r);
+    gn_pin(xr);
+    gn_pin(dr);
+    if (!act) return;
+    const float S10 = (float)(r[0] / count), S20 = (float)(r[GW] / count);
+    const float S11 = GW == 2 ? (float)(r[1] / count) : 0.f, S21 = GW == 2 ? (float)(r[2 * GW - 1] / count) : 0.f;
+#pragma unroll
+    for (int i = 0; i < NPIX; ++i) {
+      uint32_t o[W];
+      if (add) gn_load<W>(o, add + sbase + i * istep + toff);     // may be out itself (in-place accumulate)
+#pragma unroll
+      for (int w = 0; w < W; ++w) {
+        float rr[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int j = 2 * w + h;
+          const float rs = GN_SEL(j, rstd0, rstd1);
+          const float xh = (GN_X(i, j) - GN_SEL(j, mean0, mean1)) * rs;
+          float d = GN_D(i, j);
+          if (SILU) d *= silu_grad(xh * gm[j] + bt[j]);
+          d *= gm[j];
+          rr[h] = rs * (d - GN_SEL(j, S10, S11) - xh * GN_SEL(j, S20, S21));
+          if (add) rr[h] += h ? gn_hi(o[w]) : gn_lo(o[w]);
+        }
+        o[w] = gn_pack(rr[0], rr[1]);
+      }
+      if (i + 1 < NPIX) {
+        float dep = __builtin_bit_cast(float, o[W - 1]);
+        gn_chain<W>(dep, xr[i + 1], dr[i + 1]);
+        o[W - 1] = __builtin_bit_cast(uint32_t, dep);
+      }
+      gn_store<W>(out + sbase + i * istep + toff, o);
+    }
+  }
+#undef GN_X
+#undef GN_D
+#undef GN_SEL
+}
+
+// which one-kernel form (if any) holds a [HW][C] sample's group slab in one workgroup's registers
+struct GnFused { int vec, npix, gw, threads, ppb; };
+static bool gn_fused_geometry(int HW, int C, int groups, int bwd, GnFused* f) {
+  static const bool off = getenv("PEA_GN_UNFUSED") != nullptr;      // A/B switch
+  if (off) return false;
+  const int cpg = C / groups;
+  if (cpg % 8 == 0) { f->vec = 8; f->gw = 1; }
+  else if (cpg % 4 == 0) { f->vec = 4; f->gw = 1; }
+  else if (cpg % 2 == 0 && groups % 2 == 0) { f->vec = 4; f->gw = 2; }
+  else return false;
+  const int nvec = f->gw * cpg / f->vec;
+  for (int npix = 8; npix <= 32; npix *= 2) {
+    if (HW % npix) continue;
+    const int regs = npix * f->vec / 2 * (1 + bwd);                 // data registers per thread
+    if (regs > 128) return false;
+    const int maxt = regs > 64 ? 640 : 1024;
+    const int thr = nvec * (HW / npix);
+    if (thr > maxt) continue;
+    f->npix = npix; f->ppb = HW / npix; f->threads = (thr + 63) / 64 * 64;
+    return true;
+  }
+  return false;
+}
+
+template <int BWD>
+static void gn_fused_launch(const GnFused& f, int blocks, hipStream_t s, const bf16* x, const bf16* dy, const float* gamma,
+                            const float* beta, float* stats, bf16* out, const bf16* add, int HW, int C, int groups, float eps,
+                            int silu) {
+#define GN_S(V, N, G, S) hipLaunchKernelGGL((gn_fused_kernel<V, N, BWD, G, S>), dim3(blocks), dim3(f.threads), 0, s, x, dy, gamma, beta, \
+                                            stats, out, add, HW, C, groups, f.ppb, eps)
+#define GN_G(V, N, G) do { if (silu) GN_S(V, N, G, 1); else GN_S(V, N, G, 0); } while (0)
+#define GN_F(V, N) do { if (f.gw == 2) GN_G(V, N, 2); else GN_G(V, N, 1); } while (0)
+  if (f.vec == 8) {
+    switch (f.npix) { case 8: GN_F(8, 8); break; case 16: GN_F(8, 16); break; default: GN_F(8, 32); break; }
+  } else {
+    switch (f.npix) { case 8: GN_F(4, 8); break; case 16: GN_F(4, 16); break; default: GN_F(4, 32); break; }
+  }
+#undef GN_S
+#undef GN_G
+#undef GN_F
+}
+
 static int gn_geometry(int HW, int C, int* threads, int* ppblk, int* nblk, size_t* lds) {
   const int nchunk = C / 8;
   if (nchunk > 1024) return -1;
@@ -237,7 +497,14 @@ int launch_groupnorm_fwd(const bf16* x, const float* gamma, const float* beta, b
   SHAPECHK(gn_geometry(HW, C, &threads, &ppblk, &nblk, &lds) == 0, "groupnorm: C=%d too wide", C);
   SHAPECHK(threads >= groups, "groupnorm: C=%d too narrow for %d groups", C, groups);
   float* partial = (float*)scratch;
-  PROF_BEGIN(4, 0.0, 2.0 * 3.0 * B * (double)HW * C, s);
+  PROF_BEGIN(4, 0.0, 2.0 * 2.0 * B * (double)HW * C, s);           // algorithmic: read x, write y
+  GnFused f;
+  if (gn_fused_geometry(HW, C, groups, 0, &f)) {
+    gn_fused_launch<0>(f, B * (groups / f.gw), s, x, nullptr, gamma, beta, stats, y, nullptr, HW, C, groups, eps, silu);
+    PROF_END(s);
+    HIPCHK(hipGetLastError());
+    return PEA_OK;
+  }
   hipLaunchKernelGGL(gn_stats_kernel<0>, dim3(nblk, B), dim3(threads), lds, s, x, nullptr, nullptr, nullptr, nullptr,
                      partial, HW, C, groups, ppblk, 0);
   hipLaunchKernelGGL(gn_finalize_kernel, dim3(B * groups), dim3(64), 0, s, partial, stats, B * groups, groups, nblk,
@@ -259,7 +526,14 @@ int launch_groupnorm_bwd(const bf16* x, const bf16* dy, const float* gamma, cons
   SHAPECHK(threads >= groups, "groupnorm: C=%d too narrow for %d groups", C, groups);
   float* partial = (float*)scratch;
   float* sums = partial + (size_t)B * nblk * groups * 2;
-  PROF_BEGIN(4, 0.0, 2.0 * 5.0 * B * (double)HW * C, s);
+  PROF_BEGIN(4, 0.0, 2.0 * (add ? 4.0 : 3.0) * B * (double)HW * C, s);   // algorithmic: read x, dy (, the addend), write dx
+  GnFused f;
+  if (gn_fused_geometry(HW, C, groups, 1, &f)) {
+    gn_fused_launch<1>(f, B * (groups / f.gw), s, x, dy, gamma, beta, const_cast<float*>(stats), dx, add, HW, C, groups, 0.f, silu);
+    PROF_END(s);
+    HIPCHK(hipGetLastError());
+    return PEA_OK;
+  }
   hipLaunchKernelGGL(gn_stats_kernel<1>, dim3(nblk, B), dim3(threads), lds, s, x, dy, gamma, beta, stats, partial, HW,
                      C, groups, ppblk, silu);
   hipLaunchKernelGGL(gn_finalize_kernel, dim3(B * groups), dim3(64), 0, s, partial, sums, B * groups, groups, nblk,

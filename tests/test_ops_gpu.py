@@ -313,8 +313,14 @@ def test_conv_in_and_conv_out_dgrad_shapes(ops, B, H, W, Cs, N):
 
 
 # ------------------------------------------------------------------------------------ norms
+# one-kernel (slab in registers) forms: 8-element vectors (40 / 80 channels per group), 4-element vectors (20 / 60), group
+# pairs (10 / 30), a ragged last wave (HW = 120 * 8), every pixels-per-thread count; three-launch general path: 16384 x 320,
+# 1024 x 960 (slab too large), HW = 16 / 36 (not a multiple of 8)
 @pytest.mark.parametrize("B,HW,C,silu", [(2, 256, 320, True), (2, 64, 64, False), (1, 1024, 960, True),
-                                         (3, 16, 2560, True), (2, 4096, 640, False)])
+                                         (3, 16, 2560, True), (2, 4096, 640, False), (2, 1024, 1280, True),
+                                         (2, 1024, 2560, True), (1, 1024, 1920, False), (1, 4096, 1280, True),
+                                         (2, 960, 1280, True), (1, 16384, 320, True), (2, 36, 640, True),
+                                         (2, 256, 960, False), (1, 4096, 640, True)])
 def test_groupnorm(ops, B, HW, C, silu):
     x = (bfr(B, HW, C, seed=1).float() * 1.5 + 0.7).to(BF)
     g = torch.Generator().manual_seed(2)
@@ -324,10 +330,21 @@ def test_groupnorm(ops, B, HW, C, silu):
     yr = F.silu(z) if silu else z
     y, stats = ops.groupnorm_fwd(x.cuda(), gamma.cuda(), beta.cuda(), 32, 1e-5, silu)
     close_bf16(f"groupnorm fwd C{C} silu{silu}", y, yr)
+    zr = z.detach().reshape(B, HW, 32, C // 32)
+    mean_ref = x.float().reshape(B, HW, 32, C // 32).mean(dim=(1, 3))
+    var_ref = x.float().reshape(B, HW, 32, C // 32).var(dim=(1, 3), unbiased=False)
+    st = stats.cpu().reshape(B, 32, 2)
+    assert torch.allclose(st[..., 0], mean_ref, rtol=1e-4, atol=1e-5), "groupnorm: saved mean"
+    assert torch.allclose(st[..., 1], (var_ref + 1e-5).rsqrt(), rtol=1e-4, atol=1e-5), "groupnorm: saved rstd"
     dy = bfr(B, HW, C, seed=3)
     yr.backward(dy.float())
     dx = ops.groupnorm_bwd(x.cuda(), dy.cuda(), gamma.cuda(), beta.cuda(), stats, 32, silu)
     close_bf16(f"groupnorm bwd C{C} silu{silu}", dx, xr.grad, ulps=2.0)
+    # accumulate form (the resnet input's gradient already holds the shortcut's share)
+    prev = bfr(B, HW, C, seed=4)
+    acc = prev.cuda().clone()
+    ops.groupnorm_bwd(x.cuda(), dy.cuda(), gamma.cuda(), beta.cuda(), stats, 32, silu, accum_into=acc)
+    close_bf16(f"groupnorm bwd accumulate C{C}", acc, xr.grad + prev.float(), ulps=2.0)
 
 
 @pytest.mark.parametrize("R,C", [(64, 640), (308, 1024), (100, 1280), (16, 128), (7, 2048)])
