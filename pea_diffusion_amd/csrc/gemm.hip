@@ -1398,167 +1398,6 @@ static int launch_lcp(const GemmP& p, hipStream_t stream) {
   return PEA_OK;
 }
 
-// ------------------------------------------------------------------------------------------------
-// Four-wave kernel: a 256 x 256 x 64 tile, ONE wave per SIMD with a 128 x 128 wave tile (4 x 4 accumulators of
-// v_mfma_f32_32x32x16_bf16 = 256 accumulator registers of the 512 a lone wave may use), every wave issuing its quarter of the
-// buffer-form LDS-DMA stream itself; two 64 KB LDS stages.  Half the LDS fragment traffic per flop of the 64 x 80 wave tile,
-// 4 instead of 12 waves at the K-step barrier.  The K-loop of a tile is ONE hand-scheduled inline-asm block
-// (gemm_w4_loop.inc, generated by scripts/gen_w4_loop.py: its header describes the schedule) -- compiled from HIP the same
-// structure issued its 16 fragment reads and then waited on them in front of every 64 MFMAs (919 against 1116 TFLOP/s for
-// the 256 x 160 kernel on M8192 N10240 K1280).  Plain GEMM (MODE 0), M % 256 == N % 256 == 0, lda / ldw % 64 == 0,
-// K >= 192; persistent with the XCD-aware tile walk of gemm_lcp_kernel.
-#include "gemm_w4_loop_4.inc"
-#include "gemm_w4_loop_2.inc"
-typedef __attribute__((ext_vector_type(4))) unsigned w4_u32x4;
-template <int NI>            // 32-wide accumulator columns per wave: 4 = 128 x 128 wave tile, 4 waves; 2 = 128 x 64, 8 waves (two per SIMD)
-__global__ __launch_bounds__(1024 / NI, 1) void gemm_w4_kernel(const GemmP p) {
-#if defined(__HIP_DEVICE_COMPILE__)
-  constexpr int BM = 256, BN = 256, KS = 32;                    // KS: k per stage
-  constexpr int STAGE = (BM + BN) * KS * 2, A_BYTES = BM * KS * 2, NSTG = 4;
-  constexpr int NPC = NI;                                       // DMA pieces (16 rows) per operand, wave and step
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int nbm = p.M / BM, nbn = p.N / BN;
-  const int nwg = nbm * nbn, nblk = gridDim.x;
-  const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
-  const int nbx = (nblk - xcd + 7) >> 3;
-  const int tq = nwg >> 3, tr = nwg & 7;
-  const int cnt_x = tq + (xcd < tr ? 1 : 0);
-  const int start_x = xcd < tr ? xcd * (tq + 1) : tr * (tq + 1) + (xcd - tr) * tq;
-  const int my_n = idx < cnt_x ? (cnt_x - idx + nbx - 1) / nbx : 0;
-  const int nt = p.K / KS;
-  if (my_n == 0) return;
-  constexpr int GROUP = 4;
-  const int per_group = GROUP * nbn;
-  auto tile_of = [&](int i, int& bm, int& bn) {
-    const int bid = start_x + idx + i * nbx;
-    const int gid = bid / per_group;
-    const int first_m = gid * GROUP;
-    const int gsize = min(nbm - first_m, GROUP);
-    const int rem = bid - gid * per_group;
-    bm = first_m + rem % gsize;
-    bn = rem / gsize;
-  };
-  // LDS image of a stage: rows of 64 bytes (32 k), 16-byte chunk c of row r at position c ^ ((r >> 2) & 3): the 32-row
-  // fragment reads (ds_read_b128: lane -> row lane & 31, chunk 2 * sub-step + (lane >> 5)) are bank-conflict free
-  // ---- DMA side: piece j of this wave = rows (wave * 4 + j) * 16 .. + 15 of the tile (1 KB of the image); the per-lane
-  // offset carries the row inside the piece and the swizzled source chunk, the scalar offset K and the piece's row block
-  const int lrow = lane >> 2, cpos = lane & 3;
-  const int chunk = cpos ^ ((lrow >> 2) & 3);
-  const int step_a = __builtin_amdgcn_readfirstlane(32 * p.lda), step_w = __builtin_amdgcn_readfirstlane(32 * p.ldw);
-  const int v_a = ((wave * NPC * 16 + lrow) * p.lda + chunk * 8) * 2;
-  const int v_w = ((wave * NPC * 16 + lrow) * p.ldw + chunk * 8) * 2;
-  auto rsrc_of = [&](const bf16* base, long long bytes) -> w4_u32x4 {
-    const unsigned long long a = (unsigned long long)base;
-    w4_u32x4 r;
-    r[0] = __builtin_amdgcn_readfirstlane((unsigned)a);
-    r[1] = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32) & 0xffffu);
-    r[2] = __builtin_amdgcn_readfirstlane((unsigned)(bytes < 0x7f000000LL ? bytes : 0x7f000000LL));
-    r[3] = 0x00020000u;
-    return r;
-  };
-  w4_u32x4 ra, rw;
-  auto setup = [&](int ti) {
-    int bm, bn;
-    tile_of(ti, bm, bn);
-    ra = rsrc_of(p.A + (long long)bm * BM * p.lda, (long long)(p.M - bm * BM) * p.lda * 2);
-    rw = rsrc_of(p.W + (long long)bn * BN * p.ldw, (long long)(p.N - bn * BN) * p.ldw * 2);
-  };
-  auto issue = [&](int st, int kstep) {            // the four steps the asm loop does not issue itself (0..3 of a tile)
-    char* base = smem + st * STAGE + wave * NPC * 1024;
-    const __amdgpu_buffer_rsrc_t ba = __builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long long)ra[1] << 32) | ra[0]), 0, (int)ra[2], 0x00020000);
-    const __amdgpu_buffer_rsrc_t bw = __builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long long)rw[1] << 32) | rw[0]), 0, (int)rw[2], 0x00020000);
-#pragma unroll
-    for (int j = 0; j < NPC; ++j)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(ba, PEA_LDS(base + j * 1024), 16, v_a, kstep * 64 + j * step_a, 0, 0);
-#pragma unroll
-    for (int j = 0; j < NPC; ++j)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(bw, PEA_LDS(base + A_BYTES + j * 1024), 16, v_w, kstep * 64 + j * step_w, 0, 0);
-  };
-  // ---- MFMA side: lane -> row (lane & 31) of a 32-row fragment, k-group lane >> 5
-  constexpr int WN = NI == 4 ? 2 : 4;                              // wave columns
-  const int wr = wave / WN, wc = wave % WN;
-  const int frow = lane & 31, fh = lane >> 5;
-  auto swz64 = [](int row, int c) { return row * 64 + ((c ^ ((row >> 2) & 3)) << 4); };
-  const int fa0 = swz64(wr * 128 + frow, fh), fw0 = swz64(wc * (32 * NI) + frow, fh);
-  int cur = 0;
-  setup(0);
-#pragma unroll
-  for (int i = 0; i < NSTG; ++i) issue(i, i);
-  for (int ti = 0; ti < my_n; ++ti) {
-    f32x16 acc[NI][4];
-    if constexpr (NI == 4) {
-      f32x16 c00, c01, c02, c03, c10, c11, c12, c13, c20, c21, c22, c23, c30, c31, c32, c33;
-      asm volatile(W4_LOOP_ASM_4
-                   : "=&a"(c00), "=&a"(c01), "=&a"(c02), "=&a"(c03), "=&a"(c10), "=&a"(c11), "=&a"(c12), "=&a"(c13), "=&a"(c20), "=&a"(c21), "=&a"(c22), "=&a"(c23), "=&a"(c30), "=&a"(c31), "=&a"(c32), "=&a"(c33)
-                   : "v"(fa0), "v"(fw0), "v"(v_a), "v"(v_w), "s"(ra), "s"(rw), "s"(step_a), "s"(step_w), "s"(nt),
-                     "s"(wave * NPC * 1024), "s"(cur)
-                   : W4_LOOP_CLOBBERS_4);
-      acc[0][0] = c00; acc[0][1] = c01; acc[0][2] = c02; acc[0][3] = c03; acc[1][0] = c10; acc[1][1] = c11; acc[1][2] = c12; acc[1][3] = c13;
-      acc[NI - 2][0] = c20; acc[NI - 2][1] = c21; acc[NI - 2][2] = c22; acc[NI - 2][3] = c23; acc[NI - 1][0] = c30; acc[NI - 1][1] = c31; acc[NI - 1][2] = c32; acc[NI - 1][3] = c33;
-    } else {
-      f32x16 c00, c01, c02, c03, c10, c11, c12, c13;
-      asm volatile(W4_LOOP_ASM_2
-                   : "=&a"(c00), "=&a"(c01), "=&a"(c02), "=&a"(c03), "=&a"(c10), "=&a"(c11), "=&a"(c12), "=&a"(c13)
-                   : "v"(fa0), "v"(fw0), "v"(v_a), "v"(v_w), "s"(ra), "s"(rw), "s"(step_a), "s"(step_w), "s"(nt),
-                     "s"(wave * NPC * 1024), "s"(cur)
-                   : W4_LOOP_CLOBBERS_2);
-      acc[0][0] = c00; acc[0][1] = c01; acc[0][2] = c02; acc[0][3] = c03; acc[1][0] = c10; acc[1][1] = c11; acc[1][2] = c12; acc[1][3] = c13;
-    }
-    cur = (cur + nt) & 3;
-    int bm, bn;
-    tile_of(ti, bm, bn);
-    if (ti + 1 < my_n) {                           // the next tile's first four steps land under this tile's epilogue
-      setup(ti + 1);
-#pragma unroll
-      for (int i = 0; i < NSTG; ++i) issue((cur + i) & 3, i);
-    }
-    // epilogue, one 32 x 32 accumulator at a time: the tuple is first pulled from the accumulation registers into vector
-    // registers (behind the generic epilogue hipcc spilled all 256 of them to scratch instead)
-#pragma unroll
-    for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-      for (int mi = 0; mi < 4; ++mi) {
-        f32x16 t = acc[ni][mi];
-        asm volatile("" : "+v"(t));
-        const int m = bm * BM + wr * 128 + mi * 32 + frow;
-        bf16* crow = (bf16*)p.C + (long long)m * p.ldc;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const int n = bn * BN + wc * (32 * NI) + ni * 32 + 8 * g + 4 * fh;
-          f32x4 b = {0.f, 0.f, 0.f, 0.f};
-          if (p.bias) b = *(const f32x4*)(p.bias + n);
-          bf16x4 o;
-#pragma unroll
-          for (int j = 0; j < 4; ++j) o[j] = (bf16)(t[4 * g + j] * p.alpha + b[j]);
-          *(bf16x4*)(crow + n) = o;
-        }
-      }
-  }
-#endif
-}
-
-static bool w4_ok(const GemmP& p) {
-  return p.mode == 0 && p.ksplit <= 1 && p.M % 256 == 0 && p.N % 256 == 0 && p.K >= 160 && p.lda % 32 == 0 && p.ldw % 32 == 0 &&
-         !p.ln_stats && !p.gbwd_pre;
-}
-template <int NI>
-static int launch_w4(const GemmP& p, hipStream_t stream) {
-  constexpr int lds = 4 * (256 + 256) * 64;
-  static bool attr_set = false;
-  if (!attr_set) {
-    HIPCHK(hipFuncSetAttribute((const void*)gemm_w4_kernel<NI>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    attr_set = true;
-  }
-  if (!g_num_cus) HIPCHK(gemm_query_cus());
-  SHAPECHK(w4_ok(p), "gemm: the four-wave kernel takes plain GEMMs with M, N multiples of 256, lda / ldw of 64, K >= 192");
-  const int tiles = (p.M / 256) * (p.N / 256);
-  const int grid = tiles < g_num_cus ? tiles : g_num_cus;
-  hipLaunchKernelGGL(gemm_w4_kernel<NI>, dim3(grid), dim3(1024 / NI), lds, stream, p);
-  return PEA_OK;
-}
-
 // ---- variant table (tile shape x wave grid x ring depth); the launcher picks one per problem shape
 int g_gemm_variant = -1;   // >= 0: forced (benchmark / debug)
 extern "C" void pea_debug_set_gemm_variant(int v) { g_gemm_variant = v; }
@@ -1573,8 +1412,6 @@ extern "C" void pea_debug_set_gemm_variant(int v) { g_gemm_variant = v; }
     case 24: rc = launch_lc<MODE, 256, 160, 4, 2, 4, 3, false, true>(p, stream); break; \
     case 25: rc = launch_lc<MODE, 128, 160, 4, 2, 4, 3, false, true>(p, stream); break; \
     case 27: rc = launch_lcp<MODE, 256, 160, 4, 2, 4, 3, 0, 0, 1>(p, stream); break; \
-    case 40: rc = w4_ok(p) ? launch_w4<4>(p, stream) : launch_lcp<MODE, 128, 160, 4, 2, 4, 3>(p, stream); break; \
-    case 41: rc = w4_ok(p) ? launch_w4<2>(p, stream) : launch_lcp<MODE, 128, 160, 4, 2, 4, 3>(p, stream); break; \
     case 28: rc = launch_lcp<MODE, 128, 160, 4, 2, 4, 3>(p, stream); break; \
     case 29: rc = launch_lcp<MODE, 128, 160, 2, 2, 4, 4>(p, stream); break; \
     case 30: rc = launch_lcp<MODE, 128, 128, 2, 2, 4, 4>(p, stream); break; \
