@@ -8,6 +8,8 @@ Tolerances (written here, used everywhere below):
     differently-ordered fp32 accumulation can flip the final rounding of an element.
 """
 import math
+import os
+import sys
 
 import pytest
 import torch
@@ -578,3 +580,15 @@ def test_attention_text_masks(ops, B, H, S, causal, padded):
                                  kv_len=lens.to(torch.int32).cuda() if padded else None)
     # with causal + padding a query row can lie beyond the valid keys only through padding; every row keeps key 0
     close_bf16(f"attn text B{B} H{H} S{S} causal={causal} padded={padded}", o, ref, ulps=2.0)   # as the other attention outputs
+
+
+def test_gemm_tile_rules_on_a_smaller_device(ops):
+    """The launcher's tile rules and persistent grids take the CU count from the device (a CPX partition of an MI355X has 32 CUs)
+    or from PEA_CU_LIMIT: the plain / epilogue / GEGLU GEMM tests again in a child process limited to 40 CUs."""
+    import subprocess
+    env = dict(os.environ, PEA_CU_LIMIT="40")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu", "-k",
+                        "test_gemm_plain or test_gemm_epilogues or test_gemm_geglu_forward_and_stash_forms or test_conv3x3"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout and "failed" not in r.stdout
