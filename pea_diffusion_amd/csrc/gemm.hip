@@ -529,6 +529,107 @@ __device__ __forceinline__ void gemm_epilogue16_fast(const GemmP& p, f32x4 (&acc
   else body(std::false_type{});
 }
 
+// Folded-LayerNorm epilogue (LN(x) W^T = rstd (x W'^T - mean s) + t with W' = gamma * W, s = rowsum(W'), t = W beta + bias):
+//   value = c1[m] * acc + (c2[m] * s[n] + t[n]),  c1 = rstd, c2 = -rstd * mean   (p.ln_stats = [M][2] (mean, rstd), p.ln_s = s, p.bias = t)
+// N-tile PAIRS outermost, 16-row blocks inside: only one pair's (s, t) quads and the row constants are live beside the
+// accumulators (the generic epilogue, 16-row blocks outermost, held s and t of the whole wave tile and spilled 27 registers in
+// the 256 x 160 persistent kernel: 104 against 76 us on M8192 N3840 K1280).  Handles what the three folded Linears need: the
+// column scale (Q prescale), GEGLU with the stash forms, plain bf16 output; no residual / row vector.
+template <int MT, int NT>
+__device__ __forceinline__ void gemm_epilogue16_lnf(const GemmP& p, f32x4 (&acc)[NT][MT], int m_base, int n_base, int r16, int q4) {
+  typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+  typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+  float c1[MT], c2[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    const float2 st = *(const float2*)(p.ln_stats + 2 * (long long)min(m_base + mt * 16 + r16, p.M - 1));
+    c1[mt] = st.y;
+    c2[mt] = -st.y * st.x;
+  }
+  const int nv = max(0, min(NT, (p.N - n_base) >> 4));                  // n-tiles of the wave tile inside N (N % 16 == 0)
+#pragma unroll
+  for (int pr = 0; pr < (NT + 1) / 2; ++pr) {
+    const int nt0 = 2 * pr, nt1 = 2 * pr + 1;
+    if (nt0 >= nv) continue;
+    const bool paired = nt1 < NT && nt1 < nv;
+    const int na = min(n_base + nt0 * 16 + 4 * q4, p.N - 4), nb = min(n_base + (nt1 < NT ? nt1 : nt0) * 16 + 4 * q4, p.N - 4);
+    f32x4 sa = *(const f32x4*)(p.ln_s + na), ta = *(const f32x4*)(p.bias + na);
+    f32x4 sb = sa, tb = ta;
+    if (paired) { sb = *(const f32x4*)(p.ln_s + nb); tb = *(const f32x4*)(p.bias + nb); }
+    const float fa = (n_base + nt0 * 16 < p.qscale_cols) ? p.qscale : 1.f, fb = (n_base + nt1 * 16 < p.qscale_cols) ? p.qscale : 1.f;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const int m = m_base + mt * 16 + r16;
+      if (m >= p.M) continue;                                           // r16 only: swap partners agree
+      float v0[4], v1[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        v0[j] = fmaf(c1[mt], acc[nt0][mt][j], fmaf(c2[mt], sa[j], ta[j])) * fa;
+        v1[j] = fmaf(c1[mt], acc[nt1 < NT ? nt1 : nt0][mt][j], fmaf(c2[mt], sb[j], tb[j])) * fb;
+      }
+      if (p.geglu_y) {
+        const bool stash = p.C && !(p.stash_rows > 0 && m >= p.stash_rows);
+        bf16* yrow = p.geglu_y + (long long)m * p.ldy;
+        bf16* crow = (bf16*)p.C + (long long)m * p.ldc;
+        union { bf16x2 h; unsigned u; } y0, y1;
+        auto geglu2 = [&](float (&v)[4], bf16x2& y) {
+          if (stash && p.stash_grad) {
+            float ga, gb, da, db;
+            gelu_val_grad(v[1], ga, da);
+            gelu_val_grad(v[3], gb, db);
+            y[0] = (bf16)(v[0] * ga);
+            y[1] = (bf16)(v[2] * gb);
+            v[1] = v[0] * da; v[0] = ga; v[3] = v[2] * db; v[2] = gb;
+          } else {
+            y[0] = (bf16)(v[0] * gelu_erf(v[1]));
+            y[1] = (bf16)(v[2] * gelu_erf(v[3]));
+          }
+        };
+        geglu2(v0, y0.h);
+        if (paired) {
+          geglu2(v1, y1.h);
+          const auto w = __builtin_amdgcn_permlane16_swap(y0.u, y1.u, false, false);
+          const u32x2 o = {w[0], w[1]};
+          *(u32x2*)(yrow + ((n_base + (nt0 + (q4 & 1)) * 16) >> 1) + 4 * (q4 >> 1)) = o;
+          if (stash) {
+            union { bf16x4 h; unsigned u[2]; } a, b;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { a.h[j] = (bf16)v0[j]; b.h[j] = (bf16)v1[j]; }
+            const auto lo = __builtin_amdgcn_permlane16_swap(a.u[0], b.u[0], false, false);
+            const auto hi = __builtin_amdgcn_permlane16_swap(a.u[1], b.u[1], false, false);
+            const u32x4 oc = {lo[0], hi[0], lo[1], hi[1]};
+            *(u32x4*)(crow + n_base + (nt0 + (q4 & 1)) * 16 + 8 * (q4 >> 1)) = oc;
+          }
+        } else {
+          *(bf16x2*)(yrow + ((n_base + nt0 * 16 + 4 * q4) >> 1)) = y0.h;
+          if (stash) {
+            bf16x4 oc;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) oc[j] = (bf16)v0[j];
+            *(bf16x4*)(crow + n_base + nt0 * 16 + 4 * q4) = oc;
+          }
+        }
+        continue;
+      }
+      bf16* crow = (bf16*)p.C + (long long)m * p.ldc;
+      if (paired) {
+        union { bf16x4 h; unsigned u[2]; } a, b;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { a.h[j] = (bf16)v0[j]; b.h[j] = (bf16)v1[j]; }
+        const auto lo = __builtin_amdgcn_permlane16_swap(a.u[0], b.u[0], false, false);
+        const auto hi = __builtin_amdgcn_permlane16_swap(a.u[1], b.u[1], false, false);
+        const u32x4 o = {lo[0], hi[0], lo[1], hi[1]};
+        *(u32x4*)(crow + n_base + (nt0 + (q4 & 1)) * 16 + 8 * (q4 >> 1)) = o;
+      } else {
+        bf16x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = (bf16)v0[j];
+        *(bf16x4*)(crow + n_base + nt0 * 16 + 4 * q4) = o;
+      }
+    }
+  }
+}
+
 // lean slice epilogue for the deferred form: alpha, optional bias, bf16 output (ldc % 8 == 0, C 16-byte aligned: the
 // launcher's rule); few live values, so it can sit inside the K-loop
 template <int MT, int NT, int M0, int M1>
@@ -840,7 +941,7 @@ __global__ __launch_bounds__((WM * WN + LW) * 64, MINW) void gemm_lc_kernel(cons
       cur = nxt;
     }
     if constexpr (LNF) {
-      gemm_epilogue16_fast<MT, NT, 1>(p, acc, bm * BM + wr * (BM / WM), bn * BN + wc * (BN / WN), r16, q4);
+      gemm_epilogue16_lnf<MT, NT>(p, acc, bm * BM + wr * (BM / WM), bn * BN + wc * (BN / WN), r16, q4);
       return;
     }
     if (p.epi_fast) {
@@ -1341,7 +1442,8 @@ __global__ __launch_bounds__((WM * WN + LW + SW) * 64, (OCC == 2 ? 3 : 1)) void 
         // inside the epilogue instead of being hoisted to kernel entry and kept (spilled) across the whole tile loop
         int r16e = r16, q4e = q4;
         asm volatile("" : "+v"(r16e), "+v"(q4e));
-        if (!PEA_PROBE(16)) gemm_epilogue16_fast<MT, NT, (EPI == 2 ? 1 : EPI == 3 ? 2 : 0)>(p, acc, bm * BM + wr * (BM / WM), bn * BN + wc * (BN / WN), r16e, q4e);
+        if constexpr (EPI == 2) gemm_epilogue16_lnf<MT, NT>(p, acc, bm * BM + wr * (BM / WM), bn * BN + wc * (BN / WN), r16e, q4e);
+        else if (!PEA_PROBE(16)) gemm_epilogue16_fast<MT, NT, (EPI == 3 ? 2 : 0)>(p, acc, bm * BM + wr * (BM / WM), bn * BN + wc * (BN / WN), r16e, q4e);
         else if (acc[0][0][0] == 12345.678f) *(float*)p.C = 1.f;   // timing probe: keep the accumulators alive
         // the next tile's first fragments were fetched at the last barrier already; fetching them AGAIN here makes that
         // copy dead across the epilogue, so its 36 registers are free for the residual quads (the K-loop body itself
