@@ -923,20 +923,27 @@ __global__ __launch_bounds__((WM * WN + LW) * 64, MINW) void gemm_lc_kernel(cons
       const int nxt = cur + 1 == S ? 0 : cur + 1;
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
+        bool late_frags = false;
         if (s2 == 1) {
           if (t + 1 < nt) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();                      // barrier_t
-            load_frags(0, smem + nxt * STAGE, 0);
+            late_frags = true;                                 // K-step t+1's first fragments: behind this half's first MFMAs (see gemm_lcp_kernel)
           }
         } else {
           load_frags(1, tile, 1);
         }
 #pragma unroll
-        for (int nt_ = 0; nt_ < NT; ++nt_)
+        for (int nt_ = 0; nt_ < NT; ++nt_) {
 #pragma unroll
           for (int mt = 0; mt < MT; ++mt)
             acc[nt_][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[s2][nt_], af[s2][mt], acc[nt_][mt], 0, 0, 0);
+          if (s2 == 1 && nt_ == 0) {
+            __builtin_amdgcn_sched_barrier(0);
+            if (late_frags) load_frags(0, smem + nxt * STAGE, 0);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
       }
       cur = nxt;
     }
@@ -1361,11 +1368,15 @@ __global__ __launch_bounds__((WM * WN + LW + SW) * 64, (OCC == 2 ? 3 : 1)) void 
       }
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
+        bool late_frags = false;
         if (s2 == 1) {
           if (g + 1 < G) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             if (!PEA_PROBE(2)) __builtin_amdgcn_s_barrier();   // barrier_g
-            if (!PEA_PROBE(4)) load_frags(0, smem + nxt * STAGE, 0);    // first fragments of K-step g+1 (maybe the next tile's)
+            // first fragments of K-step g+1 (maybe the next tile's): issued BEHIND this half's first MFMAs -- except in the fused
+            // GEGLU-backward instantiations, whose register allocation turns that into +33 % on the whole launch
+            if constexpr (EPI == 3) { if (!PEA_PROBE(4)) load_frags(0, smem + nxt * STAGE, 0); }
+            else late_frags = true;
           } else if (SW > 0) {
             __builtin_amdgcn_s_barrier();                      // staged form: the last K-step keeps its barrier
           }
@@ -1373,10 +1384,18 @@ __global__ __launch_bounds__((WM * WN + LW + SW) * 64, (OCC == 2 ? 3 : 1)) void 
           if (!PEA_PROBE(4)) load_frags(1, tile, 1);
         }
 #pragma unroll
-        for (int nt_ = 0; nt_ < NT; ++nt_)
+        for (int nt_ = 0; nt_ < NT; ++nt_) {
 #pragma unroll
           for (int mt = 0; mt < MT; ++mt)
             acc[nt_][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[s2][nt_], af[s2][mt], acc[nt_][mt], 0, 0, 0);
+          if (EPI != 3 && s2 == 1 && nt_ == 0) {
+            // (issued right behind the barrier, hipcc's wait in front of this half's first MFMA covered these reads as well: every
+            // wave of the CU then sat out an LDS round trip per K-step with the MFMA pipes idle)
+            __builtin_amdgcn_sched_barrier(0);
+            if (late_frags && !PEA_PROBE(4)) load_frags(0, smem + nxt * STAGE, 0);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
       }
       cur = nxt;
     }
