@@ -406,16 +406,17 @@ __device__ __forceinline__ void gemm_epilogue16_fast(const GemmP& p, f32x4 (&acc
       // GEGLU backward in the epilogue of the FF output projection's dgrad: a lane's 4 columns n..n+3 of d y meet the 4 stashed
       // (h, gate) pairs at columns 2n..2n+7 (one 16-byte load) and leave as 4 (dh, dgate) pairs (one 16-byte store; the four
       // lanes of a row cover 64 contiguous bytes).  Pairs one 16-row block ahead, as the residual quads below.
-      bf16x8 pq[2][NT];
-      auto load_pre = [&](int buf, int mt) {
+      // (one buffer: two -- the next 16-row block's pairs in flight under this block's arithmetic -- cost the 256 x 160 persistent
+      // instantiation 16 spilled registers, among them loop invariants it then reloaded from scratch in every K-step)
+      bf16x8 pq[NT];
+      auto load_pre = [&](int mt) {
         const long long mo = (long long)min(m_base + mt * 16 + r16, p.M - 1) * p.ldgp;
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) pq[buf][nt] = *(const bf16x8*)(p.gbwd_pre + mo + 2 * min(n_base + nt * 16 + 4 * q4, p.N - 4));
+        for (int nt = 0; nt < NT; ++nt) pq[nt] = *(const bf16x8*)(p.gbwd_pre + mo + 2 * min(n_base + nt * 16 + 4 * q4, p.N - 4));
       };
-      load_pre(0, 0);
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
-        if (mt + 1 < MT) load_pre((mt + 1) & 1, mt + 1);
+        load_pre(mt);
         __builtin_amdgcn_sched_barrier(0);
         const int m = m_base + mt * 16 + r16;
         bf16* crow = (bf16*)p.C + (long long)min(m, p.M - 1) * p.ldc;
@@ -428,10 +429,10 @@ __device__ __forceinline__ void gemm_epilogue16_fast(const GemmP& p, f32x4 (&acc
             float dh, dg;
             if (p.gbwd_form) {        // the stash holds (gelu(gate), h * gelu'(gate)): two multiplies
               const float d = val(nt, mt, j);
-              dh = d * (float)pq[mt & 1][nt][2 * j];
-              dg = d * (float)pq[mt & 1][nt][2 * j + 1];
+              dh = d * (float)pq[nt][2 * j];
+              dg = d * (float)pq[nt][2 * j + 1];
             } else {
-              geglu_pair_bwd((float)pq[mt & 1][nt][2 * j], (float)pq[mt & 1][nt][2 * j + 1], val(nt, mt, j), dh, dg);
+              geglu_pair_bwd((float)pq[nt][2 * j], (float)pq[nt][2 * j + 1], val(nt, mt, j), dh, dg);
             }
             o[2 * j] = (bf16)dh;
             o[2 * j + 1] = (bf16)dg;
@@ -1329,8 +1330,17 @@ __global__ __launch_bounds__((WM * WN + LW + SW) * 64, (OCC == 2 ? 3 : 1)) void 
   // fragment addresses as (per-lane base) + (compile-time offset): rows 16 apart share the swizzle term ((row >> 1) & 7)
   // and the two k32 halves differ by XOR 64 bytes, so FOUR per-lane offsets address all 2 x (MT + NT) fragments (the
   // per-fragment form kept up to 18 loop-invariant address registers live beside 152 accumulator + fragment registers)
-  const int a_off[2] = {swz_off(a_row0, q4), swz_off(a_row0, 4 + q4)};
-  const int w_off[2] = {A_BYTES + swz_off(w_row0, q4), A_BYTES + swz_off(w_row0, 4 + q4)};
+  int a_off[2] = {swz_off(a_row0, q4), swz_off(a_row0, 4 + q4)};
+  int w_off[2] = {A_BYTES + swz_off(w_row0, q4), A_BYTES + swz_off(w_row0, 4 + q4)};
+  // re-derived at the top of every tile from laundered lane ids (same values): the four registers are then not live across the
+  // epilogue -- where the fused GEGLU-backward instantiation spilled them and RELOADED them from scratch in every K-step
+  auto frag_offsets = [&]() {
+    int r16l = r16, q4l = q4;
+    asm volatile("" : "+v"(r16l), "+v"(q4l));
+    const int ar = wr * (BM / WM) + r16l, wrw = wc * (BN / WN) + r16l;
+    a_off[0] = swz_off(ar, q4l); a_off[1] = swz_off(ar, 4 + q4l);
+    w_off[0] = A_BYTES + swz_off(wrw, q4l); w_off[1] = A_BYTES + swz_off(wrw, 4 + q4l);
+  };
   auto load_frags = [&](int which, const char* tile, int s2) {
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) af[which][mt] = *(const bf16x8*)(tile + a_off[s2] + mt * 2048);
@@ -1360,6 +1370,7 @@ __global__ __launch_bounds__((WM * WN + LW + SW) * 64, (OCC == 2 ? 3 : 1)) void 
     for (int i = 0; i < NT; ++i)
 #pragma unroll
       for (int j = 0; j < MT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (ti > 0) frag_offsets();
     for (int t = 0; t < nt; ++t, ++g) {
       const char* tile = smem + cur * STAGE;
       const int nxt = cur + 1 == S ? 0 : cur + 1;
@@ -1373,10 +1384,7 @@ __global__ __launch_bounds__((WM * WN + LW + SW) * 64, (OCC == 2 ? 3 : 1)) void 
           if (g + 1 < G) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             if (!PEA_PROBE(2)) __builtin_amdgcn_s_barrier();   // barrier_g
-            // first fragments of K-step g+1 (maybe the next tile's): issued BEHIND this half's first MFMAs -- except in the fused
-            // GEGLU-backward instantiations, whose register allocation turns that into +33 % on the whole launch
-            if constexpr (EPI == 3) { if (!PEA_PROBE(4)) load_frags(0, smem + nxt * STAGE, 0); }
-            else late_frags = true;
+            late_frags = true;                                 // first fragments of K-step g+1 (maybe the next tile's): issued BEHIND this half's first MFMAs
           } else if (SW > 0) {
             __builtin_amdgcn_s_barrier();                      // staged form: the last K-step keeps its barrier
           }
@@ -1388,7 +1396,7 @@ __global__ __launch_bounds__((WM * WN + LW + SW) * 64, (OCC == 2 ? 3 : 1)) void 
 #pragma unroll
           for (int mt = 0; mt < MT; ++mt)
             acc[nt_][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[s2][nt_], af[s2][mt], acc[nt_][mt], 0, 0, 0);
-          if (EPI != 3 && s2 == 1 && nt_ == 0) {
+          if (s2 == 1 && nt_ == 0) {
             // (issued right behind the barrier, hipcc's wait in front of this half's first MFMA covered these reads as well: every
             // wave of the CU then sat out an LDS round trip per K-step with the MFMA pipes idle)
             __builtin_amdgcn_sched_barrier(0);
