@@ -931,17 +931,18 @@ __global__ __launch_bounds__((WM * WN + LW) * 64, MINW) void gemm_lc_kernel(cons
             __builtin_amdgcn_s_barrier();                      // barrier_t
             late_frags = true;                                 // K-step t+1's first fragments: behind this half's first MFMAs (see gemm_lcp_kernel)
           }
-        } else {
-          load_frags(1, tile, 1);
+        } else if (MT < 4) {
+          load_frags(1, tile, 1);                              // (32-row wave tiles: hipcc's own placement measures better)
         }
 #pragma unroll
         for (int nt_ = 0; nt_ < NT; ++nt_) {
 #pragma unroll
           for (int mt = 0; mt < MT; ++mt)
             acc[nt_][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[s2][nt_], af[s2][mt], acc[nt_][mt], 0, 0, 0);
-          if (s2 == 1 && nt_ == 0) {
+          if (nt_ == 0 && (s2 == 1 || MT >= 4)) {             // the other half's fragments behind this half's first MFMAs
             __builtin_amdgcn_sched_barrier(0);
-            if (late_frags) load_frags(0, smem + nxt * STAGE, 0);
+            if (s2 == 0) load_frags(1, tile, 1);
+            else if (late_frags) load_frags(0, smem + nxt * STAGE, 0);
             __builtin_amdgcn_sched_barrier(0);
           }
         }
@@ -1388,14 +1389,19 @@ __global__ __launch_bounds__((WM * WN + LW + SW) * 64, (OCC == 2 ? 3 : 1)) void 
           } else if (SW > 0) {
             __builtin_amdgcn_s_barrier();                      // staged form: the last K-step keeps its barrier
           }
-        } else {
-          if (!PEA_PROBE(4)) load_frags(1, tile, 1);
+        } else if (MT < 4) {
+          if (!PEA_PROBE(4)) load_frags(1, tile, 1);           // (32-row wave tiles: hipcc's own placement measures better)
         }
 #pragma unroll
         for (int nt_ = 0; nt_ < NT; ++nt_) {
 #pragma unroll
           for (int mt = 0; mt < MT; ++mt)
             acc[nt_][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[s2][nt_], af[s2][mt], acc[nt_][mt], 0, 0, 0);
+          if (MT >= 4 && s2 == 0 && nt_ == 0) {                // this K-step's second-half fragments, behind the first MFMAs as well
+            __builtin_amdgcn_sched_barrier(0);
+            if (!PEA_PROBE(4)) load_frags(1, tile, 1);
+            __builtin_amdgcn_sched_barrier(0);
+          }
           if (s2 == 1 && nt_ == 0) {
             // (issued right behind the barrier, hipcc's wait in front of this half's first MFMA covered these reads as well: every
             // wave of the CU then sat out an LDS round trip per K-step with the MFMA pipes idle)
