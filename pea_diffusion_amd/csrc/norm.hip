@@ -573,6 +573,17 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const bf16* __restrict__ x,
       if (ck < nchunk) v[r][i] = *(const bf16x8*)(x + (long long)row * C + ck * 8);
     }
   }
+  // gamma / beta requested with the rows (read behind the reductions they added a second memory round trip to the wave's
+  // critical path)
+  f32x4 g0[STATS_ONLY ? 1 : NCH], g1[STATS_ONLY ? 1 : NCH], b0[STATS_ONLY ? 1 : NCH], b1[STATS_ONLY ? 1 : NCH];
+  if constexpr (!STATS_ONLY) {
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int ck = min(lane + 64 * i, nchunk - 1);
+      g0[i] = *(const f32x4*)(gamma + ck * 8); g1[i] = *(const f32x4*)(gamma + ck * 8 + 4);
+      b0[i] = *(const f32x4*)(beta + ck * 8); b1[i] = *(const f32x4*)(beta + ck * 8 + 4);
+    }
+  }
   float mean[LN_NR], rstd[LN_NR];
 #pragma unroll
   for (int r = 0; r < LN_NR; ++r) {
@@ -603,16 +614,14 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const bf16* __restrict__ x,
   for (int i = 0; i < NCH; ++i) {
     const int ck = lane + 64 * i;
     if (ck < nchunk) {
-      const f32x4 g0 = *(const f32x4*)(gamma + ck * 8), g1 = *(const f32x4*)(gamma + ck * 8 + 4);
-      const f32x4 b0 = *(const f32x4*)(beta + ck * 8), b1 = *(const f32x4*)(beta + ck * 8 + 4);
 #pragma unroll
       for (int r = 0; r < LN_NR; ++r) {
         if (row0 + r >= R) break;
         bf16x8 o;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          o[j] = (bf16)(((float)v[r][i][j] - mean[r]) * rstd[r] * g0[j] + b0[j]);
-          o[4 + j] = (bf16)(((float)v[r][i][4 + j] - mean[r]) * rstd[r] * g1[j] + b1[j]);
+          o[j] = (bf16)(((float)v[r][i][j] - mean[r]) * rstd[r] * g0[STATS_ONLY ? 0 : i][j] + b0[STATS_ONLY ? 0 : i][j]);
+          o[4 + j] = (bf16)(((float)v[r][i][4 + j] - mean[r]) * rstd[r] * g1[STATS_ONLY ? 0 : i][j] + b1[STATS_ONLY ? 0 : i][j]);
         }
         *(bf16x8*)(y + (long long)(row0 + r) * C + ck * 8) = o;
       }

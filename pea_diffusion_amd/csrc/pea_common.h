@@ -94,32 +94,46 @@ __device__ __forceinline__ float silu_grad(float x) {
   return s * (1.0f + x * (1.0f - s));
 }
 
-// Butterfly reductions over the 64 lanes.  The four steps inside a 16-lane row are DPP moves (one VALU instruction each:
-// quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_half_mirror, row_mirror -- after each step every lane of the group holds
-// the group's value, so the mirrors act as the xor-4 / xor-8 exchanges); only the two cross-row steps go through
-// ds_bpermute.  The all-__shfl_xor form compiled to six dependent ds_bpermute round trips (the LayerNorm kernels spent
-// most of their time in them).
+// Butterfly reductions over the 64 lanes, without LDS.  The four steps inside a 16-lane row are DPP moves (one VALU
+// instruction each: quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_half_mirror, row_mirror -- after each step every lane of
+// the group holds the group's value, so the mirrors act as the xor-4 / xor-8 exchanges); the two cross-row steps are
+// v_permlane16_swap (odd rows of one copy <-> even rows of the other: the sum of the two copies is the xor-16 step) and
+// v_permlane32_swap (upper half <-> lower half: xor-32).  As ds_bpermute round trips those two steps were ~250 cycles of
+// every reduction -- eight of them in a row on the critical path of a LayerNorm wave.  (Inline assembly: with fp32 operands
+// bit-cast in and out of the builtins hipcc 7.2 folds the second result onto the first; the s_nops are the VALU hazards.)
 template <int CTRL>
 __device__ __forceinline__ float dpp_move(float v) {
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ void swap_rows16(float& a, float& b) {
+  asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+}
+__device__ __forceinline__ void swap_halves32(float& a, float& b) {
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
 }
 __device__ __forceinline__ float wave_sum(float v) {
   v += dpp_move<0xB1>(v);
   v += dpp_move<0x4E>(v);
   v += dpp_move<0x141>(v);
   v += dpp_move<0x140>(v);
-  v += __shfl_xor(v, 16, 64);
-  v += __shfl_xor(v, 32, 64);
-  return v;
+  float a = v, b = v;
+  swap_rows16(a, b);
+  v = a + b;
+  a = v; b = v;
+  swap_halves32(a, b);
+  return a + b;
 }
 __device__ __forceinline__ float wave_max(float v) {
   v = fmaxf(v, dpp_move<0xB1>(v));
   v = fmaxf(v, dpp_move<0x4E>(v));
   v = fmaxf(v, dpp_move<0x141>(v));
   v = fmaxf(v, dpp_move<0x140>(v));
-  v = fmaxf(v, __shfl_xor(v, 16, 64));
-  v = fmaxf(v, __shfl_xor(v, 32, 64));
-  return v;
+  float a = v, b = v;
+  swap_rows16(a, b);
+  v = fmaxf(a, b);
+  a = v; b = v;
+  swap_halves32(a, b);
+  return fmaxf(a, b);
 }
 
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
