@@ -569,8 +569,8 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const bf16* __restrict__ x,
     const int row = min(row0 + r, R - 1);
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
-      const int ck = lane + 64 * i;
-      if (ck < nchunk) v[r][i] = *(const bf16x8*)(x + (long long)row * C + ck * 8);
+      const int ck = min(lane + 64 * i, nchunk - 1);          // (clamped: every request of the wave leaves in one batch, no branches)
+      v[r][i] = *(const bf16x8*)(x + (long long)row * C + ck * 8);
     }
   }
   // gamma / beta requested with the rows (read behind the reductions they added a second memory round trip to the wave's
@@ -645,24 +645,27 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16* __restrict__ x,
     const int row = min(row0 + r, R - 1);
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
-      const int ck = lane + 64 * i;
-      if (ck < nchunk) {
-        xv[r][i] = *(const bf16x8*)(x + (long long)row * C + ck * 8);
-        dv[r][i] = *(const bf16x8*)(dy + (long long)row * C + ck * 8);
-        if (add) av[r][i] = *(const bf16x8*)(add + (long long)row * C + ck * 8);   // may be dx itself (in-place accumulate)
-      }
+      const int ck = min(lane + 64 * i, nchunk - 1);          // (clamped: all requests of the wave leave in one batch, no branches)
+      xv[r][i] = *(const bf16x8*)(x + (long long)row * C + ck * 8);
+      dv[r][i] = *(const bf16x8*)(dy + (long long)row * C + ck * 8);
+      if (add) av[r][i] = *(const bf16x8*)(add + (long long)row * C + ck * 8);   // may be dx itself (in-place accumulate)
     }
   }
+  // gamma and BOTH rows' statistics with the rows: requested behind the first row's arithmetic / store they put two more memory
+  // round trips on the wave's critical path
   f32x4 g0[NCH], g1[NCH];
 #pragma unroll
   for (int i = 0; i < NCH; ++i) {
-    const int ck = lane + 64 * i;
-    if (ck < nchunk) { g0[i] = *(const f32x4*)(gamma + ck * 8); g1[i] = *(const f32x4*)(gamma + ck * 8 + 4); }
+    const int ck = min(lane + 64 * i, nchunk - 1);
+    g0[i] = *(const f32x4*)(gamma + ck * 8); g1[i] = *(const f32x4*)(gamma + ck * 8 + 4);
   }
+  float2 st[LN_NR];
+#pragma unroll
+  for (int r = 0; r < LN_NR; ++r) st[r] = *(const float2*)(stats + 2 * (long long)min(row0 + r, R - 1));
+  __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
   for (int r = 0; r < LN_NR; ++r) {
-    const int row = min(row0 + r, R - 1);
-    const float mean = stats[2 * (long long)row], rstd = stats[2 * (long long)row + 1];
+    const float mean = st[r].x, rstd = st[r].y;
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int i = 0; i < NCH; ++i)
