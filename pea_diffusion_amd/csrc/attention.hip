@@ -257,7 +257,7 @@ __device__ __forceinline__ void attn_q_body(const AttnP& p, char* smem, int blk_
 #pragma unroll
         for (int j = 0; j < 8; ++j) dsum += (float)dof[nd][s][j] * (float)o[j];
       }
-    dsum += __shfl_xor(dsum, 32, 64);
+    { float da = dsum, db = dsum; swap_halves32(da, db); dsum = da + db; }
     dlt = dsum;
     if (WRITE_DELTA && qvalid && fh == 0 && chunk == 0) {       // row constants of the dK/dV kernel (see attn_delta_kernel)
       p.delta[li] = -dsum;
@@ -516,7 +516,9 @@ __device__ __forceinline__ void attn_q_body(const AttnP& p, char* smem, int blk_
   // epilogue: oacc[2*no+db][4g+j] = X^T[d = no*64 + db*32 + 8g + 4h + j][q = lane&31]
   float inv = MODE == 1 ? p.scale : 1.f;
   if (MODE == 0) {
-    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    float la = l_run, lb = l_run;
+    swap_halves32(la, lb);                                     // (l_run + its partner half, without an LDS round trip)
+    const float l_tot = la + lb;
     inv = 1.f / l_tot;
     if (p.lse && qvalid && fh == 0)
       p.lse[((long long)b * p.H + head) * p.Sq + qrow] = (m_run + log2f(l_tot)) * 0.6931471805599453f;
@@ -1097,7 +1099,7 @@ __global__ __launch_bounds__(256, 2) void xattn_bwd_kernel(const AttnP p, int up
 #pragma unroll
         for (int j = 0; j < 8; ++j) dsum += (float)d[j] * (float)o_pf[i][j];
       }
-      dsum += __shfl_xor(dsum, 1, 64);
+      dsum += dpp_move<0xB1>(dsum);                          // lane ^ 1, a DPP move
       if (dhalf == 0) {                       // the unit's row constants, negated: C operand of dP, addend of the exp2 argument
         const bool rv = u * 128 + dq_l < p.Sq;             // rows past Sq (ragged last unit): P = exp2(-inf) = 0
         rc[128 + dq_l] = rv ? -dsum : 0.f;
@@ -1305,11 +1307,14 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const AttnP p) {
   const long long total = (long long)p.B * p.Sq * p.H * 8;
   const int sub = (int)(idx & 7);
   const int D = 64 * p.nd;
-  float s = 0.f;
-  long long row = idx >> 3;
+  float s = 0.f, lse = 0.f;
+  long long row = idx >> 3, li = 0;
   if (idx < total) {
     const int head = (int)(row % p.H);
     const long long bq = row / p.H;
+    const int b = (int)(bq / p.Sq), q = (int)(bq % p.Sq);
+    li = ((long long)b * p.H + head) * p.Sq + q;
+    if (sub == 0) lse = p.lse[li];                             // requested with the rows (behind the reduction: a second round trip)
     for (int nd = 0; nd < p.nd; ++nd) {
       const bf16x8 a = *(const bf16x8*)(p.dO + bq * p.lddo + head * D + nd * 64 + sub * 8);
       const bf16x8 o = *(const bf16x8*)(p.O + bq * p.ldo + head * D + nd * 64 + sub * 8);
@@ -1317,16 +1322,12 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const AttnP p) {
       for (int j = 0; j < 8; ++j) s += (float)a[j] * (float)o[j];
     }
   }
-  s += __shfl_xor(s, 1, 64);
-  s += __shfl_xor(s, 2, 64);
-  s += __shfl_xor(s, 4, 64);
+  s += dpp_move<0xB1>(s);                                      // xor 1, xor 2, xor 4 over the 8 lanes of a row: DPP moves, no LDS
+  s += dpp_move<0x4E>(s);
+  s += dpp_move<0x141>(s);
   if (idx < total && sub == 0) {
-    const int head = (int)(row % p.H);
-    const long long bq = row / p.H;
-    const int b = (int)(bq / p.Sq), q = (int)(bq % p.Sq);
-    const long long li = ((long long)b * p.H + head) * p.Sq + q;
     p.delta[li] = -s;                                                    // C operand of the dP products
-    p.delta[(long long)p.B * p.H * p.Sq + li] = -p.lse[li] * LOG2E;      // addend of the exp2 argument
+    p.delta[(long long)p.B * p.H * p.Sq + li] = -lse * LOG2E;            // addend of the exp2 argument
   }
 }
 
