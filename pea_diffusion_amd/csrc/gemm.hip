@@ -457,20 +457,25 @@ __device__ __forceinline__ void gemm_epilogue16_fast(const GemmP& p, f32x4 (&acc
   auto body = [&](auto has_res_t) {
     constexpr bool HR = decltype(has_res_t)::value;
     constexpr int NP = (NT + 1) / 2;
-    bf16x8 rp[2][HR ? NP : 1];
-    bf16x4 rs[2];
-    auto load_res = [&](int buf, int mt) {
-      const long long mo = (long long)min(m_base + mt * 16 + r16, p.M - 1) * p.ldres;
+    // ALL residual pieces of the wave tile are requested before the first store (48 registers; the fragment registers are
+    // free by now).  gfx950 counts loads and stores in one vmcnt and they complete out of order with respect to each other, so
+    // a wait for a load while stores are pending is a wait for vmcnt(0): with the pieces one 16-row block ahead of the
+    // arithmetic (round 2) every block's stores were waited out -- three store round trips in series per tile epilogue.
+    bf16x8 rp[HR ? MT : 1][HR ? NP : 1];
+    bf16x4 rs[HR ? MT : 1];
+    if constexpr (HR) {
 #pragma unroll
-      for (int pr = 0; pr < NT / 2; ++pr)
-        if (2 * pr + 1 < nv) rp[buf][pr] = *(const bf16x8*)(p.res + mo + n_base + (2 * pr + (q4 & 1)) * 16 + 8 * (q4 >> 1));
-      if (nv & 1) rs[buf] = *(const bf16x4*)(p.res + mo + n_base + (nv - 1) * 16 + 4 * q4);
-    };
-    if (HR) load_res(0, 0);
+      for (int mt = 0; mt < MT; ++mt) {
+        const long long mo = (long long)min(m_base + mt * 16 + r16, p.M - 1) * p.ldres;
+#pragma unroll
+        for (int pr = 0; pr < NT / 2; ++pr)
+          if (2 * pr + 1 < nv) rp[mt][pr] = *(const bf16x8*)(p.res + mo + n_base + (2 * pr + (q4 & 1)) * 16 + 8 * (q4 >> 1));
+        if (nv & 1) rs[mt] = *(const bf16x4*)(p.res + mo + n_base + (nv - 1) * 16 + 4 * q4);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
-      if (HR && mt + 1 < MT) load_res((mt + 1) & 1, mt + 1);
-      __builtin_amdgcn_sched_barrier(0);
       const int m = m_base + mt * 16 + r16;
       if (m < p.M) {                                                   // r16 only: swap partners agree
         bf16* crow = (bf16*)p.C + (long long)m * p.ldc;
@@ -491,7 +496,7 @@ __device__ __forceinline__ void gemm_epilogue16_fast(const GemmP& p, f32x4 (&acc
                 hi[j] = val(nt + 1 < NT ? nt + 1 : nt, mt, j);
                 asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(lo[j]), "+v"(hi[j]));
               }
-              const bf16x8 r8 = rp[mt & 1][nt >> 1];
+              const bf16x8 r8 = rp[mt][nt >> 1];
               bf16x8 o;
 #pragma unroll
               for (int j = 0; j < 4; ++j) {
@@ -516,14 +521,13 @@ __device__ __forceinline__ void gemm_epilogue16_fast(const GemmP& p, f32x4 (&acc
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
               float v = val(nt, mt, j);
-              if constexpr (HR) v += (float)rs[mt & 1][j];
+              if constexpr (HR) v += (float)rs[mt][j];
               o[j] = (bf16)v;
             }
             *(bf16x4*)(crow + n_base + nt * 16 + 4 * q4) = o;
           }
         }
       }
-      __builtin_amdgcn_sched_barrier(0);
     }
   };
   if (has_res) body(std::true_type{});
