@@ -1,3 +1,4 @@
+"""per-family and per-shape GEMM milliseconds of the bench step (for scripts/lib_multi.py A/B runs)"""
 import json, os, subprocess, sys
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--no-cpu-baseline", "--steps", "10", "--warmup", "3", "--dump-prof", "/tmp/pl.csv"], capture_output=True, text=True)
