@@ -228,6 +228,14 @@ int pea_unet_create(const pea_unet_config* cfg, int B, int H, int W, int L, int 
  * / gradient arenas will take in HBM.  Use it to size a configuration against 288 GB before creating it.   */
 int pea_unet_plan(const pea_unet_config* cfg, int B, int H, int W, int L, int flags, int* n_ops, int* n_weights,
                   long long* n_params, long long* weight_bytes, long long* act_bytes, long long* grad_bytes);
+/* Attention ops on a graph (any handle of this library that owns an op tape: UNet, ControlNet, VAE, text encoder) and how
+ * many of them are fed a Q the producing projection already multiplied by softmax_scale * log2(e) (the accurate path: one
+ * rounding, from the fp32 accumulator).  An op outside that count runs the operator-level plain-Q path, which rounds the
+ * scaled operand to bf16 once more.  pea_unet_plan_attention: the same census from the host-only planning pass. */
+int pea_tape_attention_census(void* graph, int* n_attn, int* n_prescaled);
+int pea_unet_plan_attention(const pea_unet_config* cfg, int B, int H, int W, int L, int flags, int* n_attn, int* n_prescaled);
+int pea_graph_plan_attention(int graph, const pea_unet_config* cfg, int B, int H, int W, int L, int* n_attn,
+                             int* n_prescaled);          /* graph: 1 VAE encoder, 2 ControlNet, 3 VAE decoder */
 /* ControlNet extras of the UNet call (tests/test_sdxl_zh_controlnet.py:534-535): `down_block_additional_residuals`
  * (conv_in output, then every down-block resnet/attention output and downsampler output, in diffusers order) followed
  * by `mid_block_additional_residual` LAST.  ptrs: HOST array of n device pointers ([B,C,H,W]; NULL entry = zero);
@@ -281,6 +289,7 @@ typedef struct pea_text_config {
   int rel_max_dist; /* T5: relative_attention_max_distance (128) */
 } pea_text_config;
 int pea_text_create(const pea_text_config* cfg, int B, int L, void** out);
+int pea_text_plan_attention(const pea_text_config* cfg, int B, int L, int* n_attn, int* n_prescaled);   /* see pea_tape_attention_census */
 int pea_text_forward(void* enc, const long long* ids, int hidden_index, float* hidden_out, float* pooled_out, void* stream);
 /* T5 flavour only: the additive attention bias the encoder uses, bias_out fp32 [heads][L][L] =
  * relative_attention_bias[bucket(k - q)][h] * log2(e) (HF T5Attention.compute_bias; the attention kernels work in the

@@ -52,7 +52,8 @@ class ControlNetRef(nn.Module):
                                               down=(i != nb - 1)))
             for _ in range(cfg.layers_per_block + (1 if i != nb - 1 else 0)):
                 self.controlnet_down_blocks.append(nn.Conv2d(out, out, 1))
-        self.mid_block = MidBlock(cfg, boc[-1], cfg.transformer_layers_per_block[-1], cfg.num_attention_heads[-1])
+        last = cfg.transformer_layers_per_block[-1]                    # same rule as UNet2DConditionRef: element [0] of a nested entry
+        self.mid_block = MidBlock(cfg, boc[-1], last if isinstance(last, int) else last[0], cfg.num_attention_heads[-1])
         self.controlnet_mid_block = nn.Conv2d(boc[-1], boc[-1], 1)
 
     @property

@@ -173,11 +173,29 @@ class ToyEnc:
         return e, None            # chinese_clip branch unpacks (tokens, pooled) train_sdxl_zh.py:329
 
 
-def gen_step(ref, which, zh_pattern, mask_pattern, tag):
-    from oracle.unet_ref import UNet2DConditionRef, UNetConfig, tiny_config, sd15_config
+def _round_bf16_(module):
+    """every >= 2-D weight to a bf16-representable fp32 value (what the device path stores)"""
+    with torch.no_grad():
+        for p in module.parameters():
+            if p.dim() >= 2:
+                p.copy_(p.to(torch.bfloat16).float())
+
+
+def gen_step(ref, which, zh_pattern, mask_pattern, tag, hip=False, shared_teacher=False):
+    """hip=True: the SAME reference training_step on collaborators at the dims the device path's MFMA tiles accept
+    (oracle tiny_config / tiny15_config: 64/128/128 channels, cross 128, MLP (128, pooled, 192, 128), L = 12, 16x16
+    latents), UNet / MLP weights and the text-side inputs bf16-representable, so that `-m gpu` can compare PEATrainer
+    with what the reference itself produced (tests/test_model_gpu.py::test_step_matches_reference_golden)."""
+    from oracle.unet_ref import UNet2DConditionRef, UNetConfig, tiny_config, tiny15_config, sd15_config
     from oracle.step_ref import AdapterRef
     sdxl = which == "sdxl"
-    if sdxl:
+    if hip and sdxl:
+        cfg = tiny_config()
+        mlp_args = (128, cfg.pooled_dim, 192, cfg.cross_attention_dim, False)
+    elif hip:
+        cfg = tiny15_config()
+        mlp_args = (128, cfg.cross_attention_dim, 192)
+    elif sdxl:
         cfg = UNetConfig(sample_size=8, block_out_channels=(32, 64, 64), transformer_layers_per_block=(1, 1, 1),
                          num_attention_heads=(1, 2, 2), cross_attention_dim=64, addition_time_embed_dim=16,
                          projection_class_embeddings_input_dim=48 + 96, name="toy")
@@ -190,19 +208,25 @@ def gen_step(ref, which, zh_pattern, mask_pattern, tag):
                          addition_embed_type=None, addition_time_embed_dim=0,
                          projection_class_embeddings_input_dim=0, name="toy15")
         mlp_args = (32, 48, 40)
-    B, L, hw = len(zh_pattern), 6, cfg.sample_size
+    B, L, hw = len(zh_pattern), (12 if hip else 6), cfg.sample_size
     torch.manual_seed(2024)
     unet_s = UNet2DConditionRef(cfg)
     unet_t = UNet2DConditionRef(cfg)          # reference loads teacher from the same path (:151); here a
-    wsum = checksum(unet_s.state_dict()) + checksum(unet_t.state_dict())   # different init to make KD terms non-zero
+    if shared_teacher:                        # different init to make KD terms non-zero -- unless shared_teacher: the
+        unet_t.load_state_dict(unet_s.state_dict())     # reference's own set-up (merged passes on the device path)
     proj = ref.MLP(*mlp_args)
+    if hip:
+        for m in (unet_s, unet_t, proj):
+            _round_bf16_(m)
+    wsum = checksum(unet_s.state_dict()) + checksum(unet_t.state_dict())
     g = torch.Generator().manual_seed(5)
+    q = (lambda x: x.to(torch.bfloat16).float()) if hip else (lambda x: x)
     lat16 = (torch.randn(B, 4, hw, hw, generator=g)).half()
-    enc = torch.randn(B, L, mlp_args[0], generator=g)
-    enc_u = torch.randn(1, L, mlp_args[0], generator=g).repeat(B, 1, 1)
-    t_ehs = torch.randn(B, 77, cfg.cross_attention_dim, generator=g)
-    t_neg = torch.randn(1, 77, cfg.cross_attention_dim, generator=g).repeat(B, 1, 1)
-    t_pool = torch.randn(B, 48, generator=g)
+    enc = q(torch.randn(B, L, mlp_args[0], generator=g))
+    enc_u = q(torch.randn(1, L, mlp_args[0], generator=g)).repeat(B, 1, 1)
+    t_ehs = q(torch.randn(B, 77, cfg.cross_attention_dim, generator=g))
+    t_neg = q(torch.randn(1, 77, cfg.cross_attention_dim, generator=g)).repeat(B, 1, 1)
+    t_pool = q(torch.randn(B, cfg.pooled_dim if (hip and sdxl) else 48, generator=g))
     sf = 0.5
     self = types.SimpleNamespace()
     self.vae = ToyVAE(lat16.float(), sf)
@@ -211,6 +235,9 @@ def gen_step(ref, which, zh_pattern, mask_pattern, tag):
     self.text_encoder = ToyEnc({1: enc, 2: enc_u})
     self.proj = proj
     self.KD_student, self.KD_teacher = {}, {}
+    eps_cap = {}
+    unet_s.register_forward_hook(lambda m, i, o: eps_cap.__setitem__("s", o[0].detach().clone()))
+    unet_t.register_forward_hook(lambda m, i, o: eps_cap.__setitem__("t", o[0].detach().clone()))
     ref.cast_hook(unet_s, self.KD_student)        # the reference's own hook installer
     ref.cast_hook(unet_t, self.KD_teacher)
     logs = {}
@@ -246,7 +273,8 @@ def gen_step(ref, which, zh_pattern, mask_pattern, tag):
     if sdxl:
         noise = noise + 0.5 * torch.randn(B, 4, 1, 1)
     timesteps = torch.randint(0, 1000, (B,))
-    d = {"B": B, "L": L, "seed_model": 2024, "wsum_unets": wsum, "mlp_args": np.array([int(a) for a in mlp_args]),
+    d = {"B": B, "L": L, "seed_model": 2024, "wsum_unets": wsum, "hip_dims": int(hip), "shared_teacher": int(shared_teacher),
+         "noise_pred": eps_cap["s"], "noise_pred_teacher": eps_cap["t"], "mlp_args": np.array([int(a) for a in mlp_args]),
          "cfg_boc": np.array(cfg.block_out_channels), "cfg_heads": np.array(cfg.num_attention_heads),
          "cfg_cross": cfg.cross_attention_dim, "cfg_add_dim": cfg.addition_time_embed_dim,
          "cfg_proj_in": cfg.projection_class_embeddings_input_dim, "cfg_sample": cfg.sample_size,
@@ -289,6 +317,12 @@ def main():
     gen_step(ref_sdxl, "sdxl", [0, 0, 0, 0], [True, False, False, True], "sdxl_all_en")
     gen_step(ref_sdxl, "sdxl", [1, 1, 1], [False, False, False], "sdxl_all_zh")
     gen_step(ref_sd, "sd15", [1, 0, 0, 1], [False, True, False, False], "sd15_mixed")
+    # the same reference step at dims the device path accepts: read by `-m gpu` tests/test_model_gpu.py
+    gen_step(ref_sdxl, "sdxl", [1, 0, 0, 1], [False, False, True, False], "sdxl_hip_mixed", hip=True)
+    gen_step(ref_sdxl, "sdxl", [0, 0, 0, 0], [True, False, False, True], "sdxl_hip_all_en", hip=True)
+    gen_step(ref_sdxl, "sdxl", [1, 1, 1], [False, False, False], "sdxl_hip_all_zh", hip=True)
+    gen_step(ref_sdxl, "sdxl", [1, 0, 0, 1], [False, True, False, False], "sdxl_hip_shared_teacher", hip=True, shared_teacher=True)
+    gen_step(ref_sd, "sd15", [1, 0, 0, 1], [False, True, False, False], "sd15_hip_mixed", hip=True)
     gen_rescale(ref_test)
 
 

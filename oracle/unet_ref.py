@@ -361,13 +361,14 @@ class UNet2DConditionRef(nn.Module):
             self.down_blocks.append(DownBlock(cfg, cin, out, cfg.transformer_layers_per_block[i],
                                               cfg.num_attention_heads[i], ty.startswith("CrossAttn"),
                                               down=(i != nb - 1)))
-        # diffusers >= 0.22 [ext]: the mid block takes the last down entry (its last element when that is a list);
-        # `mid_block_type: null` leaves `self.mid_block = None`
+        # diffusers >= 0.22 [ext]: UNet2DConditionModel hands transformer_layers_per_block[-1] to UNetMidBlock2DCrossAttn,
+        # which broadcasts an int over its num_layers = 1 attention and otherwise reads element [0] (same rule as
+        # pea_diffusion_amd/config.py:depth_tables); `mid_block_type: null` leaves `self.mid_block = None`
         if cfg.mid_block_type is None:
             self.mid_block = None
         else:
             last = cfg.transformer_layers_per_block[-1]
-            self.mid_block = MidBlock(cfg, boc[-1], last if isinstance(last, int) else last[-1], cfg.num_attention_heads[-1])
+            self.mid_block = MidBlock(cfg, boc[-1], last if isinstance(last, int) else last[0], cfg.num_attention_heads[-1])
         self.up_blocks = nn.ModuleList()
         rboc = list(reversed(boc))
         if cfg.reverse_transformer_layers_per_block is not None:

@@ -61,7 +61,8 @@ def ssd1b_uniform_config() -> UNetConfig:
 def depth_tables(cfg):
     """(down[i][j], up[i][j], mid) transformer depths from the diffusers fields, following UNet2DConditionModel.__init__
     (diffusers >= 0.22 [ext]): ints are broadcast over a block's attentions, the up path defaults to the reversed down
-    list, the mid block takes the LAST down entry (its last element when that is a list)."""
+    list, the mid block takes the LAST down entry (element [0] when that is a list: UNetMidBlock2DCrossAttn indexes
+    its depth list by attention, and it has one)."""
     n = len(cfg.block_out_channels)
     lpb = cfg.layers_per_block
     tl = cfg.transformer_layers_per_block

@@ -72,6 +72,56 @@ int pea_unet_plan(const pea_unet_config* cfg, int B, int H, int W, int L, int fl
   if (grad_bytes) *grad_bytes = (long long)u.gbytes;
   return PEA_OK;
 }
+/* attention ops of a graph and how many of them receive a Q already multiplied by scale * log2(e) by the producing
+ * projection's epilogue (Tape::tag_q_prescale); every graph the product builds is expected to have the two equal */
+int pea_tape_attention_census(void* h, int* n_attn, int* n_prescaled) {
+  NOTNULL(h, "pea_tape_attention_census");
+  const Tape* u = (const Tape*)h;
+  if (n_attn) *n_attn = u->n_attn;
+  if (n_prescaled) *n_prescaled = u->n_attn_pre;
+  return PEA_OK;
+}
+int pea_unet_plan_attention(const pea_unet_config* cfg, int B, int H, int W, int L, int flags, int* n_attn, int* n_prescaled) {
+  NOTNULL(cfg, "pea_unet_plan_attention");
+  Tape u;
+  memcpy(&u.cfg, cfg, sizeof(PeaUnetCfg));
+  u.B = B; u.H = H; u.W = W; u.L = L; u.needs_grad = (flags & 1) != 0; u.residual_inputs = (flags & 2) != 0;
+  u.plan_only = true;
+  int rc = u.build();
+  if (rc == PEA_OK) rc = u.alloc();
+  if (rc != PEA_OK) return rc;
+  if (n_attn) *n_attn = u.n_attn;
+  if (n_prescaled) *n_prescaled = u.n_attn_pre;
+  return PEA_OK;
+}
+static int plan_census(Tape& u, int* n_attn, int* n_prescaled) {
+  u.plan_only = true;
+  int rc = u.build();
+  if (rc == PEA_OK) rc = u.alloc();
+  if (rc != PEA_OK) return rc;
+  if (n_attn) *n_attn = u.n_attn;
+  if (n_prescaled) *n_prescaled = u.n_attn_pre;
+  return PEA_OK;
+}
+/* graph: 1 VAE encoder, 2 ControlNet, 3 VAE decoder (the values of Tape::graph) */
+int pea_graph_plan_attention(int graph, const pea_unet_config* cfg, int B, int H, int W, int L, int* n_attn, int* n_prescaled) {
+  NOTNULL(cfg, "pea_graph_plan_attention");
+  if (graph < 1 || graph > 3) { pea_set_error("pea_graph_plan_attention: graph %d (1 VAE encoder, 2 ControlNet, 3 VAE decoder)", graph); return PEA_E_INVALID; }
+  Tape u;
+  memcpy(&u.cfg, cfg, sizeof(PeaUnetCfg));
+  u.graph = graph;
+  u.B = B; u.H = H; u.W = W; u.L = graph == 2 ? L : 0; u.needs_grad = false; u.owns_weights = true;
+  return plan_census(u, n_attn, n_prescaled);
+}
+int pea_text_plan_attention(const pea_text_config* cfg, int B, int L, int* n_attn, int* n_prescaled) {
+  NOTNULL(cfg, "pea_text_plan_attention");
+  Tape u;
+  memset(&u.cfg, 0, sizeof(PeaUnetCfg));
+  memcpy(&u.tcfg, cfg, sizeof(PeaTextCfg));
+  u.graph = 4;
+  u.B = B; u.H = 1; u.W = L; u.L = L; u.needs_grad = false; u.owns_weights = true;
+  return plan_census(u, n_attn, n_prescaled);
+}
 int pea_controlnet_create(const pea_unet_config* cfg, int B, int H, int W, int L, void** out) {
   NOTNULL(cfg, "pea_controlnet_create");
   NOTNULL(out, "pea_controlnet_create");

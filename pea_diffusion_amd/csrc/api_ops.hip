@@ -23,7 +23,31 @@ int pea_zero_page(const bf16** out) {
   return PEA_OK;
 }
 
-static int g_api_q_prescaled = 0;      // set around a call by the *_prescaled entry points
+// bodies of the attention operators with the Q convention as a PARAMETER (the entry points below pass 0 or 1): nothing
+// process-wide is written around a call, so concurrent callers (ctypes releases the GIL) cannot see each other's mode
+static int attention_fwd_impl(const void* Q, int ldq, const void* K, int ldk, const void* V, int ldv, void* O, int ldo,
+                              float* lse, int B, int H, int Sq, int Skv, float scale, int nd, int q_prescaled, void* stream) {
+  AttnP p;
+  memset(&p, 0, sizeof(p));
+  p.Q = (const bf16*)Q; p.K = (const bf16*)K; p.V = (const bf16*)V; p.ldq = ldq; p.ldk = ldk; p.ldv = ldv;
+  p.O = (bf16*)O; p.ldo = ldo; p.lse = lse; p.B = B; p.H = H; p.Sq = Sq; p.Skv = Skv; p.scale = scale; p.nd = nd;
+  p.q_prescaled = q_prescaled;
+  return launch_attention_fwd(p, (hipStream_t)stream);
+}
+static int attention_bwd_impl(const void* Q, int ldq, const void* K, int ldk, const void* V, int ldv, const void* O,
+                              int ldo, const void* dO, int lddo, const float* lse, float* delta, void* dQ, int lddq,
+                              void* dK, int lddk, void* dV, int lddv, int B, int H, int Sq, int Skv, float scale,
+                              int accum_dq, int accum_dkv, int nd, void* scratch, int q_prescaled, void* stream) {
+  AttnP p;
+  memset(&p, 0, sizeof(p));
+  p.Q = (const bf16*)Q; p.K = (const bf16*)K; p.V = (const bf16*)V; p.ldq = ldq; p.ldk = ldk; p.ldv = ldv;
+  p.O = (bf16*)O; p.ldo = ldo; p.lse = (float*)lse; p.B = B; p.H = H; p.Sq = Sq; p.Skv = Skv; p.scale = scale;
+  p.dO = (const bf16*)dO; p.lddo = lddo; p.delta = delta;
+  p.dQ = (bf16*)dQ; p.lddq = lddq; p.dK = (bf16*)dK; p.lddk = lddk; p.dV = (bf16*)dV; p.lddv = lddv;
+  p.accum_dq = accum_dq; p.accum_dkv = accum_dkv; p.dkv_part = (float*)scratch; p.nd = nd;
+  p.q_prescaled = q_prescaled;
+  return launch_attention_bwd(p, (hipStream_t)stream);
+}
 
 extern "C" {
 
@@ -161,21 +185,13 @@ int pea_op_layernorm_bwd(const void* x, const void* dy, const float* gamma, cons
 
 int pea_op_attention_fwd(const void* Q, int ldq, const void* K, int ldk, const void* V, int ldv, void* O, int ldo,
                          float* lse, int B, int H, int Sq, int Skv, float scale, int nd, void* stream) {
-  AttnP p;
-  memset(&p, 0, sizeof(p));
-  p.Q = (const bf16*)Q; p.K = (const bf16*)K; p.V = (const bf16*)V; p.ldq = ldq; p.ldk = ldk; p.ldv = ldv;
-  p.O = (bf16*)O; p.ldo = ldo; p.lse = lse; p.B = B; p.H = H; p.Sq = Sq; p.Skv = Skv; p.scale = scale; p.nd = nd;
-  p.q_prescaled = g_api_q_prescaled;
-  return launch_attention_fwd(p, (hipStream_t)stream);
+  return attention_fwd_impl(Q, ldq, K, ldk, V, ldv, O, ldo, lse, B, H, Sq, Skv, scale, nd, 0, stream);
 }
 /* the same two operators on a Q that already carries scale * log2(e) (what the model's Q|K|V / to_q projections hand over:
  * pea_op_gemm_qscale); `scale` is still the softmax scale: dQ comes back as the gradient w.r.t. the UNSCALED q */
 int pea_op_attention_fwd_prescaled(const void* Q, int ldq, const void* K, int ldk, const void* V, int ldv, void* O, int ldo,
                                    float* lse, int B, int H, int Sq, int Skv, float scale, int nd, void* stream) {
-  g_api_q_prescaled = 1;
-  const int rc = pea_op_attention_fwd(Q, ldq, K, ldk, V, ldv, O, ldo, lse, B, H, Sq, Skv, scale, nd, stream);
-  g_api_q_prescaled = 0;
-  return rc;
+  return attention_fwd_impl(Q, ldq, K, ldk, V, ldv, O, ldo, lse, B, H, Sq, Skv, scale, nd, 1, stream);
 }
 int pea_op_attention_fwd_masked(const void* Q, int ldq, const void* K, int ldk, const void* V, int ldv, void* O, int ldo,
                                 float* lse, int B, int H, int Sq, int Skv, float scale, int causal, const int* kv_len,
@@ -191,25 +207,15 @@ int pea_op_attention_bwd(const void* Q, int ldq, const void* K, int ldk, const v
                          int ldo, const void* dO, int lddo, const float* lse, float* delta, void* dQ, int lddq,
                          void* dK, int lddk, void* dV, int lddv, int B, int H, int Sq, int Skv, float scale,
                          int accum_dq, int accum_dkv, int nd, void* scratch, void* stream) {
-  AttnP p;
-  memset(&p, 0, sizeof(p));
-  p.Q = (const bf16*)Q; p.K = (const bf16*)K; p.V = (const bf16*)V; p.ldq = ldq; p.ldk = ldk; p.ldv = ldv;
-  p.O = (bf16*)O; p.ldo = ldo; p.lse = (float*)lse; p.B = B; p.H = H; p.Sq = Sq; p.Skv = Skv; p.scale = scale;
-  p.dO = (const bf16*)dO; p.lddo = lddo; p.delta = delta;
-  p.dQ = (bf16*)dQ; p.lddq = lddq; p.dK = (bf16*)dK; p.lddk = lddk; p.dV = (bf16*)dV; p.lddv = lddv;
-  p.accum_dq = accum_dq; p.accum_dkv = accum_dkv; p.dkv_part = (float*)scratch; p.nd = nd;
-  p.q_prescaled = g_api_q_prescaled;
-  return launch_attention_bwd(p, (hipStream_t)stream);
+  return attention_bwd_impl(Q, ldq, K, ldk, V, ldv, O, ldo, dO, lddo, lse, delta, dQ, lddq, dK, lddk, dV, lddv, B, H, Sq, Skv,
+                            scale, accum_dq, accum_dkv, nd, scratch, 0, stream);
 }
 int pea_op_attention_bwd_prescaled(const void* Q, int ldq, const void* K, int ldk, const void* V, int ldv, const void* O,
                                    int ldo, const void* dO, int lddo, const float* lse, float* delta, void* dQ, int lddq,
                                    void* dK, int lddk, void* dV, int lddv, int B, int H, int Sq, int Skv, float scale,
                                    int accum_dq, int accum_dkv, int nd, void* scratch, void* stream) {
-  g_api_q_prescaled = 1;
-  const int rc = pea_op_attention_bwd(Q, ldq, K, ldk, V, ldv, O, ldo, dO, lddo, lse, delta, dQ, lddq, dK, lddk, dV, lddv, B, H,
-                                      Sq, Skv, scale, accum_dq, accum_dkv, nd, scratch, stream);
-  g_api_q_prescaled = 0;
-  return rc;
+  return attention_bwd_impl(Q, ldq, K, ldk, V, ldv, O, ldo, dO, lddo, lse, delta, dQ, lddq, dK, lddk, dV, lddv, B, H, Sq, Skv,
+                            scale, accum_dq, accum_dkv, nd, scratch, 1, stream);
 }
 
 int pea_op_geglu_fwd(const void* hg, void* y, long long rows, int inner, void* stream) {

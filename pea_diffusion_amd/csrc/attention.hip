@@ -280,6 +280,7 @@ __device__ __forceinline__ void attn_q_body(const AttnP& p, char* smem, int blk_
 #pragma unroll
     for (int r = 0; r < 16; ++r) oacc[i][r] = 0.f;
   float m_run = 0.f, l_run = 0.f;            // m_run: log2-domain offset the P values of this query are relative to
+  [[maybe_unused]] bool seen = false;        // TXT instance: this lane's query has met a key that is not masked
 
   TileSrc ksrc[ND], vsrc[ND];
 #pragma unroll
@@ -405,14 +406,21 @@ __device__ __forceinline__ void attn_q_body(const AttnP& p, char* smem, int blk_
 #pragma unroll
       for (int r = 1; r < 16; ++r) mx = fmaxf(fmaxf(mx, sacc[0][r]), sacc[1][r]);     // one v_max3 per pair of scores
       mx = xhalf_max(mx);
-      const bool moved = t == 0 || mx > ATTN_MOVE_THR;
+      // "first" = this query has not seen a valid key yet.  The UNet instance always has one in tile 0 (Skv >= 1, checked on the
+      // host).  TXT: a per-sample key count of 0 (or a padded context shorter than a tile boundary) leaves whole tiles at -inf;
+      // the offset then stays 0 -- with m_run = -1e30 the next tile's scores would be absorbed by the C operand and every key
+      // would come out with weight 1 -- and is set by the first tile with a finite maximum (a row without any key ends as 0 / 0).
+      bool first = t == 0;
+      if constexpr (TXT) first = !seen;
+      const bool moved = (first || mx > ATTN_MOVE_THR) && (!TXT || mx > -INFINITY);
+      if constexpr (TXT) seen = seen || mx > -INFINITY;
       if (__any(moved)) {
-        const float mrel = moved ? fmaxf(mx, -1e30f) : 0.f;      // (a fully masked first tile keeps a finite offset)
+        const float mrel = moved ? mx : 0.f;
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
           for (int r = 0; r < 16; ++r) sacc[kb][r] -= mrel;
-        const float alpha = t == 0 ? 0.f : fast_exp2(-mrel);     // O and l are still zero in the first tile
+        const float alpha = first ? 0.f : fast_exp2(-mrel);      // O and l are still zero before the first valid key
         l_run *= alpha;
 #pragma unroll
         for (int i = 0; i < 2 * NO; ++i)

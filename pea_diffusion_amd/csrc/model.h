@@ -122,6 +122,8 @@ struct Op {
   int fold = -1;                  // OP_LN / OP_LINEAR: index into Tape::folds (LayerNorm folded into the consuming Linear)
   int qs_cols = 0; float qs = 1.f; // OP_LINEAR: output columns [0, qs_cols) leave multiplied by qs (the Q block of an attention's projection)
   int pre = 0;                    // OP_ATTN: Q arrives multiplied by scale * log2(e) (Tape::tag_q_prescale)
+  int stash_form = -1;            // fused-GEGLU OP_LINEAR: what the last FORWARD left in its stash (0: (h, gate), 1: the backward's
+                                  // factors); written by Tape::forward, read by Tape::backward -- never re-derived there
 };
 
 // The static op tape: tensors, weight slots and ops of ONE graph, built once per (config, batch, size).  graph selects the
@@ -188,6 +190,7 @@ struct Tape {
   int* cross_kvlen = nullptr;        // graph 0: per-sample valid context tokens of the cross-attention (merged passes with a shorter
                                      // student context; rows beyond it in t_ehs are zero padding), null = all L
   int exec_ops(size_t begin, size_t end, bool skip_cached, hipStream_t s);
+  int n_attn = 0, n_attn_pre = 0;    // attention ops on the tape / of those, fed a prescaled Q (tag_q_prescale)
   void tag_q_prescale();
   int ensure_acts();                 // lazy allocation of the activation / gradient arenas and scratch
   int alloc();

@@ -725,7 +725,23 @@ int Tape::build() {
 // projection's data-gradient GEMM is unchanged.
 void Tape::tag_q_prescale() {
   static const bool off = getenv("PEA_ATTN_NO_PRESCALE") != nullptr;          // A/B switch
+  n_attn = n_attn_pre = 0;
+  for (const Op& a : ops)
+    if (a.kind == OP_ATTN) { ++n_attn; n_attn_pre += a.pre ? 1 : 0; }
   if (off) return;
+  // An attention op that fails a condition below keeps a plain Q: the kernels then round Q * scale * log2(e) to bf16 themselves
+  // (attention.hip: scale_frag), one more rounding than the tagged path.  Nothing on the product's graphs may take that path
+  // silently: the census (pea_tape_attention_census) is asserted by the tests for every graph, and a miss is logged once here.
+  struct Census {
+    Tape* t;
+    ~Census() {
+      t->n_attn_pre = 0;
+      for (const Op& a : t->ops) t->n_attn_pre += (a.kind == OP_ATTN && a.pre) ? 1 : 0;
+      if (t->n_attn_pre != t->n_attn && !t->plan_only)
+        fprintf(stderr, "pea: graph %d: %d of %d attention ops run on a plain (not prescaled) Q\n", t->graph,
+                t->n_attn - t->n_attn_pre, t->n_attn);
+    }
+  } census{this};
   for (size_t i = 0; i < ops.size(); ++i) {
     Op& a = ops[i];
     if (a.kind != OP_ATTN || a.pre || a.acol != 0) continue;
@@ -733,7 +749,7 @@ void Tape::tag_q_prescale() {
     for (size_t j = 0; j < ops.size(); ++j) {
       const Op& o = ops[j];
       if (o.out == a.a && j < i) prod = (int)j;
-      if (j != i && (o.a == a.a || o.res == a.a || o.rv == a.a || (o.kind != OP_LINEAR && (o.b == a.a || o.c == a.a)))) {
+      if (j != i && (o.a == a.a || o.res == a.a || o.rv == a.a || (o.kind != OP_LINEAR && o.kind != OP_EMBED && (o.b == a.a || o.c == a.a)))) {   // (OP_EMBED's b / c are weight slots, not tensors)
         // the attention itself may read K / V from the same tensor (fused Q|K|V): other columns, not a reader of the Q block
         ++readers;
       }
@@ -1110,7 +1126,7 @@ int Tape::exec_ops(size_t begin, size_t end, bool skip_cached, hipStream_t s) {
           p.N = 2 * out.cols; p.geglu_y = out.d; p.ldy = out.cols; p.geglu_tanh = o.p1;
           p.C = o.c >= 0 ? tn[o.c].d : nullptr; p.ldc = 2 * out.cols;
           if (bwd_batch > 0) p.stash_rows = (int)(out.rows / B * bwd_batch);   // only the differentiated samples are stashed
-          p.stash_grad = geglu_stash_form(o);
+          p.stash_grad = o.stash_form = geglu_stash_form(o);        // the form travels with the stash (Op::stash_form)
         }
         if (o.res >= 0) { p.res = tn[o.res].d; p.ldres = tn[o.res].cols; }
         if (o.fold >= 0) {                // folded LayerNorm: the GEMM reads the un-normalised rows
@@ -1309,7 +1325,8 @@ int Tape::backward(const float* deps, hipStream_t s) {
         }
         if (a.rg && o.p3 == 3) {          // fused GEGLU: d(pre-activation) into scratch, then the dgrad GEMM over K = 8C
           Tn& hg = tn[o.c];
-          if (dpre_of != o.out) RC(launch_geglu_bwd_il(hg.d, out.g, geglu_tmp, rb(out), out.cols, s, geglu_stash_form(o)));
+          SHAPECHK(o.stash_form >= 0, "unet: GEGLU op %d has no stash from a forward pass", oi);
+          if (dpre_of != o.out) RC(launch_geglu_bwd_il(hg.d, out.g, geglu_tmp, rb(out), out.cols, s, o.stash_form));
           dpre_of = -1;
           WSlot& w = slots[o.w];
           GemmP p; fill_gemm(p);
@@ -1334,7 +1351,8 @@ int Tape::backward(const float* deps, hipStream_t s) {
           if (g_geglu_bwd_fused && prev && prev->kind == OP_LINEAR && prev->p3 == 3 && prev->out == o.a && prev->c >= 0 &&
               tn[prev->a].rg && !a.gw && !a.gpend && geglu_tmp && a.cols % 16 == 0) {
             Tn& hg = tn[prev->c];
-            p.gbwd_pre = hg.d; p.ldgp = hg.cols; p.gbwd_form = geglu_stash_form(*prev);
+            SHAPECHK(prev->stash_form >= 0, "unet: GEGLU op %d has no stash from a forward pass", oi - 1);
+            p.gbwd_pre = hg.d; p.ldgp = hg.cols; p.gbwd_form = prev->stash_form;
             p.C = geglu_tmp; p.ldc = hg.cols;
             RC(launch_gemm(p, s));
             a.gw = true;

@@ -146,6 +146,48 @@ def test_ssd1b_tiny_layout_vs_oracle(gpu):
     assert e < 3e-2
 
 
+def test_nested_last_entry_with_mid_block_vs_oracle(gpu):
+    """A nested LAST transformer_layers_per_block entry with unequal values AND a mid block: diffusers hands that entry to
+    UNetMidBlock2DCrossAttn, which reads element [0].  The oracle and the product build their graphs independently from the
+    same config; the weight tables must agree key for key and the forward (every tap, mid included) must match."""
+    from oracle import unet_ref as ou
+    from pea_diffusion_amd import config as pc
+    from pea_diffusion_amd.unet import HipUNet
+    B, L = 2, 12
+    kw = dict(transformer_layers_per_block=(1, 1, (2, 1)), reverse_transformer_layers_per_block=((1, 2, 1), 1, 1))
+    cfg_o, cfg_p = ou.tiny_config(), pc.tiny_config()
+    for k, v in kw.items():
+        setattr(cfg_o, k, v)
+        setattr(cfg_p, k, v)
+    assert pc.depth_tables(cfg_p)[2] == 2
+    torch.manual_seed(4)
+    uo = ou.UNet2DConditionRef(cfg_o)
+    assert len(uo.mid_block.attentions[0].transformer_blocks) == 2
+    round_weights_bf16_(uo)
+    hu = HipUNet(cfg_p, B, 16, 16, L, needs_grad=False)
+    table, sd = hu.weight_table(), uo.state_dict()
+    assert set(table) == set(sd), sorted(set(table) ^ set(sd))[:8]
+    hu.load_state_dict(sd)
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(B, 4, 16, 16, generator=g)
+    t = torch.tensor([17, 801])
+    ehs = torch.randn(B, L, cfg_o.cross_attention_dim, generator=g).to(torch.bfloat16).float()
+    pooled = torch.randn(B, cfg_o.pooled_dim, generator=g).to(torch.bfloat16).float()
+    tid = torch.tensor([[128., 128, 0, 0, 128, 128]] * B)
+    taps = {}
+    ou.cast_hook_ref(uo, taps)
+    with torch.no_grad():
+        eps_o = uo(x, t, ehs, added_cond_kwargs={"text_embeds": pooled, "time_ids": tid})[0]
+    eps_h = hu(x.cuda(), t.cuda(), ehs.cuda(), added_cond_kwargs={"text_embeds": pooled.cuda(), "time_ids": tid.cuda()},
+               return_dict=False)[0]
+    e = rel_l2(eps_h, eps_o)
+    assert e < 1.5e-2, e
+    assert "m" in hu.tap_names and list(taps) == hu.tap_names
+    for i, k in enumerate(hu.tap_names):
+        assert rel_l2(hu.tap(i), taps[k]) < 2e-2, k
+    print(f"[nested-last + mid] eps rel_l2={e:.3e}")
+
+
 def _build_fast(cfg, seed):
     from oracle import unet_ref as ou
     orig = torch.nn.init.kaiming_uniform_, torch.nn.init.uniform_

@@ -158,3 +158,76 @@ def test_sdxl_controlnet_full_size_steps(gpu):
     p.use_cn = False
     c = denoise(p, DPMSolverMultistep(), lat.clone(), ehs, added, num_inference_steps=3, guidance_scale=5.0)
     assert torch.isfinite(c).all() and not torch.equal(a, c)
+
+
+def test_sdxl_controlnet_full_size_step_vs_oracle(gpu):
+    """BASELINE config 5 at full size AGAINST THE ORACLE: one ControlNet + UNet evaluation of the reference's denoise loop
+    (tests/test_sdxl_zh_controlnet.py:510-538: `controlnet(...)` -> `unet(..., down_block_additional_residuals=...,
+    mid_block_additional_residual=...)`) at 1024x1024, batch 1, full 2.57 B UNet + 1.25 B ControlNet: the ten residuals and
+    eps vs oracle/controlnet_ref.py + oracle/unet_ref.py in fp32 on the host cores (about a minute)."""
+    import time
+    from oracle import unet_ref as ou
+    from oracle.controlnet_ref import ControlNetRef
+    from pea_diffusion_amd import config as pc
+    from pea_diffusion_amd.controlnet import HipControlNet
+    from pea_diffusion_amd.unet import HipUNet
+    from test_model_gpu import _fast_fill_
+    torch.set_num_threads(min(64, len(__import__("os").sched_getaffinity(0))))
+    cfg = ou.sdxl_config()
+    B, L, hw = 1, 77, 128
+    orig = torch.nn.init.kaiming_uniform_, torch.nn.init.uniform_
+    torch.nn.init.kaiming_uniform_ = lambda t, *a, **k: t
+    torch.nn.init.uniform_ = lambda t, *a, **k: t
+    try:
+        uref, cref = ou.UNet2DConditionRef(cfg), ControlNetRef(cfg)
+    finally:
+        torch.nn.init.kaiming_uniform_, torch.nn.init.uniform_ = orig
+    _fast_fill_(uref, seed=7)
+    _fast_fill_(cref, seed=8)
+    for m in (uref, cref):
+        round_weights_bf16_(m)
+        for p in m.parameters():
+            p.requires_grad_(False)
+    unet = HipUNet(pc.sdxl_config(), B, hw, hw, L, residual_inputs=True)
+    missing, unexpected = unet.load_state_dict(uref.state_dict())
+    assert not missing and not unexpected
+    cn = HipControlNet(pc.sdxl_config(), B, hw, hw, L)
+    assert set(cn.weight_table()) == set(cref.state_dict())
+    missing, unexpected = cn.load_state_dict(cref.state_dict())
+    assert not missing and not unexpected
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(B, 4, hw, hw, generator=g)
+    t = torch.tensor([601])
+    ehs = torch.randn(B, L, 2048, generator=g).to(torch.bfloat16).float()
+    added = {"text_embeds": torch.randn(B, 1280, generator=g).to(torch.bfloat16).float(),
+             "time_ids": torch.tensor([[1024., 1024, 0, 0, 1024, 1024]] * B)}
+    img = (torch.rand(B, 3, 8 * hw, 8 * hw, generator=g) > 0.9).float()        # canny-like sparse edges
+    scale = 0.5
+    t0 = time.time()
+    with torch.no_grad():
+        dref, mref = cref(x, t, ehs, img, conditioning_scale=scale, added_cond_kwargs=added)
+        eps_ref = uref(x, t, ehs, added_cond_kwargs=added, down_block_additional_residuals=dref,
+                       mid_block_additional_residual=mref)[0]
+        eps_plain = uref(x, t, ehs, added_cond_kwargs=added)[0]
+    t_or = time.time() - t0
+    cadd = {k: v.cuda() for k, v in added.items()}
+    down, mid = cn(x.cuda(), t.cuda(), encoder_hidden_states=ehs.cuda(), controlnet_cond=img.cuda(),
+                   conditioning_scale=scale, guess_mode=False, added_cond_kwargs=cadd, return_dict=False)
+    worst = 0.0
+    for i, (a, b) in enumerate(zip(down + [mid], dref + [mref])):
+        e = rel_l2(a, b)
+        worst = max(worst, e)
+        assert a.shape == b.shape and e < 1.5e-2, (i, e)
+    eps = unet(x.cuda(), t.cuda(), ehs.cuda(), added_cond_kwargs=cadd, down_block_additional_residuals=down,
+               mid_block_additional_residual=mid, return_dict=False)[0]
+    e = rel_l2(eps, eps_ref)
+    # device-to-device hand-over (cn.run + cn.feed) gives the same eps as the tensor route
+    cn.run(x.cuda(), t.cuda(), ehs.cuda(), img.cuda(), cadd)
+    cn.feed(unet, scale)
+    eps_fed = unet(x.cuda(), t.cuda(), encoder_hidden_states=ehs.cuda(), added_cond_kwargs=cadd)[0]
+    e_fed = rel_l2(eps_fed, eps_ref)
+    moved = rel_l2(eps_ref, eps_plain)
+    print(f"[sdxl + controlnet 1024x1024 B=1 vs oracle] worst residual rel_l2={worst:.3e} eps rel_l2={e:.3e} "
+          f"(fed device-to-device {e_fed:.3e}); the ControlNet moves eps by {moved:.3e}; oracle {t_or:.0f} s")
+    assert e < 1.5e-2 and e_fed < 1.5e-2
+    assert moved > 10 * e, "residual injection too weak to be tested by this comparison"

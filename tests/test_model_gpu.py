@@ -579,6 +579,84 @@ def test_sd15_full_size_step_vs_oracle(gpu):
     _sd15_step_check("sd15_config", B=2, L=77, hw=64, enc_dim=1024, hidden=2048, tol_fwd=2e-2, tol_grad=6e-3)   # measured grad 2.1e-3
 
 
+@pytest.mark.parametrize("tag", ["sdxl_hip_mixed", "sdxl_hip_all_en", "sdxl_hip_all_zh", "sdxl_hip_shared_teacher",
+                                 "sd15_hip_mixed"])
+def test_step_matches_reference_golden(gpu, golden_dir, tag):
+    """DIRECT HIP-vs-reference check of the whole step: tests/golden/step_*_hip_*.npz hold what the reference's own
+    `StableDiffusion.training_step` (train_sdxl_zh.py:305-449, train_sd_zh.py:184-281; run by oracle/make_golden.py on
+    collaborators at dims the MFMA tiles accept) produced -- the four logged scalars, eps of both UNets and the adapter's
+    parameter gradients (seven for SDXL, five for SD1.5) for forced CFG-dropout masks.  PEATrainer gets the same weights
+    (UNets regenerated from the fixture's seed, checksum-checked; MLP weights stored) and the same batch; no oracle code
+    sits between the two.  `shared_teacher`: teacher == student checkpoint as the reference loads it (:138,151) -> the
+    merged-pass launch set of bench.py."""
+    import os
+    from oracle import unet_ref as ou      # weights only: the fixture stores the UNets as seed + checksum
+    from pea_diffusion_amd import config as pc
+    from pea_diffusion_amd.adapter import PEAAdapter
+    from pea_diffusion_amd.train import PEATrainer
+    from pea_diffusion_amd.unet import HipUNet
+    g = np.load(os.path.join(golden_dir, f"step_{tag}.npz"))
+    T = lambda a: torch.from_numpy(np.asarray(a))
+    sdxl = tag.startswith("sdxl")
+    ocfg, pcfg = (ou.tiny_config(), pc.tiny_config()) if sdxl else (ou.tiny15_config(), pc.tiny15_config())
+    torch.manual_seed(int(g["seed_model"]))
+    us, ut = ou.UNet2DConditionRef(ocfg), ou.UNet2DConditionRef(ocfg)
+    shared = bool(int(g["shared_teacher"]))
+    if shared:
+        ut.load_state_dict(us.state_dict())
+    round_weights_bf16_(us), round_weights_bf16_(ut)
+    wsum = sum(float(v.double().abs().sum()) for m in (us, ut) for v in m.state_dict().values())
+    assert abs(wsum - float(g["wsum_unets"])) < 1e-6 * float(g["wsum_unets"]), "seeded UNet weights drifted"
+    B, L, hw = int(g["B"]), int(g["L"]), ocfg.sample_size
+    hs = HipUNet(pcfg, B, hw, hw, L, needs_grad=True)
+    hs.load_state_dict(us.state_dict())
+    if shared:
+        ht = HipUNet(pcfg, B, hw, hw, 77, share_weights_from=hs)
+    else:
+        ht = HipUNet(pcfg, B, hw, hw, 77)
+        ht.load_state_dict(ut.state_dict())
+    a = [int(v) for v in g["mlp_args"]]
+    ad = PEAAdapter(a[0], a[1], a[2], a[3], bool(a[4])) if sdxl else PEAAdapter(a[0], a[1], a[2], None, False)
+    ad.load_state_dict({k[2:]: T(g[k]) for k in g.files if k.startswith("w.")})     # the reference MLP's own keys
+    ad = ad.cuda()
+    keys = ["latents", "noise", "timesteps", "enc", "enc_uncond", "prompt_mask", "zh_or_not", "teacher_ehs", "teacher_neg"]
+    if sdxl:
+        keys += ["teacher_pooled", "time_ids"]
+    batch = {k: T(g[k]) for k in keys}
+    tr = PEATrainer(ad, hs, ht, nan_guard=not sdxl)
+    out = tr.training_step(batch, 0, sync=True)
+    if shared:
+        assert lib_merge_state(tr) == 1
+    e_s = rel_l2(tr.export("eps_student"), T(g["noise_pred"]))
+    e_t = rel_l2(tr.export("eps_teacher"), T(g["noise_pred_teacher"]))
+    assert e_s < 1.5e-2 and e_t < 1.5e-2, (e_s, e_t)
+    total = abs(float(g["loss"]))
+    for k in tr.LOG_KEYS:
+        h, r = float(out[k]), float(g[k])
+        # 1 % relative; the KD terms of a shared-checkpoint pair are differences of nearly equal bf16 tensors (absolute
+        # noise floor: 0.5 % of the total loss)
+        assert abs(h - r) <= 1e-2 * abs(r) + (5e-3 * total if shared else 1e-3 * total), (k, h, r)
+    names = [n for n, _ in ad.named_parameters()]
+    assert sorted("g." + n for n in names) == sorted(k for k in g.files if k.startswith("g."))
+    flat = ad.flat_grad.float().cpu()
+    worst = 0.0
+    for p, o in zip(ad._plist(), ad._offsets):
+        n = [nm for nm, q in ad.named_parameters() if q is p][0]
+        want = T(g["g." + n]).float()
+        got = flat[o:o + p.numel()].view_as(want)
+        if float(want.abs().max()) == 0.0:              # e.g. fc.* when no sample's pooled output reaches a loss
+            assert float(got.abs().max()) == 0.0, n
+            continue
+        e = rel_l2(got, want)
+        worst = max(worst, e)
+        assert e < 4e-2, (n, e)
+    g_ref = torch.cat([T(g["g." + [nm for nm, q in ad.named_parameters() if q is p][0]]).reshape(-1) for p in ad._plist()])
+    e_all = rel_l2(flat, g_ref)
+    print(f"[{tag}] eps rel_l2 student {e_s:.2e} teacher {e_t:.2e}; loss hip={float(out['loss']):.6f} ref={float(g['loss']):.6f}; "
+          f"adapter grad rel_l2 flat {e_all:.2e}, worst parameter {worst:.2e}")
+    assert e_all < 3e-2
+
+
 def _fast_fill_(module, seed=0):
     """deterministic weights without torch's single-threaded default init of 2.57 B parameters: every >= 2-D tensor is
     filled from one seeded uniform buffer read at a per-tensor offset, scaled to variance 1/(3 fan_in); norm weights 1,

@@ -66,6 +66,9 @@ def test_adapter_param_counts():
 
 
 def _cfg_from(g, which):
+    if "hip_dims" in g.files and int(g["hip_dims"]):
+        from oracle.unet_ref import tiny15_config
+        return tiny_config() if which == "sdxl" else tiny15_config()
     boc = tuple(int(v) for v in g["cfg_boc"])
     heads = tuple(int(v) for v in g["cfg_heads"])
     if which == "sdxl":
@@ -81,13 +84,25 @@ def _cfg_from(g, which):
                       projection_class_embeddings_input_dim=0, name="toy15")
 
 
-@pytest.mark.parametrize("tag", ["sdxl_mixed", "sdxl_all_en", "sdxl_all_zh", "sd15_mixed"])
+def _round_bf16_(module):
+    with torch.no_grad():
+        for p in module.parameters():
+            if p.dim() >= 2:
+                p.copy_(p.to(torch.bfloat16).float())
+
+
+@pytest.mark.parametrize("tag", ["sdxl_mixed", "sdxl_all_en", "sdxl_all_zh", "sd15_mixed", "sdxl_hip_mixed", "sdxl_hip_all_en",
+                                 "sdxl_hip_all_zh", "sdxl_hip_shared_teacher", "sd15_hip_mixed"])
 def test_training_step_vs_reference(golden_dir, tag):
     g = np.load(os.path.join(golden_dir, f"step_{tag}.npz"))
     which = "sdxl" if tag.startswith("sdxl") else "sd15"
     cfg = _cfg_from(g, which)
     torch.manual_seed(int(g["seed_model"]))
     us, ut = UNet2DConditionRef(cfg), UNet2DConditionRef(cfg)
+    if int(g["shared_teacher"]):
+        ut.load_state_dict(us.state_dict())
+    if int(g["hip_dims"]):                # the *_hip_* fixtures were generated on bf16-representable weights
+        _round_bf16_(us), _round_bf16_(ut)
     assert abs(_wsum(us.state_dict()) + _wsum(ut.state_dict()) - float(g["wsum_unets"])) < 1e-6 * float(g["wsum_unets"])
     ad = _adapter_from(g["mlp_args"])
     ad.load_state_dict({k[2:]: T(g[k]) for k in g.files if k.startswith("w.")})
@@ -103,6 +118,7 @@ def test_training_step_vs_reference(golden_dir, tag):
     for k, p in ad.named_parameters():
         torch.testing.assert_close(p.grad, T(g["g." + k]), rtol=2e-4, atol=2e-6)
     assert int(g["unet_wgrad_populated"]) == 1   # documented reference quirk
+    torch.testing.assert_close(out["noise_pred"], T(g["noise_pred"]), rtol=1e-4, atol=1e-5)
 
 
 def test_rescale_noise_cfg(golden_dir):
@@ -182,6 +198,16 @@ def test_ssd1b_layout_known_answers_and_config_json():
     nested = dataclasses.replace(pc.sdxl_config(), transformer_layers_per_block=(1, 2, (4, 10)),
                                  reverse_transformer_layers_per_block=((10, 4, 4), 2, 1))
     assert pc.depth_tables(nested)[2] == 4 and pc.depth_tables(nested)[0][2] == [4, 10]
+    # ... and the oracle built from that SAME nested config agrees with the product's table at every position, mid included
+    from oracle.unet_ref import sdxl_config as o_sdxl
+    ocfg = o_sdxl()
+    ocfg.transformer_layers_per_block, ocfg.reverse_transformer_layers_per_block = (1, 2, (4, 10)), ((10, 4, 4), 2, 1)
+    with torch.device("meta"):
+        mo = UNet2DConditionRef(ocfg)
+    d_, u_, mid_ = pc.depth_tables(nested)
+    assert len(mo.mid_block.attentions[0].transformer_blocks) == mid_ == 4
+    assert [len(a.transformer_blocks) for a in mo.down_blocks[2].attentions] == d_[2]
+    assert [len(a.transformer_blocks) for a in mo.up_blocks[0].attentions] == u_[0]
     sd = dict(js, transformer_layers_per_block=[1, 2, 10], reverse_transformer_layers_per_block=None,
               mid_block_type="UNetMidBlock2DCrossAttn")
     assert pc.depth_tables(pc.unet_config_from_diffusers(sd)) == pc.depth_tables(pc.sdxl_config())
