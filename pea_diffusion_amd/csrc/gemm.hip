@@ -23,6 +23,24 @@
 #endif
 
 #define BK 64
+#ifndef PEA_GEMM_ILV
+#define PEA_GEMM_ILV 1          // 1: fragment reads interleaved with the MFMAs of the 64-row-wave-tile K-loops (0: one burst behind the first n-tile)
+#endif
+#ifndef PEA_GEMM_ILV_M
+#define PEA_GEMM_ILV_M 1        // MFMAs between two interleaved ds_reads
+#endif
+#ifndef PEA_GEMM_ILV_HEAD
+#define PEA_GEMM_ILV_HEAD 4     // MFMAs in front of the first interleaved ds_read
+#endif
+#ifndef PEA_GEMM_ILV_EPI3
+#define PEA_GEMM_ILV_EPI3 1      // also in the fused GEGLU-backward instantiations (whole step 104.51 / 104.21 -> 103.98 / 103.79 ms)
+#endif
+#ifndef PEA_GEMM_ILV_LC
+#define PEA_GEMM_ILV_LC 0        // the one-tile-per-workgroup kernel: the burst form measures better there (104.1 vs 104.5 ms with it interleaved)
+#endif
+#ifndef PEA_GEMM_PRIO_YOUNG
+#define PEA_GEMM_PRIO_YOUNG 0   // 1: static s_setprio 1 for consumer waves 4..7 (the younger wave of every SIMD) -- experiment
+#endif
 
 __device__ __forceinline__ int swz_off(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
 
@@ -282,6 +300,48 @@ __device__ __forceinline__ void gemm_epilogue16(const GemmP& p, f32x4 (&acc)[NT]
 //   value = rstd[m] * (acc - mean[m] * s[n]) + t[n]        (p.ln_stats = [M][2] (mean, rstd), p.ln_s = s[N]);
 // such GEMMs have no residual and no row vector (QKV, attn2.to_q, FF projection with GEGLU).
 // EK: 0 = common form, 1 = LNF, 2 = the fused GEGLU backward (p.gbwd_pre; own instantiations for the same reason)
+// Stores of the batched-load epilogue, HIDDEN from hipcc's s_waitcnt bookkeeping (inline assembly; PEA_EPI_HIDDEN_STORES = 0
+// restores plain stores for an A/B).  Why: gfx950 has ONE vmcnt for loads and stores, and hipcc treats the two kinds as
+// completing out of order -- with a store pending, the only wait it can emit for a load is vmcnt(0).  In the persistent kernel
+// the registers that received the epilogue's bias / residual loads are the next tile's fragment registers; on the paths where
+// a load's use is predicated away the compiler still sees it pending at the first ds_read into that register (a write-after-
+// write hazard), and because the tile's stores are pending too it put `s_waitcnt vmcnt(0)` INSIDE the K-loop (and vmcnt(2) in
+// its preheader): every consumer wave waited out its own 10 KB of stores in the first K-step of the next tile, with the MFMA
+// pipes idle -- the store drain the persistent form exists to hide.  With the stores invisible every wait hipcc emits is a
+// wait for loads only (all loads of the epilogue are issued, and their data consumed, before its first store -- an asm load
+// wait would be unsafe otherwise), nothing is pending after the epilogue, and the stores drain under the next tile's K-steps.
+// The s_nop 1 of the 16-byte form is the store-data hazard hipcc would have padded (a following write of the data registers).
+#ifndef PEA_EPI_HIDDEN_STORES
+#define PEA_EPI_HIDDEN_STORES 0
+#endif
+typedef __attribute__((ext_vector_type(4))) unsigned epi_u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned epi_u32x2;
+// "this loaded value has been consumed": an empty asm use.  Placed behind every predicated region of the epilogue for the loads
+// whose real uses sit inside it, so that on the path that skips the region (all lanes of the wave past M: s_cbranch_execz) the
+// load is still waited for -- otherwise hipcc carries it as pending into the next tile's K-loop (see above).  No instruction.
+template <typename T>
+__device__ __forceinline__ void epi_consumed(const T& v) { asm volatile("" :: "v"(v)); }
+__device__ __forceinline__ void epi_store16(void* ptr, epi_u32x4 v) {
+#if PEA_EPI_HIDDEN_STORES
+  asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" :: "v"(ptr), "v"(v) : "memory");
+#else
+  *(epi_u32x4*)ptr = v;
+#endif
+}
+__device__ __forceinline__ void epi_store8(void* ptr, epi_u32x2 v) {
+#if PEA_EPI_HIDDEN_STORES
+  asm volatile("global_store_dwordx2 %0, %1, off" :: "v"(ptr), "v"(v) : "memory");
+#else
+  *(epi_u32x2*)ptr = v;
+#endif
+}
+__device__ __forceinline__ void epi_store4(void* ptr, unsigned v) {
+#if PEA_EPI_HIDDEN_STORES
+  asm volatile("global_store_dword %0, %1, off" :: "v"(ptr), "v"(v) : "memory");
+#else
+  *(unsigned*)ptr = v;
+#endif
+}
 template <int MT, int NT, int EK = 0>
 __device__ __forceinline__ void gemm_epilogue16_fast(const GemmP& p, f32x4 (&acc)[NT][MT], int m_base, int n_base, int r16,
                                                      int q4) {
@@ -378,7 +438,7 @@ __device__ __forceinline__ void gemm_epilogue16_fast(const GemmP& p, f32x4 (&acc
           // lane row q4 receives the words of lane rows (q4 & ~1) and (q4 | 1) of n-tile nt + (q4 & 1): 8 contiguous bytes
           const auto w = __builtin_amdgcn_permlane16_swap(y0.u, y1.u, false, false);
           const u32x2 o = {w[0], w[1]};
-          *(u32x2*)(yrow + ((n_base + (nt + (q4 & 1)) * 16) >> 1) + 4 * (q4 >> 1)) = o;
+          epi_store8(yrow + ((n_base + (nt + (q4 & 1)) * 16) >> 1) + 4 * (q4 >> 1), o);
           if (stash) {
             union { bf16x4 h; unsigned u[2]; } a, b;
 #pragma unroll
@@ -386,19 +446,21 @@ __device__ __forceinline__ void gemm_epilogue16_fast(const GemmP& p, f32x4 (&acc
             const auto lo = __builtin_amdgcn_permlane16_swap(a.u[0], b.u[0], false, false);
             const auto hi = __builtin_amdgcn_permlane16_swap(a.u[1], b.u[1], false, false);
             const u32x4 oc = {lo[0], hi[0], lo[1], hi[1]};
-            *(u32x4*)(crow + n_base + (nt + (q4 & 1)) * 16 + 8 * (q4 >> 1)) = oc;
+            epi_store16(crow + n_base + (nt + (q4 & 1)) * 16 + 8 * (q4 >> 1), oc);
           }
         } else {
-          *(bf16x2*)(yrow + ((n_base + nt * 16 + 4 * q4) >> 1)) = y0.h;
+          epi_store4(yrow + ((n_base + nt * 16 + 4 * q4) >> 1), y0.u);
           if (stash) {
-            bf16x4 oc;
+            union { bf16x4 h; u32x2 u; } oc;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) oc[j] = (bf16)v0[j];
-            *(bf16x4*)(crow + n_base + nt * 16 + 4 * q4) = oc;
+            for (int j = 0; j < 4; ++j) oc.h[j] = (bf16)v0[j];
+            epi_store8(crow + n_base + nt * 16 + 4 * q4, oc.u);
           }
         }
       }
     }
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) epi_consumed(bq[nt]);
     return;
   }
   if constexpr (EK == 2) {
@@ -497,13 +559,13 @@ __device__ __forceinline__ void gemm_epilogue16_fast(const GemmP& p, f32x4 (&acc
                 asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(lo[j]), "+v"(hi[j]));
               }
               const bf16x8 r8 = rp[mt][nt >> 1];
-              bf16x8 o;
+              union { bf16x8 h; u32x4 u; } o;
 #pragma unroll
               for (int j = 0; j < 4; ++j) {
-                o[j] = (bf16)(lo[j] + (float)r8[j]);
-                o[4 + j] = (bf16)(hi[j] + (float)r8[4 + j]);
+                o.h[j] = (bf16)(lo[j] + (float)r8[j]);
+                o.h[4 + j] = (bf16)(hi[j] + (float)r8[4 + j]);
               }
-              *(bf16x8*)(crow + n_base + (nt + (q4 & 1)) * 16 + 8 * (q4 >> 1)) = o;
+              epi_store16(crow + n_base + (nt + (q4 & 1)) * 16 + 8 * (q4 >> 1), o.u);
             } else {
               union { bf16x4 h; unsigned u[2]; } a, b;
 #pragma unroll
@@ -514,21 +576,28 @@ __device__ __forceinline__ void gemm_epilogue16_fast(const GemmP& p, f32x4 (&acc
               const auto lo = __builtin_amdgcn_permlane16_swap(a.u[0], b.u[0], false, false);
               const auto hi = __builtin_amdgcn_permlane16_swap(a.u[1], b.u[1], false, false);
               const u32x4 o = {lo[0], hi[0], lo[1], hi[1]};
-              *(u32x4*)(crow + n_base + (nt + (q4 & 1)) * 16 + 8 * (q4 >> 1)) = o;
+              epi_store16(crow + n_base + (nt + (q4 & 1)) * 16 + 8 * (q4 >> 1), o);
             }
           } else {                                                     // the single last tile of an odd nv
-            bf16x4 o;
+            union { bf16x4 h; u32x2 u; } o;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
               float v = val(nt, mt, j);
               if constexpr (HR) v += (float)rs[mt][j];
-              o[j] = (bf16)v;
+              o.h[j] = (bf16)v;
             }
-            *(bf16x4*)(crow + n_base + nt * 16 + 4 * q4) = o;
+            epi_store8(crow + n_base + nt * 16 + 4 * q4, o.u);
           }
         }
       }
+      if constexpr (HR) {
+#pragma unroll
+        for (int pr = 0; pr < NT / 2; ++pr) epi_consumed(rp[mt][pr]);
+        epi_consumed(rs[mt]);
+      }
     }
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) epi_consumed(bq[nt]);
   };
   if (has_res) body(std::true_type{});
   else body(std::false_type{});
@@ -938,6 +1007,27 @@ __global__ __launch_bounds__((WM * WN + LW) * 64, MINW) void gemm_lc_kernel(cons
         } else if (MT < 4) {
           load_frags(1, tile, 1);                              // (32-row wave tiles: hipcc's own placement measures better)
         }
+#if PEA_GEMM_ILV && PEA_GEMM_ILV_LC
+        if (MT >= 4) {                                         // (see gemm_lcp_kernel: fragment reads interleaved with the MFMAs)
+          __builtin_amdgcn_sched_barrier(0);
+          if (s2 == 0) load_frags(1, tile, 1);
+          else load_frags(0, smem + nxt * STAGE, 0);           // unconditional (last K-step: a harmless read of a stale slot)
+#pragma unroll
+          for (int nt_ = 0; nt_ < NT; ++nt_)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+              acc[nt_][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[s2][nt_], af[s2][mt], acc[nt_][mt], 0, 0, 0);
+          __builtin_amdgcn_sched_group_barrier(0x008, PEA_GEMM_ILV_HEAD, 0);
+#pragma unroll
+          for (int i = 0; i < MT + NT; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, PEA_GEMM_ILV_M, 0);
+          }
+          __builtin_amdgcn_sched_group_barrier(0x008, MT * NT, 0);
+          __builtin_amdgcn_sched_barrier(0);
+          continue;
+        }
+#endif
 #pragma unroll
         for (int nt_ = 0; nt_ < NT; ++nt_) {
 #pragma unroll
@@ -1352,6 +1442,9 @@ __global__ __launch_bounds__((WM * WN + LW + SW) * 64, (OCC == 2 ? 3 : 1)) void 
 #pragma unroll
     for (int nt_ = 0; nt_ < NT; ++nt_) wf[which][nt_] = *(const bf16x8*)(tile + w_off[s2] + nt_ * 2048);
   };
+#if PEA_GEMM_PRIO_YOUNG
+  if (NWC == 8 && wave >= 4) __builtin_amdgcn_s_setprio(1);
+#endif
   __builtin_amdgcn_s_barrier();                                // prologue barrier
   load_frags(0, smem, 0);
   int cur = 0, g = 0;
@@ -1396,6 +1489,31 @@ __global__ __launch_bounds__((WM * WN + LW + SW) * 64, (OCC == 2 ? 3 : 1)) void 
         } else if (MT < 4) {
           if (!PEA_PROBE(4)) load_frags(1, tile, 1);           // (32-row wave tiles: hipcc's own placement measures better)
         }
+#if PEA_GEMM_ILV
+        // the other half's fragment reads INTERLEAVED with this half's MFMAs (sched_group_barrier: HEAD MFMAs, then one ds_read per
+        // ILV_M MFMAs) instead of one burst of MT + NT reads behind the first n-tile: the 8 consumer waves of a CU run in lockstep
+        // between barriers, so a burst is 72 KB hitting the LDS at once while no wave issues an MFMA.  Whole step (round 4, alternating
+        // processes on one box): 104.38 / 103.99 ms -> 103.68 / 103.55 (M = 1, HEAD = 4), 104.04 / 103.65 (M = 2, HEAD = 2)
+        if (MT >= 4 && (EPI != 3 || PEA_GEMM_ILV_EPI3)) {
+          __builtin_amdgcn_sched_barrier(0);
+          if (s2 == 0) { if (!PEA_PROBE(4)) load_frags(1, tile, 1); }
+          else if (!PEA_PROBE(4)) load_frags(0, smem + nxt * STAGE, 0);     // unconditional (behind the block's last K-step: a harmless read of a stale slot)
+#pragma unroll
+          for (int nt_ = 0; nt_ < NT; ++nt_)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+              acc[nt_][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[s2][nt_], af[s2][mt], acc[nt_][mt], 0, 0, 0);
+          __builtin_amdgcn_sched_group_barrier(0x008, PEA_GEMM_ILV_HEAD, 0);
+#pragma unroll
+          for (int i = 0; i < MT + NT; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, PEA_GEMM_ILV_M, 0);
+          }
+          __builtin_amdgcn_sched_group_barrier(0x008, MT * NT, 0);
+          __builtin_amdgcn_sched_barrier(0);
+          continue;
+        }
+#endif
 #pragma unroll
         for (int nt_ = 0; nt_ < NT; ++nt_) {
 #pragma unroll
@@ -1558,6 +1676,7 @@ extern "C" void pea_debug_set_gemm_variant(int v) { g_gemm_variant = v; }
     case 33: rc = launch_lcp<MODE, 256, 128, 4, 2, 4, 3, 0, 0, 1>(p, stream); break; \
     case 34: rc = launch_lcp<MODE, 128, 160, 4, 2, 4, 3, 4>(p, stream); break; /* staged epilogue */ \
     case 35: rc = launch_lcp<MODE, 128, 160, 4, 2, 4, 3, 0, 1>(p, stream); break; /* deferred epilogue */ \
+    case 38: rc = launch_lcp<MODE, 256, 160, 4, 2, 2, 3, 0, 0, 1>(p, stream); break; /* 27 with TWO loader waves (experiment) */ \
     case 36: rc = launch_lcp<MODE, 128, 160, 2, 2, 2, 2, 0, 0, 1, 2>(p, stream); break; /* two workgroups per CU */ \
     case 37: rc = launch_lcp<MODE, 128, 128, 2, 2, 2, 2, 0, 0, 1, 2>(p, stream); break; \
     default: rc = launch_lc<MODE, 128, 128, 2, 2, 4, 4, false, true>(p, stream); break; \
