@@ -379,7 +379,7 @@ int pea_train_step(void* tr, const float* latents, const float* noise, const lon
  * context lengths agree, both UNet forwards run as ONE pass over 2B samples and the backward differentiates the
  * first B; otherwise the two-stream path is used) */
 int pea_trainer_set_option(void* tr, const char* name, int value);
-int pea_trainer_get_option(void* trainer, const char* name);   /* also "merge_state": 0 undecided, 1 merged, -1 n/a */
+int pea_trainer_get_option(void* trainer, const char* name);   /* also "merge_state": 0 undecided, 1 merged, -1 n/a; "kd_samples_hint" (set: profiling only -- samples with zh_or_not == 0, for the KD-loss kernel's byte count) */
 /* pea_unet_release_activations on the trainer's student, teacher and merged-pass contexts.  The reference trains over
  * nine aspect-ratio buckets (utils/custom_dataset_sdxl.py:30, one bucket per batch): a caller keeps one trainer per
  * bucket -- all sharing one set of weights and one adapter -- and releases the least recently used when HBM runs short
@@ -420,6 +420,11 @@ const char* pea_prof_family_name(int fam);
 /* CSV of every recorded launch: family, ms, flops, bytes, shape tags (GEMM: M,N,K,epilogue flags) */
 int pea_prof_dump(const char* path);
 int pea_prof_report(int fam, double* ms, double* flops, double* bytes, long long* launches);
+/* Sustained MFMA ceiling of this device: v_mfma_f32_16x16x32_bf16 (shape32 = 1: 32x32x16) issued back to back from registers on
+ * random operands, two waves per SIMD on every CU, launches back to back for `seconds` (<= 30; default 2); *tflops = the last
+ * launch's FLOP/s from HIP events, *clock_mhz = its in-kernel clock (delta s_memtime / delta s_memrealtime x 100 MHz, median over
+ * the workgroups).  Synchronises the stream.  bench.py reports it as roofline.sustained_peak beside the 2.5 PFLOP/s spec peak. */
+int pea_probe_mfma_peak(double seconds, int shape32, double* tflops, double* clock_mhz, void* stream);
 
 /* debugging aid for the parity tests: 1 = ds_read_b64_tr_b16 transpose reads (default), 0 = scalar gathers */
 void pea_debug_set_attn_tr(int v);

@@ -571,6 +571,7 @@ int pea_trainer_set_option(void* h, const char* name, int value) {
   if (!strcmp(name, "two_stream")) t->two_stream = value;
   else if (!strcmp(name, "merge_passes")) t->merge_passes = value;
   else if (!strcmp(name, "nan_guard")) t->nan_guard = value;
+  else if (!strcmp(name, "kd_samples_hint")) t->kd_samples_hint = value;    /* profiling only: samples with zh_or_not == 0 */
   else {
     pea_set_error("pea_trainer_set_option: unknown option '%s'", name);
     return PEA_E_INVALID;
@@ -592,6 +593,7 @@ int pea_trainer_get_option(void* h, const char* name) {
   if (!strcmp(name, "merge_passes")) return t->merge_passes;
   if (!strcmp(name, "merge_state")) return t->merge_state;     /* 0 undecided, 1 merged, -1 not eligible */
   if (!strcmp(name, "nan_guard")) return t->nan_guard;
+  if (!strcmp(name, "kd_samples_hint")) return t->kd_samples_hint;
   if (!strcmp(name, "merged_mib"))                                /* activations + gradients of the merged-pass context */
     return t->merged && t->merged->aarena ? (int)((t->merged->abytes + t->merged->gbytes) >> 20) : 0;
   return PEA_E_INVALID;

@@ -251,6 +251,7 @@ int pea_op_kd_loss(int ntaps, const void* const* taps_s, const void* const* taps
   }
   KdLossP p;
   memset(&p, 0, sizeof(p));
+  p.kd_samples_hint = -1;
   p.ntaps = ntaps;
   for (int k = 0; k < ntaps; ++k) {
     p.fs[k] = (const bf16*)taps_s[k];

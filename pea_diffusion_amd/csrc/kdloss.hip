@@ -169,9 +169,14 @@ int launch_kd_loss(const KdLossP& p, hipStream_t s) {
   int* skip = (int*)p.partial;
   float* partial = (float*)(skip + PEA_MAX_TAPS);
   {
+    // bytes actually moved: a sample with zh_or_not == 0 reads both taps and writes its seed (3 x 2 B per element); a masked one
+    // is not read at all, only its zero seed is written (2 B).  The mask lives on the device: the count is a caller's hint
+    // (pea_trainer_set_option "kd_samples_hint", bench.py); without it every sample is counted as read (an upper bound).
+    const int on = (p.kd_samples_hint >= 0 && p.kd_samples_hint <= p.B) ? p.kd_samples_hint : p.B;
     double by = 0;
-    for (int k = 0; k < p.ntaps; ++k) by += 3.0 * 2.0 * p.B * (double)p.per[k];     // 2 reads + 1 write, bf16
-    by += 4.0 * 4.0 * p.B * (double)p.per_eps;
+    for (int k = 0; k < p.ntaps; ++k) by += 2.0 * (3.0 * on + 1.0 * (p.B - on)) * (double)p.per[k] * (p.dfs[k] ? 1.0 : 0.0)
+                                            + (p.dfs[k] ? 0.0 : 2.0 * 2.0 * on * (double)p.per[k]);
+    by += 4.0 * (p.deps_s ? 3.0 : 2.0) * p.B * (double)p.per_eps;                       // eps: two fp32 reads (+ the seed write)
     PROF_BEGIN(7, 0.0, by, s);
   }
   hipLaunchKernelGGL(kd_loss_kernel, dim3((unsigned)blk), dim3(256), 0, s, p, segs, partial);

@@ -243,6 +243,7 @@ struct Trainer {
   int two_stream = 1; hipStream_t side = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   // merged passes: when the teacher IS the student checkpoint (shared weights, reference default) both forwards run
   // as ONE pass over 2B samples (student rows first) and the backward differentiates the first B only
+  int kd_samples_hint = -1;          // profiling only (KdLossP::kd_samples_hint)
   int merge_passes = 1; int merge_state = 0;   // state: 0 undecided, 1 merged, -1 not eligible
   Tape* merged = nullptr;
   float *xt2 = nullptr, *eps2 = nullptr, *t2 = nullptr, *tid2 = nullptr;

@@ -1756,6 +1756,7 @@ int Trainer::step(const float* latents, const float* noise, const long long* tim
   // fused KD loss + seeds; :399-441
   KdLossP kp;
   memset(&kp, 0, sizeof(kp));
+  kp.kd_samples_hint = kd_samples_hint;
   kp.ntaps = (int)tap_pairs.size();
   S.begin_backward();
   for (int k = 0; k < kp.ntaps; ++k) {
@@ -1833,6 +1834,7 @@ int Trainer::step_merged(const float* latents, const float* noise, const long lo
   RC(M.forward(xt2, t2, ehs.d, 1, text, 1, tid2, eps2, s));
   KdLossP kp;
   memset(&kp, 0, sizeof(kp));
+  kp.kd_samples_hint = kd_samples_hint;
   kp.ntaps = (int)M.taps.size();
   M.begin_backward();
   for (int k = 0; k < kp.ntaps; ++k) {

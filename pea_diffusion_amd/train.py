@@ -57,6 +57,7 @@ class PEATrainer:
         self.comm: Optional[pdist.NativeComm] = None      # RCCL communicator + comm stream inside libpea_hip.so
         self._pending = None                               # torch.distributed work handle (gloo / torch-NCCL path)
         self._comm_inflight = False                        # an all-reduce launched on the native communicator, not joined yet
+        self.local_only = False                            # True: steps skip the gradient all-reduce (bench.py: the single-GPU-equivalent step time of an N-rank run)
 
     def __del__(self):
         try:
@@ -95,7 +96,7 @@ class PEATrainer:
                                    ptr(tp), ptr(tid), 1.0, ptr(self.adapter.flat_grad), 0, ptr(self.losses),
                                    stream_ptr()))
         self._keep = (b, ts, pm, zh, tp, tid)
-        if self.comm is not None or world > 1:
+        if (self.comm is not None or world > 1) and not self.local_only:
             self.all_reduce_grads_async()   # launched right behind the adapter wgrad
             if not async_allreduce:
                 self.join_grads()

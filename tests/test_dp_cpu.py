@@ -138,6 +138,10 @@ def test_bench_launcher_spawns_two_ranks_over_gloo():
     out = json.loads(lines[0])
     assert out["ranks"] == 2 and out["n_gpus"] == 2 and out["per_gpu_batch"] == 8 and out["global_batch"] == 16
     assert out["allreduce_max_abs_err"] < 1e-5 and out["dry_run"] is True
+    # pre-flight of the 8 x batch-8 run: the per-rank HBM plan (host-only planning pass of the C ABI) fits 288 GB with room,
+    # and every rank was pinned to its own slice of the host's cores
+    assert 100.0 < out["hbm_plan_gb_per_rank"] < 0.92 * out["hbm_capacity_gb"] and out["per_gpu_batch"] == 8
+    assert out["cores_per_rank"] >= 1
     # the whole control flow ran on BOTH ranks: warm-up + K timed steps + the instrumented replay (each step holds a
     # collective, so a replay on rank 0 only would have left this subprocess hanging) + the closing barrier
     assert out["steps_run_per_rank"] == 3 + 2 + 2 and out["replay"] == {"replayed_steps": 2}
