@@ -763,7 +763,7 @@ def main():
     # measured in this run -- the single-GPU number the N-rank value is weak scaling against (the driver's N = 1 line runs
     # BASELINE configs[1], batch 4: a different per-GPU workload)
     solo_ms = None
-    if world > 1:
+    if world > 1 or args.force_collective:                  # (--force-collective: the same code path with one rank)
         barrier()
         trainer.local_only = True
         evs = []
@@ -775,7 +775,7 @@ def main():
         trainer.local_only = False
         if comm is not None:
             comm.broadcast_(adapter.flat_param, 0)            # the replicas diverged during the local-only steps
-        else:
+        elif use_dist:
             from pea_diffusion_amd import dist as pdist2
             pdist2.broadcast_params_(adapter.flat_param, src=0)
         adapter.mark_updated()

@@ -132,3 +132,8 @@ def test_bench_subprocess_with_collective_and_side_stream_vae(gpu):
     fams = {f["family"]: f for f in out["roofline"]["families"]}
     assert any(k.startswith("gemm") for k in fams) and "attn_bwd" in fams and "kd_loss" in fams
     assert out["ms_per_step"] > 0 and out["ms_per_step_mean"] > 0
+    # round 4: the single-GPU-equivalent step (collective switched off) measured in the same run, the HBM plan, the MFMA probe
+    assert out["single_gpu_equivalent"]["ms_per_step"] > 0 and out["hbm_plan_gb_per_rank"] > 0
+    sp = out["roofline"]["sustained_peak"]
+    assert sp["tflops"] > 500 and 800 < sp["in_kernel_clock_mhz"] <= 2500 and out["roofline"]["frac_of_sustained"] > 0
+    assert isinstance(out["roofline"]["adapter_golden_rel_l2"]["measured_in_this_run"], list)
