@@ -521,6 +521,8 @@ def main():
                     help="also time the CPU step with the student UNet left trainable as the reference leaves it "
                          "(train_sdxl_zh.py:166-168: 2.57 B unused weight gradients); one-off, recorded under profiles/")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-dead-row-line", action="store_true",
+                    help="skip the supplementary dead-row-elimination measurement (10 extra steps after the timed region)")
     ap.add_argument("--force-collective", action="store_true", help="init RCCL and all-reduce even with one rank (path test)")
     ap.add_argument("--dump-prof", default="", help="write every profiled launch (shape-tagged) to this CSV")
     ap.add_argument("--breakdown", action="store_true", help="print the per-kernel-family table to stderr")
@@ -781,6 +783,43 @@ def main():
         adapter.mark_updated()
         barrier()
 
+    # Supplementary (never `value`): the same steps with dead-row elimination -- teacher rows whose KD weight (1 - zh_or_not) is
+    # zero are not computed (PEATrainer.skip_dead_teacher_rows; identical losses and gradients, tests/test_dead_rows_gpu.py).
+    # The headline above computes every teacher row, as the reference does.
+    dre = None
+    if world == 1 and not args.no_dead_row_line and lib().pea_trainer_get_option(trainer._h, b"merge_state") == 1:
+        zh_host = batch["zh_or_not"].cpu()
+        batch_dre = dict(batch, zh_or_not=zh_host)               # the dataloader's mask is a host tensor: no synchronising copy
+        trainer.skip_dead_teacher_rows = True
+        try:
+            def step_dre(marks):
+                trainer.training_step(batch_dre, async_allreduce=True)
+                trainer.optimizer_step()
+                if marks is not None:
+                    e = torch.cuda.Event(enable_timing=True)
+                    e.record()
+                    marks.append(e)
+            for _ in range(3):
+                step_dre(None)
+            torch.cuda.synchronize()
+            evs = []
+            t0 = time.perf_counter()
+            for _ in range(10):
+                step_dre(evs)
+            torch.cuda.synchronize()
+            wall = time.perf_counter() - t0
+            ts = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(len(evs) - 1))
+            rows = lib().pea_trainer_get_option(trainer._h, b"merged_rows")
+            dre = {"ms_per_step": round(ts[len(ts) // 2], 3), "images_per_s": round(B * 10 / wall, 3),
+                   "merged_rows": rows, "of": 2 * B,
+                   "what": f"{int((zh_host == 1).sum())} of {B} samples have zh_or_not = 1: their teacher rows carry KD weight 0 and are "
+                           "skipped; supplementary, NOT the headline (10 steps after the timed region)"}
+        finally:
+            trainer.skip_dead_teacher_rows = False
+            trainer.training_step(batch, async_allreduce=True)    # back on the full 2B-row context before the instrumented replay
+            trainer.optimizer_step()
+            torch.cuda.synchronize()
+
     roof, cpu = after_timing(args, rank, world, step, instrument, barrier)
 
     if use_dist:
@@ -828,6 +867,7 @@ def main():
                                        "what": f"the same per-GPU batch {B} step with the all-reduce switched off, median of 5 steps on "
                                                "rank 0 right after the timed region of THIS run: the weak-scaling reference for this "
                                                "line (N x images_per_s = perfect scaling)"} if solo_ms else None),
+            "dead_row_elimination": dre,
             "hbm_plan_gb_per_rank": plan_gb, "cores_per_rank": cores_per_rank or None,
             "gpu": sampler.summary() if sampler is not None else None,
             "roofline": roof, "cpu_baseline": cpu,

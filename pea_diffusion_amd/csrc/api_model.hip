@@ -571,6 +571,7 @@ int pea_trainer_set_option(void* h, const char* name, int value) {
   if (!strcmp(name, "two_stream")) t->two_stream = value;
   else if (!strcmp(name, "merge_passes")) t->merge_passes = value;
   else if (!strcmp(name, "nan_guard")) t->nan_guard = value;
+  else if (!strcmp(name, "live_teacher_mask")) t->live_teacher_mask = value;   /* dead-row elimination: bit i = compute sample i's teacher row; -1 = all */
   else if (!strcmp(name, "kd_samples_hint")) t->kd_samples_hint = value;    /* profiling only: samples with zh_or_not == 0 */
   else {
     pea_set_error("pea_trainer_set_option: unknown option '%s'", name);
@@ -583,7 +584,9 @@ int pea_trainer_release_activations(void* h) {
   Trainer* t = (Trainer*)h;
   RCX(t->student->release_acts());
   RCX(t->teacher->release_acts());
+  for (auto& kv : t->merged_n) RCX(kv.second->release_acts());     /* borrowers first */
   if (t->merged) RCX(t->merged->release_acts());
+  t->last_ctx = nullptr;
   return PEA_OK;
 }
 int pea_trainer_get_option(void* h, const char* name) {
@@ -594,6 +597,8 @@ int pea_trainer_get_option(void* h, const char* name) {
   if (!strcmp(name, "merge_state")) return t->merge_state;     /* 0 undecided, 1 merged, -1 not eligible */
   if (!strcmp(name, "nan_guard")) return t->nan_guard;
   if (!strcmp(name, "kd_samples_hint")) return t->kd_samples_hint;
+  if (!strcmp(name, "live_teacher_mask")) return t->live_teacher_mask;
+  if (!strcmp(name, "merged_rows")) return t->last_ctx ? t->last_ctx->B : (t->merged ? t->merged->B : 0);   /* samples in the last merged pass */
   if (!strcmp(name, "merged_mib"))                                /* activations + gradients of the merged-pass context */
     return t->merged && t->merged->aarena ? (int)((t->merged->abytes + t->merged->gbytes) >> 20) : 0;
   return PEA_E_INVALID;
@@ -605,6 +610,16 @@ int pea_trainer_export(void* h, int which, float* out, void* stream) {
   const bool mg = t->merge_passes && t->merge_state == 1;
   const float* src = mg ? (which == 0 ? t->xt2 : which == 1 ? t->eps2 : t->eps2 + n)
                         : (which == 0 ? t->xt : which == 1 ? t->eps_s : t->eps_t);
+  const int B = t->student->B;
+  if (mg && which == 2 && t->last_ctx && t->last_ctx->B != 2 * B) {
+    /* dead-row elimination: the teacher rows are compacted; rows that were not computed come back as NaN */
+    const size_t per = n / B;
+    HIPCHK(hipMemsetAsync(out, 0xff, n * 4, (hipStream_t)stream));
+    for (int i = 0; i < B; ++i)
+      if (t->tmap_h[i] >= 0)
+        HIPCHK(hipMemcpyAsync(out + i * per, src + (size_t)t->tmap_h[i] * per, per * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return PEA_OK;
+  }
   HIPCHK(hipMemcpyAsync(out, src, n * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));
   return PEA_OK;
 }

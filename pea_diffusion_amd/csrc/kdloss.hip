@@ -47,8 +47,9 @@ __global__ __launch_bounds__(256) void kd_loss_kernel(const KdLossP p, const KdS
       const bool on = p.zh[b] == 0;          // weight (1 - zh_or_not)
       bf16x8 g;
       if (on) {
+        const long long ct = p.tmap ? (long long)p.tmap[b] * per8 + (c - (long long)b * per8) : c;
         const bf16x8 a = *(const bf16x8*)(fs + c * 8);
-        const bf16x8 t = *(const bf16x8*)(ft + c * 8);
+        const bf16x8 t = *(const bf16x8*)(ft + ct * 8);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
           const float d = (float)a[j] - (float)t[j];
@@ -70,7 +71,8 @@ __global__ __launch_bounds__(256) void kd_loss_kernel(const KdLossP p, const KdS
       const int b = (int)(c / per4);
       const bool zh = p.zh[b] != 0;
       const f32x4 es = *(const f32x4*)(p.eps_s + c * 4);
-      const f32x4 other = zh ? *(const f32x4*)(p.eps + c * 4) : *(const f32x4*)(p.eps_t + c * 4);
+      const long long ct = (!zh && p.tmap) ? (long long)p.tmap[b] * per4 + (c - (long long)b * per4) : c;
+      const f32x4 other = zh ? *(const f32x4*)(p.eps + c * 4) : *(const f32x4*)(p.eps_t + ct * 4);
       f32x4 g;
       float acc = 0.f;
 #pragma unroll

@@ -190,6 +190,8 @@ struct Tape {
   int* cross_kvlen = nullptr;        // graph 0: per-sample valid context tokens of the cross-attention (merged passes with a shorter
                                      // student context; rows beyond it in t_ehs are zero padding), null = all L
   int exec_ops(size_t begin, size_t end, bool skip_cached, hipStream_t s);
+  Tape* arena_donor = nullptr;       // activation / gradient arenas borrowed from this (larger) tape: the two are never live at once
+  bool arena_borrowed = false;
   int n_attn = 0, n_attn_pre = 0;    // attention ops on the tape / of those, fed a prescaled Q (tag_q_prescale)
   void tag_q_prescale();
   int ensure_acts();                 // lazy allocation of the activation / gradient arenas and scratch
@@ -246,6 +248,17 @@ struct Trainer {
   int kd_samples_hint = -1;          // profiling only (KdLossP::kd_samples_hint)
   int merge_passes = 1; int merge_state = 0;   // state: 0 undecided, 1 merged, -1 not eligible
   Tape* merged = nullptr;
+  // Dead-row elimination (opt-in, option "live_teacher_mask"): the KD terms of a sample carry the weight (1 - zh_or_not)
+  // (train_sdxl_zh.py:402-441), so the teacher row of a sample with zh_or_not == 1 is multiplied by zero and never read by the
+  // loss kernel -- with the mask known on the host that row is not computed: the merged pass runs over B + n_t samples (student
+  // rows first, then the n_t live teacher rows, compacted).  Bit i set = sample i's teacher row is computed; -1 = all (default).
+  int live_teacher_mask = -1;
+  std::map<int, Tape*> merged_n;        // contexts for B + n_t rows, n_t < B: built on first use, arenas borrowed from `merged`
+  Tape* last_ctx = nullptr;
+  int* tmap_d = nullptr;                // device int[B]: teacher row of sample b (relative to the first teacher row) or -1
+  int tmap_h[32];                       // host copy of the last step's map (export)
+  bf16* tpool_c = nullptr;              // [B][pooled] bf16: teacher pooled embeds of all samples, before compaction
+  int context_for(int nt, Tape** out);
   float *xt2 = nullptr, *eps2 = nullptr, *t2 = nullptr, *tid2 = nullptr;
   int step_merged(const float* latents, const float* noise, const long long* timesteps, const float* enc,
                   const float* enc_uncond, const unsigned char* prompt_mask, const long long* zh, const float* teacher_ehs,

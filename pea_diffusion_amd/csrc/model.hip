@@ -845,8 +845,16 @@ int Tape::alloc() {
 // which is half of the resident HBM at the benchmark size.
 int Tape::ensure_acts() {
   if (aarena) return PEA_OK;
-  HIPCHK(hipMalloc((void**)&aarena, abytes));
-  if (gbytes) HIPCHK(hipMalloc((void**)&garena, gbytes));
+  if (arena_donor) {
+    RC(arena_donor->ensure_acts());
+    SHAPECHK(abytes <= arena_donor->abytes && gbytes <= arena_donor->gbytes, "tape: borrowed arenas are too small");
+    aarena = arena_donor->aarena;
+    garena = gbytes ? arena_donor->garena : nullptr;
+    arena_borrowed = true;
+  } else {
+    HIPCHK(hipMalloc((void**)&aarena, abytes));
+    if (gbytes) HIPCHK(hipMalloc((void**)&garena, gbytes));
+  }
   for (Tn& t : tn) {
     t.d = (bf16*)(aarena + t.off_d);
     if (needs_grad && t.rg) t.g = (bf16*)(garena + t.off_g);
@@ -922,6 +930,7 @@ int Tape::ensure_acts() {
 // keep only the recently used ones resident.
 int Tape::release_acts() {
   HIPCHK(hipDeviceSynchronize());
+  if (arena_borrowed) { aarena = nullptr; garena = nullptr; arena_borrowed = false; }    // the donor frees them
   void** bufs[] = {(void**)&aarena, (void**)&garena, (void**)&gn_scratch, (void**)&delta, (void**)&ups_tmp, (void**)&tproj_grad,
                    (void**)&cs_scratch, (void**)&attn_part, (void**)&kv_part, (void**)&geglu_tmp, (void**)&am_scores,
                    (void**)&am_vt, (void**)&vae_h, (void**)&kvlen, (void**)&rel_bias, (void**)&rel_bucket};
@@ -936,8 +945,8 @@ int Tape::release_acts() {
 Tape::~Tape() {
   if (owns_weights && warena) hipFree(warena);
   if (tmp_f32) hipFree(tmp_f32);
-  if (aarena) hipFree(aarena);
-  if (garena) hipFree(garena);
+  if (aarena && !arena_borrowed) hipFree(aarena);
+  if (garena && !arena_borrowed) hipFree(garena);
   if (gn_scratch) hipFree(gn_scratch);
   if (delta) hipFree(delta);
   if (ups_tmp) hipFree(ups_tmp);
@@ -1598,6 +1607,9 @@ Trainer::~Trainer() {
   for (void* p : {(void*)xt, (void*)eps_s, (void*)eps_t, (void*)deps, (void*)ac, (void*)t_ehs_sel, (void*)dehs_full, (void*)t_f32,
                   (void*)losses, (void*)kd_ws, (void*)tehs_c, (void*)tehs_n, (void*)xt2, (void*)eps2, (void*)t2, (void*)tid2})
     if (p) hipFree(p);
+  for (auto& kv : merged_n) delete kv.second;           // (their arenas are borrowed from `merged`: freed below)
+  if (tmap_d) hipFree(tmap_d);
+  if (tpool_c) hipFree(tpool_c);
   delete merged;
 }
 
@@ -1792,25 +1804,81 @@ int Trainer::step(const float* latents, const float* noise, const long long* tim
 // difference between one and two 128-row tiles per CU in most launches -- and the backward pass walks the tape on
 // the leading B samples only (Tape::bwd_batch).  The teacher half runs without `no_grad` bookkeeping differences:
 // nothing in the forward depends on whether a gradient will be taken.
+// merged-pass context for B student rows + nt live teacher rows (nt < B); see Trainer::live_teacher_mask
+int Trainer::context_for(int nt, Tape** out) {
+  Tape& S = *student;
+  Tape& Tt = *teacher;
+  const int B = S.B;
+  if (nt >= B) { *out = merged; return PEA_OK; }
+  auto it = merged_n.find(nt);
+  if (it != merged_n.end()) { *out = it->second; return PEA_OK; }
+  Tape* m = new Tape();
+  m->cfg = S.cfg;
+  m->B = B + nt; m->H = S.H; m->W = S.W; m->L = Tt.L;
+  m->needs_grad = true; m->owns_weights = false; m->bwd_batch = B;
+  int rc = m->build();
+  if (rc == PEA_OK) rc = m->share_weights_from(S);
+  if (rc == PEA_OK) rc = m->alloc();
+  if (rc != PEA_OK) { delete m; return rc; }
+  m->arena_donor = merged;
+  if (S.L != Tt.L) {
+    std::vector<int> kl(B + nt, Tt.L);
+    for (int i = 0; i < B; ++i) kl[i] = S.L;
+    HIPCHK(hipMalloc((void**)&m->cross_kvlen, sizeof(int) * (B + nt)));
+    HIPCHK(hipMemcpy(m->cross_kvlen, kl.data(), sizeof(int) * (B + nt), hipMemcpyHostToDevice));
+    m->tn[m->t_ehs].zero_init = true;
+  }
+  merged_n[nt] = m;
+  *out = m;
+  return PEA_OK;
+}
+
 int Trainer::step_merged(const float* latents, const float* noise, const long long* timesteps, const float* enc,
                          const float* enc_uncond, const unsigned char* prompt_mask, const long long* zh,
                          const float* teacher_ehs, const float* teacher_neg, const float* teacher_pooled,
                          const float* time_ids, float grad_scale, float* grads, int accumulate, float* losses_out,
                          hipStream_t s) {
-  Tape& M = *merged;
+  const int B = student->B;
+  // live teacher rows (dead-row elimination, model.h): idx[j] = the sample whose teacher row is merged row B + j
+  int idx[32], nt = 0;
+  const bool dre = live_teacher_mask >= 0 && B <= 30 && (live_teacher_mask & ((1 << B) - 1)) != ((1 << B) - 1);
+  for (int i = 0; i < B; ++i) {
+    const bool live = !dre || ((live_teacher_mask >> i) & 1);
+    tmap_h[i] = live ? nt : -1;
+    if (live) idx[nt++] = i;
+  }
+  Tape* Mp = merged;
+  if (dre) RC(context_for(nt, &Mp));
+  Tape& M = *Mp;
   SHAPECHK(M.t_text < 0 || (teacher_pooled != nullptr && time_ids != nullptr),
            "trainer: teacher_pooled / time_ids are required for a text_time UNet (added_cond_kwargs, train_sdxl_zh.py:386-396)");
   RC(M.ensure_acts());
+  if (last_ctx != Mp && (dre || last_ctx != nullptr)) {
+    // the contexts share one pair of arenas with different layouts: whatever must read as zero is cleared again
+    for (Tn& t : M.tn)
+      if (t.zero_init) HIPCHK(hipMemsetAsync(t.d, 0, (size_t)t.rows * t.cols * 2, s));
+    for (int e : M.ext_res) HIPCHK(hipMemsetAsync(M.tn[e].d, 0, (size_t)M.tn[e].rows * M.tn[e].cols * 2, s));
+  }
+  last_ctx = Mp;
   Adapter& A = *ad;
-  const int B = student->B;
   const long long per_img = (long long)M.cfg.in_channels * M.H * M.W;
   RC(launch_add_noise(latents, noise, timesteps, ac, xt2, B, per_img, s));
-  HIPCHK(hipMemcpyAsync(xt2 + B * per_img, xt2, (size_t)B * per_img * 4, hipMemcpyDeviceToDevice, s));
   RC(launch_cast_i64_f32(timesteps, t2, B, s));
-  HIPCHK(hipMemcpyAsync(t2 + B, t2, (size_t)B * 4, hipMemcpyDeviceToDevice, s));
+  if (!dre) {
+    HIPCHK(hipMemcpyAsync(xt2 + B * per_img, xt2, (size_t)B * per_img * 4, hipMemcpyDeviceToDevice, s));
+    HIPCHK(hipMemcpyAsync(t2 + B, t2, (size_t)B * 4, hipMemcpyDeviceToDevice, s));
+  } else {
+    for (int j = 0; j < nt; ++j) {
+      HIPCHK(hipMemcpyAsync(xt2 + (B + j) * per_img, xt2 + idx[j] * per_img, (size_t)per_img * 4, hipMemcpyDeviceToDevice, s));
+      HIPCHK(hipMemcpyAsync(t2 + B + j, t2 + idx[j], 4, hipMemcpyDeviceToDevice, s));
+    }
+  }
   if (time_ids) {
     HIPCHK(hipMemcpyAsync(tid2, time_ids, (size_t)B * 6 * 4, hipMemcpyDeviceToDevice, s));
-    HIPCHK(hipMemcpyAsync(tid2 + B * 6, time_ids, (size_t)B * 6 * 4, hipMemcpyDeviceToDevice, s));
+    if (!dre) HIPCHK(hipMemcpyAsync(tid2 + B * 6, time_ids, (size_t)B * 6 * 4, hipMemcpyDeviceToDevice, s));
+    else
+      for (int j = 0; j < nt; ++j)
+        HIPCHK(hipMemcpyAsync(tid2 + (B + j) * 6, time_ids + idx[j] * 6, 6 * 4, hipMemcpyDeviceToDevice, s));
   }
   const long long per_tok = (long long)M.L * M.cfg.cross_dim;               // merged context: the teacher's length
   const long long per_stok = (long long)student->L * M.cfg.cross_dim;       // tokens the adapter emits per sample
@@ -1818,7 +1886,13 @@ int Trainer::step_merged(const float* latents, const float* noise, const long lo
   // teacher rows: where(prompt_mask, negative, prompt) (:413)
   RC(launch_cast_f32_bf16(teacher_ehs, tehs_c, B * per_tok, s));
   RC(launch_cast_f32_bf16(teacher_neg, tehs_n, B * per_tok, s));
-  RC(launch_select_rows(tehs_c, tehs_n, prompt_mask, ehs.d + B * per_tok, B, per_tok, s));
+  if (!dre) RC(launch_select_rows(tehs_c, tehs_n, prompt_mask, ehs.d + B * per_tok, B, per_tok, s));
+  else {
+    // select in place (every sample), then move the live rows to their compacted places behind the student rows
+    RC(launch_select_rows(tehs_c, tehs_n, prompt_mask, tehs_c, B, per_tok, s));
+    for (int j = 0; j < nt; ++j)
+      HIPCHK(hipMemcpyAsync(ehs.d + (B + j) * per_tok, tehs_c + idx[j] * per_tok, (size_t)per_tok * 2, hipMemcpyDeviceToDevice, s));
+  }
   // student rows: adapter on (cond | uncond), CFG-dropout select (:383-395); a shorter student context leaves the
   // sample's tail rows at their zero padding (masked by Tape::cross_kvlen)
   RC(A.forward(enc, enc_uncond, 0, s));
@@ -1828,8 +1902,19 @@ int Trainer::step_merged(const float* latents, const float* noise, const long lo
   if (M.t_text >= 0) {
     Tn& q = M.tn[M.t_text];
     HIPCHK(hipMemcpyAsync(q.d, A.pooled, (size_t)B * q.cols * 2, hipMemcpyDeviceToDevice, s));
-    RC(launch_cast_f32_bf16(teacher_pooled, q.d + (long long)B * q.cols, (long long)B * q.cols, s));
+    if (!dre) RC(launch_cast_f32_bf16(teacher_pooled, q.d + (long long)B * q.cols, (long long)B * q.cols, s));
+    else {
+      if (!tpool_c) HIPCHK(hipMalloc((void**)&tpool_c, (size_t)B * q.cols * 2));
+      RC(launch_cast_f32_bf16(teacher_pooled, tpool_c, (long long)B * q.cols, s));
+      for (int j = 0; j < nt; ++j)
+        HIPCHK(hipMemcpyAsync(q.d + (long long)(B + j) * q.cols, tpool_c + (long long)idx[j] * q.cols, (size_t)q.cols * 2,
+                              hipMemcpyDeviceToDevice, s));
+    }
     text = q.d;
+  }
+  if (dre) {
+    if (!tmap_d) HIPCHK(hipMalloc((void**)&tmap_d, sizeof(int) * 32));
+    HIPCHK(hipMemcpyAsync(tmap_d, tmap_h, sizeof(int) * B, hipMemcpyHostToDevice, s));
   }
   RC(M.forward(xt2, t2, ehs.d, 1, text, 1, tid2, eps2, s));
   KdLossP kp;
@@ -1839,7 +1924,7 @@ int Trainer::step_merged(const float* latents, const float* noise, const long lo
   M.begin_backward();
   for (int k = 0; k < kp.ntaps; ++k) {
     Tn& tp = M.tn[M.taps[k]];
-    const long long half = tp.rows / 2 * tp.cols;
+    const long long half = tp.rows / M.B * B * tp.cols;                      // the B student samples come first
     kp.fs[k] = tp.d; kp.ft[k] = tp.d + half; kp.dfs[k] = tp.g;
     kp.per[k] = tp.rows / M.B * tp.cols;
     tp.gw = true;
@@ -1847,6 +1932,7 @@ int Trainer::step_merged(const float* latents, const float* noise, const long lo
   kp.eps_s = eps2; kp.eps = noise; kp.eps_t = eps2 + B * per_img; kp.deps_s = deps; kp.per_eps = per_img; kp.zh = zh;
   kp.B = B; kp.feat_weight = feat_weight; kp.nan_guard = nan_guard; kp.grad_scale = grad_scale; kp.losses = losses;
   kp.partial = (float*)kd_ws;
+  kp.tmap = dre ? tmap_d : nullptr;
   RC(launch_kd_loss(kp, s));
   if (losses_out) HIPCHK(hipMemcpyAsync(losses_out, losses, 16, hipMemcpyDeviceToDevice, s));
   RC(M.backward(deps, s));

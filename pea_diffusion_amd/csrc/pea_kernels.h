@@ -181,6 +181,8 @@ struct KdLossP {
   const int* tap_finite_flags;     // unused (SD1.5 NaN guard handled through `nan_guard`)
   int nan_guard;
   float grad_scale;                // multiplies every seed (1/world for DP averaging, usually 1)
+  const int* tmap;                 // optional device int[B]: teacher sample index of student sample b inside ft[] / eps_t (compacted
+                                   // teacher rows, Trainer::live_teacher_mask); entries of samples with zh_or_not != 0 are not read
   int kd_samples_hint;             // profiling only: samples with zh_or_not == 0 (their taps are READ; the others' seeds are only
                                    // written as zeros) when the host knows it, else -1 = count every sample as read
 };

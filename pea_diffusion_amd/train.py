@@ -58,6 +58,11 @@ class PEATrainer:
         self._pending = None                               # torch.distributed work handle (gloo / torch-NCCL path)
         self._comm_inflight = False                        # an all-reduce launched on the native communicator, not joined yet
         self.local_only = False                            # True: steps skip the gradient all-reduce (bench.py: the single-GPU-equivalent step time of an N-rank run)
+        # Dead-row elimination (opt-in): with teacher == student checkpoint (merged passes) the teacher row of a sample whose
+        # zh_or_not is 1 only ever meets the weight (1 - zh_or_not) = 0 (train_sdxl_zh.py:402-441), so it is not computed: the
+        # merged pass runs over B + n_t samples.  Same losses and gradients; needs zh_or_not on the host (a CPU tensor from the
+        # dataloader costs nothing; a device tensor costs one small synchronising copy per step).
+        self.skip_dead_teacher_rows = False
 
     def __del__(self):
         try:
@@ -91,6 +96,11 @@ class PEATrainer:
         tp = dev(batch["teacher_pooled"], f32) if "teacher_pooled" in batch else None
         tid = dev(batch["time_ids"], f32) if "time_ids" in batch else None
         world = self.world_size
+        if self.skip_dead_teacher_rows and self.student.B <= 30:
+            live = (batch["zh_or_not"].detach().reshape(-1).cpu() == 0).tolist()
+            check(lib().pea_trainer_set_option(self._h, b"live_teacher_mask", sum(1 << i for i, v in enumerate(live) if v)))
+        elif lib().pea_trainer_get_option(self._h, b"live_teacher_mask") != -1:
+            check(lib().pea_trainer_set_option(self._h, b"live_teacher_mask", -1))
         check(lib().pea_train_step(self._h, ptr(b["latents"]), ptr(b["noise"]), ptr(ts), ptr(b["enc"]),
                                    ptr(b["enc_uncond"]), ptr(pm), ptr(zh), ptr(b["teacher_ehs"]), ptr(b["teacher_neg"]),
                                    ptr(tp), ptr(tid), 1.0, ptr(self.adapter.flat_grad), 0, ptr(self.losses),

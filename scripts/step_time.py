@@ -1,7 +1,7 @@
 """median step time of the bench workload (no CPU baseline, no roofline replay) -- for A/B runs through scripts/lib_multi.py"""
 import json, os, subprocess, sys
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--no-cpu-baseline", "--no-roofline", "--steps", "16", "--warmup", "3"] + sys.argv[1:],
+r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--no-cpu-baseline", "--no-roofline", "--steps", "16", "--warmup", "3", "--no-dead-row-line"] + sys.argv[1:],
                    capture_output=True, text=True)
 d = json.loads(r.stdout.strip().splitlines()[-1])
 g = d.get("gpu") or {}
