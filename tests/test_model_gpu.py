@@ -649,12 +649,13 @@ def test_step_matches_reference_golden(gpu, golden_dir, tag):
             continue
         e = rel_l2(got, want)
         worst = max(worst, e)
-        assert e < 4e-2, (n, e)
+        # (shared checkpoint: the KD gradient is a difference of nearly equal bf16 tensors; measured 3.0e-2 worst / 2.6e-2 flat)
+        assert e < (6e-2 if shared else 4e-2), (n, e)
     g_ref = torch.cat([T(g["g." + [nm for nm, q in ad.named_parameters() if q is p][0]]).reshape(-1) for p in ad._plist()])
     e_all = rel_l2(flat, g_ref)
     print(f"[{tag}] eps rel_l2 student {e_s:.2e} teacher {e_t:.2e}; loss hip={float(out['loss']):.6f} ref={float(g['loss']):.6f}; "
           f"adapter grad rel_l2 flat {e_all:.2e}, worst parameter {worst:.2e}")
-    assert e_all < 3e-2
+    assert e_all < (5e-2 if shared else 3e-2)
 
 
 def _fast_fill_(module, seed=0):
