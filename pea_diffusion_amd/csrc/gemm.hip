@@ -1676,7 +1676,6 @@ extern "C" void pea_debug_set_gemm_variant(int v) { g_gemm_variant = v; }
     case 33: rc = launch_lcp<MODE, 256, 128, 4, 2, 4, 3, 0, 0, 1>(p, stream); break; \
     case 34: rc = launch_lcp<MODE, 128, 160, 4, 2, 4, 3, 4>(p, stream); break; /* staged epilogue */ \
     case 35: rc = launch_lcp<MODE, 128, 160, 4, 2, 4, 3, 0, 1>(p, stream); break; /* deferred epilogue */ \
-    case 38: rc = launch_lcp<MODE, 256, 160, 4, 2, 2, 3, 0, 0, 1>(p, stream); break; /* 27 with TWO loader waves (experiment) */ \
     case 36: rc = launch_lcp<MODE, 128, 160, 2, 2, 2, 2, 0, 0, 1, 2>(p, stream); break; /* two workgroups per CU */ \
     case 37: rc = launch_lcp<MODE, 128, 128, 2, 2, 2, 2, 0, 0, 1, 2>(p, stream); break; \
     default: rc = launch_lc<MODE, 128, 128, 2, 2, 4, 4, false, true>(p, stream); break; \

@@ -17,7 +17,7 @@ NAMES = {0: "128x128 w2x2 S2", 1: "128x128 w2x2 S3", 2: "128x128 w2x2 S4", 3: "2
          22: "LC16 128x160 2x2 S4", 23: "LC16 128x128 2x2 S4", 24: "LC16 256x160 c8(4x2)+l4 S3", 25: "LC16 128x160 c8(4x2)+l4 S3", 26: "LC16 128x160 c8(4x2)+l4 S4",
          27: "persistent LC16 256x160 c8(4x2)+l4 S3", 28: "persistent LC16 128x160 c8(4x2)+l4 S3", 29: "persistent LC16 128x160 c4(2x2)+l4 S4",
          30: "persistent LC16 128x128 c4(2x2)+l4 S4", 31: "persistent LC16 64x160 c4(2x2)+l4 S4", 33: "persistent LC16 256x128 c8(4x2)+l4 S3", 34: "persistent LC16 128x160 c8+l4+store4 S3, staged epilogue", 35: "persistent LC16 128x160 c8+l4 S3, deferred epilogue",
-         36: "persistent LC16 128x160 c4(2x2)+l2 S2, TWO workgroups per CU", 38: "persistent LC16 256x160 c8(4x2)+l2 S3", 37: "persistent LC16 128x128 c4(2x2)+l2 S2, two workgroups per CU"}
+         36: "persistent LC16 128x160 c4(2x2)+l2 S2, TWO workgroups per CU", 37: "persistent LC16 128x128 c4(2x2)+l2 S2, two workgroups per CU"}
 
 def timeit(fn, iters=20):
     fn(); torch.cuda.synchronize()
