@@ -111,3 +111,28 @@ def test_dead_rows_sdxl_1024_bench_workload(gpu):
     e = rel_l2(ad.flat_grad, g_full)
     print(f"[dead rows, SDXL 1024 B=4] merged rows 8 -> 6; adapter gradient vs the full pass rel_l2={e:.2e}; loss {out['loss']:.6f}")
     assert e < 1e-4
+
+
+def test_dead_rows_behind_the_bucketed_trainer(gpu):
+    """dead-row elimination through BucketedTrainer: every latent shape has its own trainer context (and its own B + n_t
+    contexts behind it); releasing a context (memory cap 0) frees the borrowed arenas' donor and the borrowers together"""
+    from oracle.step_ref import synthetic_batch
+    from pea_diffusion_amd.train import BucketedTrainer
+    from test_buckets_gpu import _tiny_models
+    B, L = 2, 52
+    shapes = [(16, 16), (24, 8)]
+    cfg, us, ut, ad_ref, ad, hs, ht = _tiny_models(B, L, shapes[0])
+    tr = BucketedTrainer(ad, hs, ht)
+    for cap in (1 << 40, 0):
+        tr.max_resident_bytes = cap
+        for hw in shapes + shapes[::-1]:
+            batch = dict(synthetic_batch(cfg, B, L=L, enc_dim=128, seed=7, latent_hw=hw), zh_or_not=torch.tensor([1, 0]))
+            tr.skip_dead_teacher_rows = False
+            full = {k: float(v) for k, v in tr.training_step(batch, 0, sync=True).items()}
+            g_full = ad.flat_grad.clone()
+            tr.skip_dead_teacher_rows = True
+            out = {k: float(v) for k, v in tr.training_step(batch, 0, sync=True).items()}
+            assert _rows(tr) == B + 1, (hw, _rows(tr))
+            for k in tr.LOG_KEYS:
+                assert abs(out[k] - full[k]) <= 1e-6 * max(1.0, abs(full[k])), (hw, cap, k)
+            assert rel_l2(ad.flat_grad, g_full) < 1e-4, (hw, cap)
