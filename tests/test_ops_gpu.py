@@ -63,6 +63,17 @@ def test_gemm_plain(ops, M, N, K):
     close_bf16(f"gemm {M}x{N}x{K}", out, a.float() @ w.float().T)
 
 
+@pytest.mark.parametrize("M,N,K", [(6144, 1280, 1280), (6144, 3840, 640), (3072, 2560, 320), (6100, 1280, 640)])
+def test_gemm_192_row_tiles_by_rule(ops, M, N, K):
+    """row counts that leave 128- and 256-row tiles a partial last round (6144 = a merged pass with dead teacher rows, batch 3 / 6):
+    the launcher takes the 192-row tile (one-tile and persistent forms); plain, bias + residual, and a ragged M"""
+    a, w = bfr(M, K, seed=1), bfr(N, K, seed=2, scale=K ** -0.5)
+    bias, res = torch.randn(N), bfr(M, N, seed=3)
+    ref = a.float() @ w.float().T
+    close_bf16(f"gemm192 {M}x{N}x{K}", ops.gemm(a.cuda(), w.cuda()), ref)
+    close_bf16(f"gemm192 bias+res {M}x{N}x{K}", ops.gemm(a.cuda(), w.cuda(), bias=bias.cuda(), res=res.cuda()), ref + bias + res.float())
+
+
 @pytest.mark.parametrize("M,N,K,shift", [(8192, 3840, 1280, 0.0), (4096, 1280, 1280, 4.0), (1000, 640, 320, -2.5),
                                           (77, 160, 64, 1.0)])
 def test_ln_linear_folded(ops, M, N, K, shift):
@@ -109,7 +120,7 @@ def test_gemm_epilogues(ops):
     close_bf16("gemm bf16 accumulate", gbuf, a.float() @ w.float().T + res.float())
 
 
-@pytest.mark.parametrize("variant", [18, 19, 22, 23, 24, 25, 27, 28, 29, 30, 31, 33, 34, 35])
+@pytest.mark.parametrize("variant", [18, 19, 22, 23, 24, 25, 27, 28, 29, 30, 31, 33, 34, 35, 39, 40])
 def test_gemm_every_variant_ragged_shapes(ops, variant):
     """Every kernel form the launcher can pick (or that an experiment switch selects), forced on shapes that do not fit its
     tiles: ragged M, N that ends inside a tile / inside a 32-column store pair, fewer and more tiles than CUs (the
