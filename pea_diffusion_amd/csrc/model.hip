@@ -870,6 +870,10 @@ int Tape::ensure_acts() {
     if (o.kind == OP_ATTN) {
       delta_elems = std::max(delta_elems, (size_t)B * o.p0 * o.p1);
       part_bytes = std::max(part_bytes, attention_bwd_scratch_bytes(B, o.p0, o.p1, o.p2, o.p3));
+      // the backward runs on the leading bwd_batch samples, and a SMALLER batch can choose MORE dK / dV splits (fewer heads per
+      // round): size for that launch too (a 12-sample merged pass differentiating 8 needs 8 splits x 160 heads = 50 MB where the
+      // 12-sample count gives 4 x 240 = 38 MB -- a memory fault in round 4's dead-row contexts at batch 8)
+      if (bwd_batch > 0) part_bytes = std::max(part_bytes, attention_bwd_scratch_bytes(bwd_batch, o.p0, o.p1, o.p2, o.p3));
     }
     if (o.kind == OP_ATTN_MAT && !am_scores) {
       const size_t HW = (size_t)tn[o.a].H * tn[o.a].W;

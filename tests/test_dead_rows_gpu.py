@@ -136,3 +136,39 @@ def test_dead_rows_behind_the_bucketed_trainer(gpu):
             for k in tr.LOG_KEYS:
                 assert abs(out[k] - full[k]) <= 1e-6 * max(1.0, abs(full[k])), (hw, cap, k)
             assert rel_l2(ad.flat_grad, g_full) < 1e-4, (hw, cap)
+
+
+def test_dead_rows_sdxl_1024_batch8(gpu):
+    """per-GPU batch 8 (BASELINE configs[2] per rank) with half of the teacher rows dead: 16 -> 12 merged rows.  (Round 4: the
+    12-sample context's attention-backward scratch was sized for 12 samples' split count while the backward of its 8 student
+    samples chooses more splits -- a memory fault; Tape::ensure_acts now sizes for both.)"""
+    from pea_diffusion_amd import config as pc
+    from pea_diffusion_amd.adapter import PEAAdapter
+    from pea_diffusion_amd.train import PEATrainer
+    from pea_diffusion_amd.unet import HipUNet
+    import bench
+    cfg, hw, L, B = pc.sdxl_config(), 128, 77, 8
+    student = HipUNet(cfg, B, hw, hw, L, needs_grad=True)
+    student.init_random(3)
+    teacher = HipUNet(cfg, B, hw, hw, L, share_weights_from=student)
+    torch.manual_seed(0)
+    ad = PEAAdapter(1024, 1280, 1024, 2048, False).cuda()
+    tr = PEATrainer(ad, student, teacher)
+    batch = bench.synthetic_batch(cfg, B, L, 1024, hw, torch.device("cuda"), seed=100)
+    full = {k: float(v) for k, v in tr.training_step(batch, 0, sync=True).items()}
+    g_full, eps_s = ad.flat_grad.clone(), tr.export("eps_student")
+    tr.skip_dead_teacher_rows = True
+    for zh in ([1, 1, 1, 1, 0, 0, 0, 0], [0, 1, 1, 1, 1, 1, 1, 1]):
+        b2 = dict(batch, zh_or_not=torch.tensor(zh))
+        tr.skip_dead_teacher_rows = False
+        full = {k: float(v) for k, v in tr.training_step(b2, 0, sync=True).items()}
+        g_full, eps_s = ad.flat_grad.clone(), tr.export("eps_student")
+        tr.skip_dead_teacher_rows = True
+        out = {k: float(v) for k, v in tr.training_step(b2, 0, sync=True).items()}
+        assert _rows(tr) == B + zh.count(0)
+        assert torch.equal(tr.export("eps_student"), eps_s)
+        for k in tr.LOG_KEYS:
+            assert abs(out[k] - full[k]) <= 1e-6 * max(1.0, abs(full[k])), (zh, k)
+        assert rel_l2(ad.flat_grad, g_full) < 1e-4, zh
+    del tr, student, teacher
+    torch.cuda.empty_cache()
