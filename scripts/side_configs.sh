@@ -5,7 +5,7 @@
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/side
 mkdir -p $O
-cd $R
+cd $R; ulimit -c 0
 python3 bench.py --no-cpu-baseline --no-roofline > $O/bench_default.json 2>/dev/null
 python3 bench.py --no-cpu-baseline --no-roofline --batch 8 > $O/bench_b8.json 2>/dev/null
 python3 bench.py --no-cpu-baseline --no-roofline --student ssd1b > $O/bench_ssd1b.json 2>/dev/null
