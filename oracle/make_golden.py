@@ -122,13 +122,25 @@ def gen_mlp(ref_sdxl, ref_sd, ref_test):
         m = ctor(*args)
         nparam = sum(p.numel() for p in m.parameters())
         x = torch.randn(2, L, args[0])
-        with torch.no_grad():
-            out = m(x)
+        out = m(x)                                  # (the same forward as before; gradients recorded since round 4)
         outs = out if isinstance(out, tuple) else (out,)
         d = {"args": np.array([int(a) for a in args]), "seed": 77, "L": L, "nparam": nparam,
              "wsum": checksum(m.state_dict()), "x": x}
         for i, o in enumerate(outs):
-            d[f"out{i}"] = o
+            d[f"out{i}"] = o.detach()
+        # parameter gradients of the reference MLP for seeded output gradients: norm of every gradient + a strided sample
+        # (the full 6-13 M-element gradients are not stored)
+        gg = torch.Generator().manual_seed(78)
+        gouts = [torch.randn(o.shape, generator=gg) for o in outs]
+        torch.autograd.backward(outs, gouts)
+        for i, go in enumerate(gouts):
+            d[f"gout{i}"] = go
+        for k, p_ in m.named_parameters():
+            flat = p_.grad.reshape(-1)
+            stride = max(1, flat.numel() // 4096)
+            d["gnorm." + k] = float(flat.double().norm())
+            d["gsample." + k] = flat[::stride].clone()
+            d["gstride." + k] = stride
         d["keys"] = np.array(list(m.state_dict().keys()))
         cases[tag] = np_(d)
     for tag, d in cases.items():

@@ -173,13 +173,25 @@ def test_adapter_module_matches_reference_golden(gpu, golden_dir):
         assert abs(wsum - float(g["wsum"])) < 1e-6 * float(g["wsum"])
         assert list(m.state_dict().keys()) == [str(k) for k in g["keys"]]
         m = m.cuda()
-        with torch.no_grad():
-            out = m(torch.from_numpy(g["x"]).cuda())
+        out = m(torch.from_numpy(g["x"]).cuda())
         outs = out if isinstance(out, tuple) else (out,)
         for i, o in enumerate(outs):
             e = rel_l2(o, torch.from_numpy(g[f"out{i}"]))
             print(f"[adapter golden {tag}] out{i} rel_l2={e:.3e}")
             assert e < 1e-2
+        # backward (round 4): the reference MLP's parameter gradients for the fixture's seeded output gradients -- norm and
+        # a strided sample of every gradient -- against pea_adapter_backward (dgrad + wgrad in HIP, bf16 operands)
+        torch.autograd.backward(outs, [torch.from_numpy(g[f"gout{i}"]).cuda() for i in range(len(outs))])
+        worst = 0.0
+        for k, p_ in m.named_parameters():
+            flat = p_.grad.reshape(-1).float().cpu()
+            want = torch.from_numpy(g["gsample." + k])
+            got = flat[::int(g["gstride." + k])]
+            e = rel_l2(got, want)
+            en = abs(float(flat.double().norm()) - float(g["gnorm." + k])) / float(g["gnorm." + k])
+            worst = max(worst, e)
+            assert e < 2e-2 and en < 1e-2, (tag, k, e, en)
+        print(f"[adapter golden {tag}] parameter gradients vs the reference MLP: worst sample rel_l2={worst:.3e}")
 
 
 def test_adapter_half_surface(gpu):

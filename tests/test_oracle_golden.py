@@ -49,11 +49,16 @@ def test_adapter_full_size(golden_dir, tag):
     assert sum(p.numel() for p in m.parameters()) == int(g["nparam"])
     assert list(m.state_dict().keys()) == [str(k) for k in g["keys"]]
     assert abs(_wsum(m.state_dict()) - float(g["wsum"])) < 1e-6 * float(g["wsum"]), "seeded weights drifted"
-    with torch.no_grad():
-        out = m(T(g["x"]))
+    out = m(T(g["x"]))
     outs = out if isinstance(out, tuple) else (out,)
     for i, o in enumerate(outs):
-        torch.testing.assert_close(o, T(g[f"out{i}"]), rtol=1e-5, atol=1e-6)
+        torch.testing.assert_close(o.detach(), T(g[f"out{i}"]), rtol=1e-5, atol=1e-6)
+    # parameter gradients for the fixture's seeded output gradients: norm + strided sample of every gradient
+    torch.autograd.backward(outs, [T(g[f"gout{i}"]) for i in range(len(outs))])
+    for k, p_ in m.named_parameters():
+        flat = p_.grad.reshape(-1)
+        assert abs(float(flat.double().norm()) - float(g["gnorm." + k])) <= 1e-4 * float(g["gnorm." + k]), k
+        torch.testing.assert_close(flat[::int(g["gstride." + k])], T(g["gsample." + k]), rtol=2e-4, atol=1e-5 * float(g["gnorm." + k]))
 
 
 def test_adapter_param_counts():
