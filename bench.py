@@ -770,6 +770,9 @@ def main():
     solo_ms = None
     if world > 1 or args.force_collective:                  # (--force-collective: the same code path with one rank)
         barrier()
+        # the local-only steps update each replica from its own shard: parameters AND both AdamW moments (and the step counter)
+        # are put back afterwards, so every rank leaves this block in the replicated state it entered with
+        snap = (adapter.flat_param.clone(), trainer._m.clone(), trainer._v.clone(), trainer.global_step)
         trainer.local_only = True
         evs = []
         for _ in range(7):
@@ -778,11 +781,12 @@ def main():
         ts = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(1, len(evs) - 1))
         solo_ms = ts[len(ts) // 2]
         trainer.local_only = False
-        if comm is not None:
-            comm.broadcast_(adapter.flat_param, 0)            # the replicas diverged during the local-only steps
-        elif use_dist:
-            from pea_diffusion_amd import dist as pdist2
-            pdist2.broadcast_params_(adapter.flat_param, src=0)
+        with torch.no_grad():
+            adapter.flat_param.copy_(snap[0])
+            trainer._m.copy_(snap[1])
+            trainer._v.copy_(snap[2])
+        trainer.global_step = snap[3]
+        del snap
         adapter.mark_updated()
         barrier()
 
@@ -821,9 +825,12 @@ def main():
             dre = {"error": f"{type(e).__name__}: {e}"[:300]}
         finally:
             trainer.skip_dead_teacher_rows = False
-            trainer.training_step(batch, async_allreduce=True)    # back on the full 2B-row context before the instrumented replay
-            trainer.optimizer_step()
-            torch.cuda.synchronize()
+            try:                                                  # back on the full 2B-row context before the instrumented replay
+                trainer.training_step(batch, async_allreduce=True)
+                trainer.optimizer_step()
+                torch.cuda.synchronize()
+            except Exception as e:                                # a device error in the supplementary block must not cost the headline line
+                dre = dict(dre or {}, restore_error=f"{type(e).__name__}: {e}"[:300])
 
     roof, cpu = after_timing(args, rank, world, step, instrument, barrier)
 

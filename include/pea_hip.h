@@ -228,6 +228,11 @@ int pea_unet_create(const pea_unet_config* cfg, int B, int H, int W, int L, int 
  * / gradient arenas will take in HBM.  Use it to size a configuration against 288 GB before creating it.   */
 int pea_unet_plan(const pea_unet_config* cfg, int B, int H, int W, int L, int flags, int* n_ops, int* n_weights,
                   long long* n_params, long long* weight_bytes, long long* act_bytes, long long* grad_bytes);
+/* ... and the scratch buffers the same context allocates beside those arenas on first use (GroupNorm partials, attention
+ * row constants and dK/dV split partials, the FF d(pre-activation) buffer, split-K partials of the stacked K|V projection,
+ * fp32 time-embedding gradients).  bwd_batch > 0: a merged-pass context that differentiates its leading bwd_batch samples. */
+int pea_unet_plan_scratch(const pea_unet_config* cfg, int B, int H, int W, int L, int flags, int bwd_batch,
+                          long long* scratch_bytes);
 /* Attention ops on a graph (any handle of this library that owns an op tape: UNet, ControlNet, VAE, text encoder) and how
  * many of them are fed a Q the producing projection already multiplied by softmax_scale * log2(e) (the accurate path: one
  * rounding, from the fp32 accumulator).  An op outside that count runs the operator-level plain-Q path, which rounds the
@@ -377,7 +382,12 @@ int pea_train_step(void* tr, const float* latents, const float* noise, const lon
 /* options: "two_stream" (1 = teacher forward on a side HIP stream, default), "nan_guard", "merge_passes" (default 1:
  * when the teacher context shares the student's weights -- the reference default, train_sdxl_zh.py:138,151 -- and the
  * context lengths agree, both UNet forwards run as ONE pass over 2B samples and the backward differentiates the
- * first B; otherwise the two-stream path is used) */
+ * first B; otherwise the two-stream path is used);
+ * "live_teacher_mask" (dead-row elimination, opt-in, merged passes at B <= 30): bit i set = sample i's teacher row is
+ * computed, -1 = all (default).  CONTRACT: bit i may only be cleared for a sample whose zh_or_not[i] != 0 (its KD weight
+ * 1 - zh_or_not is zero, train_sdxl_zh.py:402-441).  The mask is host state and zh_or_not is device memory, so the library
+ * cannot compare them before the step; a sample that carries KD weight without a teacher row makes the loss kernel emit
+ * NaN for the losses and for that sample's gradient seeds (never another sample's row). */
 int pea_trainer_set_option(void* tr, const char* name, int value);
 int pea_trainer_get_option(void* trainer, const char* name);   /* also "merge_state": 0 undecided, 1 merged, -1 n/a; "kd_samples_hint" (set: profiling only -- samples with zh_or_not == 0, for the KD-loss kernel's byte count) */
 /* pea_unet_release_activations on the trainer's student, teacher and merged-pass contexts.  The reference trains over

@@ -72,6 +72,26 @@ int pea_unet_plan(const pea_unet_config* cfg, int B, int H, int W, int L, int fl
   if (grad_bytes) *grad_bytes = (long long)u.gbytes;
   return PEA_OK;
 }
+/* scratch buffers the same context allocates beside its arenas on first use (host only).  bwd_batch > 0: a merged-pass context
+ * that differentiates only its leading bwd_batch samples (Tape::bwd_batch) */
+int pea_unet_plan_scratch(const pea_unet_config* cfg, int B, int H, int W, int L, int flags, int bwd_batch, long long* scratch_bytes) {
+  NOTNULL(cfg, "pea_unet_plan_scratch");
+  NOTNULL(scratch_bytes, "pea_unet_plan_scratch");
+  Tape u;
+  memcpy(&u.cfg, cfg, sizeof(PeaUnetCfg));
+  u.B = B; u.H = H; u.W = W; u.L = L; u.needs_grad = (flags & 1) != 0; u.residual_inputs = (flags & 2) != 0;
+  u.bwd_batch = bwd_batch;
+  u.plan_only = true;
+  int rc = u.build();
+  if (rc == PEA_OK) rc = u.alloc();
+  if (rc != PEA_OK) return rc;
+  size_t need[8];
+  u.scratch_needs(need);
+  long long t = 0;
+  for (int i = 0; i < 8; ++i) t += (long long)need[i];
+  *scratch_bytes = t;
+  return PEA_OK;
+}
 /* attention ops of a graph and how many of them receive a Q already multiplied by scale * log2(e) by the producing
  * projection's epilogue (Tape::tag_q_prescale); every graph the product builds is expected to have the two equal */
 int pea_tape_attention_census(void* h, int* n_attn, int* n_prescaled) {
@@ -600,7 +620,13 @@ int pea_trainer_get_option(void* h, const char* name) {
   if (!strcmp(name, "live_teacher_mask")) return t->live_teacher_mask;
   if (!strcmp(name, "merged_rows")) return t->last_ctx ? t->last_ctx->B : (t->merged ? t->merged->B : 0);   /* samples in the last merged pass */
   if (!strcmp(name, "merged_mib"))                                /* activations + gradients of the merged-pass context */
-    return t->merged && t->merged->aarena ? (int)((t->merged->abytes + t->merged->gbytes) >> 20) : 0;
+  {
+    if (!t->merged || !t->merged->aarena) return 0;
+    size_t by = t->merged->abytes + t->merged->gbytes + t->merged->scratch_own_bytes();
+    for (auto& kv : t->merged_n)                                  /* dead-row contexts: arenas and most scratch are borrowed */
+      if (kv.second->aarena) by += kv.second->scratch_own_bytes();
+    return (int)(by >> 20);
+  }
   return PEA_E_INVALID;
 }
 int pea_trainer_export(void* h, int which, float* out, void* stream) {
@@ -616,7 +642,7 @@ int pea_trainer_export(void* h, int which, float* out, void* stream) {
     const size_t per = n / B;
     HIPCHK(hipMemsetAsync(out, 0xff, n * 4, (hipStream_t)stream));
     for (int i = 0; i < B; ++i)
-      if (t->tmap_h[i] >= 0)
+      if (i < (int)t->tmap_h.size() && t->tmap_h[i] >= 0)
         HIPCHK(hipMemcpyAsync(out + i * per, src + (size_t)t->tmap_h[i] * per, per * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));
     return PEA_OK;
   }

@@ -46,8 +46,12 @@ __global__ __launch_bounds__(256) void kd_loss_kernel(const KdLossP p, const KdS
       const int b = (int)(c / per8);
       const bool on = p.zh[b] == 0;          // weight (1 - zh_or_not)
       bf16x8 g;
-      if (on) {
-        const long long ct = p.tmap ? (long long)p.tmap[b] * per8 + (c - (long long)b * per8) : c;
+      // a sample that carries KD weight but whose teacher row was not computed (tmap[b] < 0: the caller's live_teacher_mask
+      // contradicts zh_or_not) has no teacher to compare with: its terms come out as NaN -- loss, seeds and with them the
+      // adapter gradient -- instead of silently reading another sample's row
+      const int trow = (on && p.tmap) ? p.tmap[b] : 0;
+      if (on && trow >= 0) {
+        const long long ct = p.tmap ? (long long)trow * per8 + (c - (long long)b * per8) : c;
         const bf16x8 a = *(const bf16x8*)(fs + c * 8);
         const bf16x8 t = *(const bf16x8*)(ft + ct * 8);
 #pragma unroll
@@ -56,6 +60,10 @@ __global__ __launch_bounds__(256) void kd_loss_kernel(const KdLossP p, const KdS
           acc += d * d;
           g[j] = (bf16)(d * gsc);
         }
+      } else if (on) {
+        acc = __builtin_nanf("");
+#pragma unroll
+        for (int j = 0; j < 8; ++j) g[j] = (bf16)__builtin_nanf("");
       } else {
 #pragma unroll
         for (int j = 0; j < 8; ++j) g[j] = (bf16)0.f;
@@ -71,13 +79,14 @@ __global__ __launch_bounds__(256) void kd_loss_kernel(const KdLossP p, const KdS
       const int b = (int)(c / per4);
       const bool zh = p.zh[b] != 0;
       const f32x4 es = *(const f32x4*)(p.eps_s + c * 4);
-      const long long ct = (!zh && p.tmap) ? (long long)p.tmap[b] * per4 + (c - (long long)b * per4) : c;
+      const int trow = (!zh && p.tmap) ? p.tmap[b] : 0;
+      const long long ct = (!zh && p.tmap && trow >= 0) ? (long long)trow * per4 + (c - (long long)b * per4) : c;
       const f32x4 other = zh ? *(const f32x4*)(p.eps + c * 4) : *(const f32x4*)(p.eps_t + ct * 4);
       f32x4 g;
       float acc = 0.f;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const float d = es[j] - other[j];
+        const float d = trow >= 0 ? es[j] - other[j] : __builtin_nanf("");     // (no teacher row for a sample with KD weight: see above)
         acc += d * d;
         g[j] = d * gsc;
       }

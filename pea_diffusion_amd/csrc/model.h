@@ -192,6 +192,13 @@ struct Tape {
   int exec_ops(size_t begin, size_t end, bool skip_cached, hipStream_t s);
   Tape* arena_donor = nullptr;       // activation / gradient arenas borrowed from this (larger) tape: the two are never live at once
   bool arena_borrowed = false;
+  // bytes of each scratch buffer (ensure_acts) and which of them are the donor's (bit order: gn, cs, delta, ups, geglu, attn_part,
+  // kv_part, tproj_grad): a borrower takes the donor's buffer when it is large enough
+  size_t sc_gn = 0, sc_cs = 0, sc_delta = 0, sc_ups = 0, sc_geglu = 0, sc_part = 0, sc_kv = 0, sc_tproj = 0;
+  unsigned scratch_borrowed = 0;
+  void drop_borrowed_scratch();
+  void scratch_needs(size_t need[8]);
+  size_t scratch_own_bytes() const;  // scratch this context allocated itself (not borrowed)
   int n_attn = 0, n_attn_pre = 0;    // attention ops on the tape / of those, fed a prescaled Q (tag_q_prescale)
   void tag_q_prescale();
   int ensure_acts();                 // lazy allocation of the activation / gradient arenas and scratch
@@ -256,7 +263,7 @@ struct Trainer {
   std::map<int, Tape*> merged_n;        // contexts for B + n_t rows, n_t < B: built on first use, arenas borrowed from `merged`
   Tape* last_ctx = nullptr;
   int* tmap_d = nullptr;                // device int[B]: teacher row of sample b (relative to the first teacher row) or -1
-  int tmap_h[32];                       // host copy of the last step's map (export)
+  std::vector<int> tmap_h;              // host copy of the last step's map, one entry per sample (export)
   bf16* tpool_c = nullptr;              // [B][pooled] bf16: teacher pooled embeds of all samples, before compaction
   int context_for(int nt, Tape** out);
   float *xt2 = nullptr, *eps2 = nullptr, *t2 = nullptr, *tid2 = nullptr;

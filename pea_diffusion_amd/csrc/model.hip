@@ -840,6 +840,52 @@ int Tape::alloc() {
   return PEA_OK;
 }
 
+// Bytes of every scratch buffer of this graph (host only; order: GroupNorm partials, per-sample column sums, attention row
+// constants, upsample-conv gradient, FF d(pre-activation), attention dK/dV split partials, stacked K|V split-K partials,
+// fp32 time_emb_proj gradient).  Also sets kv_nsplit.
+void Tape::scratch_needs(size_t need[8]) {
+  size_t delta_elems = 0, ups_elems = 0, part_bytes = 0, geglu_elems = 0;
+  for (Op& o : ops) {
+    if (o.kind == OP_ATTN) {
+      delta_elems = std::max(delta_elems, (size_t)B * o.p0 * o.p1);
+      part_bytes = std::max(part_bytes, attention_bwd_scratch_bytes(B, o.p0, o.p1, o.p2, o.p3));
+      // the backward runs on the leading bwd_batch samples, and a SMALLER batch can choose MORE dK / dV splits (fewer heads per
+      // round): size for that launch too (a 12-sample merged pass differentiating 8 needs 8 splits x 160 heads = 50 MB where the
+      // 12-sample count gives 4 x 240 = 38 MB -- a memory fault in round 4's dead-row contexts at batch 8)
+      if (bwd_batch > 0) part_bytes = std::max(part_bytes, attention_bwd_scratch_bytes(bwd_batch, o.p0, o.p1, o.p2, o.p3));
+    }
+    if (o.kind == OP_LINEAR && o.p3 == 3 && o.c >= 0) geglu_elems = std::max(geglu_elems, (size_t)tn[o.c].rows * tn[o.c].cols);
+    if (o.kind == OP_CONV3 && o.p1 && tn[o.a].rg)
+      ups_elems = std::max(ups_elems, (size_t)tn[o.out].rows * tn[o.a].cols);
+  }
+  size_t gn_bytes = 256, cs_bytes = 256;
+  for (Op& o : ops) {
+    if (o.kind == OP_GN) gn_bytes = std::max(gn_bytes, groupnorm_scratch_bytes(tn[o.a].B, tn[o.a].H * tn[o.a].W, tn[o.a].cols, cfg.groups));
+    if (o.kind == OP_CONV3 && o.rv >= 0) cs_bytes = std::max(cs_bytes, colsum_batched_scratch_bytes(tn[o.out].B, tn[o.out].H * tn[o.out].W, tn[o.out].cols));
+  }
+  for (int i = 0; i < 8; ++i) need[i] = 0;
+  need[0] = gn_bytes;
+  if (!needs_grad) return;
+  need[1] = cs_bytes;
+  need[2] = delta_elems * 4 * 2;               // two row constants per (b, h, q): -delta, -lse*log2e
+  need[3] = ups_elems * 2;
+  need[4] = geglu_elems * 2;
+  need[5] = part_bytes;
+  if (t_ehs >= 0 && kvall_total > 0) {
+    const int ksteps = kvall_total / 64;
+    kv_nsplit = std::max(1, std::min(32, ksteps / 128));
+    need[6] = sizeof(float) * kv_nsplit * (size_t)tn[t_ehs].rows * tn[t_ehs].cols;
+  }
+  need[7] = sizeof(float) * (size_t)B * tproj_total;
+}
+size_t Tape::scratch_own_bytes() const {
+  const size_t sz[8] = {sc_gn, sc_cs, sc_delta, sc_ups, sc_geglu, sc_part, sc_kv, sc_tproj};
+  size_t t = 0;
+  for (int i = 0; i < 8; ++i)
+    if (!(scratch_borrowed & (1u << i))) t += sz[i];
+  return t;
+}
+
 // Activation / gradient arenas and scratch are allocated on first use, not at creation: a trainer that runs merged
 // passes never touches the activations of the student and teacher contexts it was given (they only carry the weights),
 // which is half of the resident HBM at the benchmark size.
@@ -865,44 +911,35 @@ int Tape::ensure_acts() {
   for (Tn& t : tn)
     if (t.zero_init) HIPCHK(hipMemset(t.d, 0, (size_t)t.rows * t.cols * 2));
   // ---- scratch
-  size_t delta_elems = 0, ups_elems = 0, part_bytes = 0, geglu_elems = 0;
-  for (Op& o : ops) {
-    if (o.kind == OP_ATTN) {
-      delta_elems = std::max(delta_elems, (size_t)B * o.p0 * o.p1);
-      part_bytes = std::max(part_bytes, attention_bwd_scratch_bytes(B, o.p0, o.p1, o.p2, o.p3));
-      // the backward runs on the leading bwd_batch samples, and a SMALLER batch can choose MORE dK / dV splits (fewer heads per
-      // round): size for that launch too (a 12-sample merged pass differentiating 8 needs 8 splits x 160 heads = 50 MB where the
-      // 12-sample count gives 4 x 240 = 38 MB -- a memory fault in round 4's dead-row contexts at batch 8)
-      if (bwd_batch > 0) part_bytes = std::max(part_bytes, attention_bwd_scratch_bytes(bwd_batch, o.p0, o.p1, o.p2, o.p3));
-    }
+  for (Op& o : ops)
     if (o.kind == OP_ATTN_MAT && !am_scores) {
       const size_t HW = (size_t)tn[o.a].H * tn[o.a].W;
       HIPCHK(hipMalloc((void**)&am_scores, HW * HW * 2));
       HIPCHK(hipMalloc((void**)&am_vt, HW * tn[o.a].cols * 2));
     }
-    if (o.kind == OP_LINEAR && o.p3 == 3 && o.c >= 0) geglu_elems = std::max(geglu_elems, (size_t)tn[o.c].rows * tn[o.c].cols);
-    if (o.kind == OP_CONV3 && o.p1 && tn[o.a].rg)
-      ups_elems = std::max(ups_elems, (size_t)tn[o.out].rows * tn[o.a].cols);
-  }
-  size_t gn_bytes = 256, cs_bytes = 256;
-  for (Op& o : ops) {
-    if (o.kind == OP_GN) gn_bytes = std::max(gn_bytes, groupnorm_scratch_bytes(tn[o.a].B, tn[o.a].H * tn[o.a].W, tn[o.a].cols, cfg.groups));
-    if (o.kind == OP_CONV3 && o.rv >= 0) cs_bytes = std::max(cs_bytes, colsum_batched_scratch_bytes(tn[o.out].B, tn[o.out].H * tn[o.out].W, tn[o.out].cols));
-  }
-  HIPCHK(hipMalloc((void**)&gn_scratch, gn_bytes));
-  if (needs_grad) HIPCHK(hipMalloc((void**)&cs_scratch, cs_bytes));
-  if (needs_grad) {
-    if (delta_elems) HIPCHK(hipMalloc((void**)&delta, delta_elems * 4 * 2));   // two row constants per (b, h, q): -delta, -lse*log2e
-    if (ups_elems) HIPCHK(hipMalloc((void**)&ups_tmp, ups_elems * 2));
-    if (geglu_elems) HIPCHK(hipMalloc((void**)&geglu_tmp, geglu_elems * 2));
-    if (part_bytes) HIPCHK(hipMalloc((void**)&attn_part, part_bytes));
-    {
-      const int ksteps = kvall_total / 64;
-      kv_nsplit = std::max(1, std::min(32, ksteps / 128));
-      HIPCHK(hipMalloc((void**)&kv_part, sizeof(float) * kv_nsplit * (size_t)tn[t_ehs].rows * tn[t_ehs].cols));
-    }
-    HIPCHK(hipMalloc((void**)&tproj_grad, sizeof(float) * B * tproj_total));
-  }
+  size_t need[8];
+  scratch_needs(need);
+  // A context that borrows its arenas (dead-row contexts of a trainer: one per live-row count, never live together with the
+  // donor) borrows the donor's scratch buffers too wherever they are large enough, instead of holding ~0.5 GB of its own each
+  // (the FF scratch alone is 0.5 GB at 12 samples, 1024 x 1024): only what the donor cannot cover is allocated here.
+  auto want = [&](void** ptr, void* const* donor_ptr, size_t* have, const size_t* donor_have, size_t need, int bit) -> int {
+    *have = need;
+    if (!need) return PEA_OK;
+    if (arena_donor && donor_ptr && *donor_ptr && *donor_have >= need) { *ptr = *donor_ptr; scratch_borrowed |= 1u << bit; return PEA_OK; }
+    HIPCHK(hipMalloc(ptr, need));
+    return PEA_OK;
+  };
+  Tape* dn = arena_donor;
+#define WANT(field, szf, need, bit) RC(want((void**)&field, dn ? (void* const*)&dn->field : nullptr, &szf, dn ? &dn->szf : nullptr, (need), bit))
+  WANT(gn_scratch, sc_gn, need[0], 0);
+  WANT(cs_scratch, sc_cs, need[1], 1);
+  WANT(delta, sc_delta, need[2], 2);
+  WANT(ups_tmp, sc_ups, need[3], 3);
+  WANT(geglu_tmp, sc_geglu, need[4], 4);
+  WANT(attn_part, sc_part, need[5], 5);
+  WANT(kv_part, sc_kv, need[6], 6);
+  WANT(tproj_grad, sc_tproj, need[7], 7);
+#undef WANT
   if (graph == 1) {
     const Tn& t = tn[t_out_in];
     HIPCHK(hipMalloc((void**)&vae_h, sizeof(float) * (size_t)B * cfg.out_channels * t.H * t.W));
@@ -935,6 +972,7 @@ int Tape::ensure_acts() {
 int Tape::release_acts() {
   HIPCHK(hipDeviceSynchronize());
   if (arena_borrowed) { aarena = nullptr; garena = nullptr; arena_borrowed = false; }    // the donor frees them
+  drop_borrowed_scratch();
   void** bufs[] = {(void**)&aarena, (void**)&garena, (void**)&gn_scratch, (void**)&delta, (void**)&ups_tmp, (void**)&tproj_grad,
                    (void**)&cs_scratch, (void**)&attn_part, (void**)&kv_part, (void**)&geglu_tmp, (void**)&am_scores,
                    (void**)&am_vt, (void**)&vae_h, (void**)&kvlen, (void**)&rel_bias, (void**)&rel_bucket};
@@ -946,7 +984,17 @@ int Tape::release_acts() {
   return PEA_OK;
 }
 
+// scratch pointers taken from the arena donor (ensure_acts) are the donor's to free
+void Tape::drop_borrowed_scratch() {
+  void** sc[] = {(void**)&gn_scratch, (void**)&cs_scratch, (void**)&delta, (void**)&ups_tmp, (void**)&geglu_tmp, (void**)&attn_part,
+                 (void**)&kv_part, (void**)&tproj_grad};
+  for (int i = 0; i < 8; ++i)
+    if (scratch_borrowed & (1u << i)) *sc[i] = nullptr;
+  scratch_borrowed = 0;
+}
+
 Tape::~Tape() {
+  drop_borrowed_scratch();
   if (owns_weights && warena) hipFree(warena);
   if (tmp_f32) hipFree(tmp_f32);
   if (aarena && !arena_borrowed) hipFree(aarena);
@@ -1844,7 +1892,11 @@ int Trainer::step_merged(const float* latents, const float* noise, const long lo
                          hipStream_t s) {
   const int B = student->B;
   // live teacher rows (dead-row elimination, model.h): idx[j] = the sample whose teacher row is merged row B + j
-  int idx[32], nt = 0;
+  // (both tables are sized from B: a merged pass may run at any batch, merge_passes = 2 with the SD1.5 micro-batch of 40,
+  // train_sd_zh.sh:18; the elimination itself needs the mask's bits, hence B <= 30)
+  int nt = 0;
+  std::vector<int> idx((size_t)B);
+  tmap_h.assign((size_t)B, 0);
   const bool dre = live_teacher_mask >= 0 && B <= 30 && (live_teacher_mask & ((1 << B) - 1)) != ((1 << B) - 1);
   for (int i = 0; i < B; ++i) {
     const bool live = !dre || ((live_teacher_mask >> i) & 1);
@@ -1892,10 +1944,11 @@ int Trainer::step_merged(const float* latents, const float* noise, const long lo
   RC(launch_cast_f32_bf16(teacher_neg, tehs_n, B * per_tok, s));
   if (!dre) RC(launch_select_rows(tehs_c, tehs_n, prompt_mask, ehs.d + B * per_tok, B, per_tok, s));
   else {
-    // select in place (every sample), then move the live rows to their compacted places behind the student rows
-    RC(launch_select_rows(tehs_c, tehs_n, prompt_mask, tehs_c, B, per_tok, s));
+    // every live row is selected straight into its compacted place behind the student rows (the kernel's pointers are
+    // __restrict__: no in-place select)
     for (int j = 0; j < nt; ++j)
-      HIPCHK(hipMemcpyAsync(ehs.d + (B + j) * per_tok, tehs_c + idx[j] * per_tok, (size_t)per_tok * 2, hipMemcpyDeviceToDevice, s));
+      RC(launch_select_rows(tehs_c + idx[j] * per_tok, tehs_n + idx[j] * per_tok, prompt_mask + idx[j], ehs.d + (B + j) * per_tok, 1,
+                            per_tok, s));
   }
   // student rows: adapter on (cond | uncond), CFG-dropout select (:383-395); a shorter student context leaves the
   // sample's tail rows at their zero padding (masked by Tape::cross_kvlen)
@@ -1918,7 +1971,7 @@ int Trainer::step_merged(const float* latents, const float* noise, const long lo
   }
   if (dre) {
     if (!tmap_d) HIPCHK(hipMalloc((void**)&tmap_d, sizeof(int) * 32));
-    HIPCHK(hipMemcpyAsync(tmap_d, tmap_h, sizeof(int) * B, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(tmap_d, tmap_h.data(), sizeof(int) * B, hipMemcpyHostToDevice, s));
   }
   RC(M.forward(xt2, t2, ehs.d, 1, text, 1, tid2, eps2, s));
   KdLossP kp;
