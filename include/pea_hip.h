@@ -344,6 +344,13 @@ int pea_unet_tap_export_nchw(void* unet, int k, int grad, float* out, void* stre
 int pea_unet_backward(void* unet, const float* deps, unsigned tap_seed_mask, void* stream);
 int pea_unet_input_grads(void* unet, void** d_ehs, void** d_text);
 /* resident bytes: weights; activations and gradients (allocated on the first forward / backward, 0 before) */
+/* Parity instrumentation: gradients of the two STACKED projections after the last backward pass, per layer.  which 0: all
+ * cross-attention to_k / to_v projections (one GEMM over encoder_hidden_states; diffusers Attention.to_k/to_v of every
+ * BasicTransformerBlock under train_sdxl_zh.py:397): d(K|V) fp32 [rows][cols], rows = differentiated samples x context length;
+ * which 1: all ResnetBlock2D.time_emb_proj layers (one GEMM over silu(emb)): fp32 [differentiated samples][cols].  out may be
+ * NULL (sizes only).  pea_unet_stacked_layout: diffusers weight key and column block of member i; PEA_E_NOTFOUND past the end. */
+int pea_unet_stacked_grad(void* unet, int which, float* out, long long* rows, int* cols, void* stream);
+int pea_unet_stacked_layout(void* unet, int which, int i, char* name, int name_len, int* col_off, int* cols);
 int pea_unet_memory(void* unet, long long* weight_bytes, long long* act_bytes, long long* grad_bytes, int* n_ops);
 /* Free the activation / gradient arenas and scratch of a context (weights stay); the next forward allocates them again.
  * Pointers handed out by pea_unet_tap_info / pea_unet_input_grads become invalid.  Synchronises the device. */
@@ -389,6 +396,9 @@ int pea_train_step(void* tr, const float* latents, const float* noise, const lon
  * cannot compare them before the step; a sample that carries KD weight without a teacher row makes the loss kernel emit
  * NaN for the losses and for that sample's gradient seeds (never another sample's row). */
 int pea_trainer_set_option(void* tr, const char* name, int value);
+/* the UNet context whose backward pass ran in the last step (the merged-pass context when the teacher is the student
+ * checkpoint, else the student's): handle for pea_unet_stacked_grad.  Owned by the trainer. */
+int pea_trainer_backward_context(void* trainer, void** unet);
 int pea_trainer_get_option(void* trainer, const char* name);   /* also "merge_state": 0 undecided, 1 merged, -1 n/a; "kd_samples_hint" (set: profiling only -- samples with zh_or_not == 0, for the KD-loss kernel's byte count) */
 /* pea_unet_release_activations on the trainer's student, teacher and merged-pass contexts.  The reference trains over
  * nine aspect-ratio buckets (utils/custom_dataset_sdxl.py:30, one bucket per batch): a caller keeps one trainer per
@@ -448,6 +458,9 @@ void pea_debug_set_geglu_bwd_fused(int v);
 void pea_debug_set_gemm_variant(int v);
 /* timing-only probes of the loader/consumer GEMM (results are wrong while set): 1 no DMA, 2 no barriers, 4 no ds_reads */
 void pea_debug_set_gemm_debug(int v);
+/* experiment aid (scripts/chain_probe.py): arms the NEXT GEMM / conv launch with a prefetch target -- its DMA waves touch
+ * [p, p + bytes) behind their last K-step (the product's tapes set the next launch's weight matrix themselves: GemmP::pf_ptr) */
+void pea_debug_set_gemm_prefetch(const void* p, long long bytes);
 
 #ifdef __cplusplus
 }

@@ -20,6 +20,19 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+try:
+    from .bf16_store import st as _st      # identity unless inside `with oracle.bf16_store.bf16_storage():`
+except ImportError:                        # pragma: no cover
+    from bf16_store import st as _st
+
+
+def _bf16_on() -> bool:
+    try:
+        from .bf16_store import enabled
+    except ImportError:                    # pragma: no cover
+        from bf16_store import enabled
+    return enabled()
+
 
 class AdapterRef(nn.Module):
     """Restates `MLP` (train_sdxl_zh.py:43-67).  out_dim1=None gives the SD1.5 variant
@@ -38,13 +51,20 @@ class AdapterRef(nn.Module):
 
     def forward(self, x):
         residual = x
-        x = self.projector(self.layernorm(x))
+        if _st is not None and _bf16_on():
+            # bf16-storage mode: the HIP adapter keeps the normalised rows, every pre-activation and every activation in bf16
+            h = _st(self.layernorm(x))
+            for m in self.projector:
+                h = _st(m(h))
+            x = h
+        else:
+            x = self.projector(self.layernorm(x))
         if self.fc is None:
             return x
-        x2 = self.fc(F.gelu(x))
+        x2 = _st(self.fc(_st(F.gelu(x))))
         if self.use_residual:
-            x = x + residual
-        return x.mean(1), x2
+            x = _st(x + residual)
+        return _st(x.mean(1)), x2
 
 
 def ddpm_alphas_cumprod(num_train_timesteps=1000, beta_start=0.00085, beta_end=0.012) -> torch.Tensor:

@@ -28,6 +28,11 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+try:                                               # (imported as oracle.unet_ref by the tests, as a plain module by scripts)
+    from .bf16_store import bf16_storage, st as _st  # noqa: F401  (identity unless inside `with bf16_storage():`)
+except ImportError:                                # pragma: no cover
+    from bf16_store import bf16_storage, st as _st  # noqa: F401
+
 
 @dataclass
 class UNetConfig:
@@ -140,7 +145,7 @@ class TimestepEmbedding(nn.Module):
         self.linear_2 = nn.Linear(dim, dim)
 
     def forward(self, x):
-        return self.linear_2(F.silu(self.linear_1(x)))
+        return self.linear_2(_st(F.silu(_st(self.linear_1(x)))))
 
 
 # ----------------------------------------------------------------------------- blocks
@@ -155,12 +160,13 @@ class ResnetBlock2D(nn.Module):
         self.conv_shortcut = nn.Conv2d(cin, cout, 1) if cin != cout else None
 
     def forward(self, x, temb):
-        h = self.conv1(F.silu(self.norm1(x)))
-        h = h + self.time_emb_proj(F.silu(temb))[:, :, None, None]
-        h = self.conv2(F.silu(self.norm2(h)))
+        # (_st: a tensor the HIP path stores in bf16 -- identity outside oracle.bf16_store.bf16_storage())
+        h = self.conv1(_st(F.silu(self.norm1(x))))
+        h = _st(h + _st(self.time_emb_proj(_st(F.silu(temb))))[:, :, None, None])
+        h = self.conv2(_st(F.silu(self.norm2(h))))
         if self.conv_shortcut is not None:
-            x = self.conv_shortcut(x)
-        return x + h
+            x = _st(self.conv_shortcut(x))
+        return _st(x + h)
 
 
 class Attention(nn.Module):
@@ -177,11 +183,11 @@ class Attention(nn.Module):
         ctx = x if ctx is None else ctx
         B, S, C = x.shape
         H = self.heads
-        q = self.to_q(x).view(B, S, H, C // H).transpose(1, 2)
-        k = self.to_k(ctx).view(B, -1, H, C // H).transpose(1, 2)
-        v = self.to_v(ctx).view(B, -1, H, C // H).transpose(1, 2)
+        q = _st(self.to_q(x)).view(B, S, H, C // H).transpose(1, 2)
+        k = _st(self.to_k(ctx)).view(B, -1, H, C // H).transpose(1, 2)
+        v = _st(self.to_v(ctx)).view(B, -1, H, C // H).transpose(1, 2)
         a = torch.softmax(q @ k.transpose(-1, -2) * (C // H) ** -0.5, dim=-1)
-        o = (a @ v).transpose(1, 2).reshape(B, S, C)
+        o = _st((_st(a) @ v).transpose(1, 2).reshape(B, S, C))          # (P is a bf16 MFMA operand of the P.V product)
         return self.to_out[0](o)
 
 
@@ -192,7 +198,7 @@ class GEGLU(nn.Module):
 
     def forward(self, x):
         h, gate = self.proj(x).chunk(2, dim=-1)
-        return h * F.gelu(gate)
+        return _st(h * F.gelu(gate))
 
 
 class FeedForward(nn.Module):
@@ -215,9 +221,9 @@ class BasicTransformerBlock(nn.Module):
         self.ff = FeedForward(dim)
 
     def forward(self, x, ctx):
-        x = self.attn1(self.norm1(x)) + x
-        x = self.attn2(self.norm2(x), ctx) + x
-        return self.ff(self.norm3(x)) + x
+        x = _st(self.attn1(_st(self.norm1(x))) + x)
+        x = _st(self.attn2(_st(self.norm2(x)), ctx) + x)
+        return _st(self.ff(_st(self.norm3(x))) + x)
 
 
 class Transformer2DModel(nn.Module):
@@ -233,18 +239,18 @@ class Transformer2DModel(nn.Module):
     def forward(self, x, ctx):
         B, C, H, W = x.shape
         res = x
-        h = self.norm(x)
+        h = _st(self.norm(x))
         if self.linear_proj:
-            h = self.proj_in(h.permute(0, 2, 3, 1).reshape(B, H * W, C))
+            h = _st(self.proj_in(h.permute(0, 2, 3, 1).reshape(B, H * W, C)))
         else:
-            h = self.proj_in(h).permute(0, 2, 3, 1).reshape(B, H * W, C)
+            h = _st(self.proj_in(h)).permute(0, 2, 3, 1).reshape(B, H * W, C)
         for blk in self.transformer_blocks:
             h = blk(h, ctx)
         if self.linear_proj:
             h = self.proj_out(h).reshape(B, H, W, C).permute(0, 3, 1, 2)
         else:
             h = self.proj_out(h.reshape(B, H, W, C).permute(0, 3, 1, 2))
-        return h + res
+        return _st(h + res)
 
 
 class Downsample2D(nn.Module):
@@ -253,7 +259,7 @@ class Downsample2D(nn.Module):
         self.conv = nn.Conv2d(c, c, 3, stride=2, padding=1)
 
     def forward(self, x):
-        return self.conv(x)
+        return _st(self.conv(x))
 
 
 class Upsample2D(nn.Module):
@@ -262,7 +268,7 @@ class Upsample2D(nn.Module):
         self.conv = nn.Conv2d(c, c, 3, padding=1)
 
     def forward(self, x):
-        return self.conv(F.interpolate(x, scale_factor=2.0, mode="nearest"))
+        return _st(self.conv(F.interpolate(x, scale_factor=2.0, mode="nearest")))
 
 
 class DownBlock(nn.Module):
@@ -399,13 +405,13 @@ class UNet2DConditionRef(nn.Module):
         if t.dim() == 0:
             t = t[None]
         t = t.expand(B)
-        emb = self.time_embedding(timestep_embedding(t, cfg.block_out_channels[0]).to(self.dtype))
+        emb = _st(self.time_embedding(_st(timestep_embedding(t, cfg.block_out_channels[0]).to(self.dtype))))
         if cfg.addition_embed_type == "text_time":
             text_embeds = added_cond_kwargs["text_embeds"]
             time_ids = added_cond_kwargs["time_ids"]
-            te = timestep_embedding(time_ids.flatten(), cfg.addition_time_embed_dim).reshape(B, -1)
-            add = torch.cat([text_embeds, te.to(text_embeds.dtype)], dim=-1)
-            emb = emb + self.add_embedding(add.to(self.dtype))
+            te = _st(timestep_embedding(time_ids.flatten(), cfg.addition_time_embed_dim)).reshape(B, -1)
+            add = torch.cat([_st(text_embeds), te.to(text_embeds.dtype)], dim=-1)
+            emb = _st(emb + self.add_embedding(add.to(self.dtype)))
         return emb
 
     def forward(self, sample, timesteps, encoder_hidden_states, added_cond_kwargs=None,
@@ -416,7 +422,7 @@ class UNet2DConditionRef(nn.Module):
         up blocks change), the mid residual is added to the mid-block output."""
         B = sample.shape[0]
         emb = self.embed(timesteps, added_cond_kwargs, B)
-        x = self.conv_in(sample)
+        x = _st(self.conv_in(sample))
         res = (x,)
         for blk in self.down_blocks:
             x, outs = blk(x, emb, encoder_hidden_states)
@@ -432,7 +438,7 @@ class UNet2DConditionRef(nn.Module):
             n = len(blk.resnets)
             take, res = res[-n:], res[:-n]
             x = blk(x, take, emb, encoder_hidden_states)
-        x = self.conv_out(F.silu(self.conv_norm_out(x)))
+        x = self.conv_out(_st(F.silu(self.conv_norm_out(x))))
         return (x,)
 
 

@@ -477,6 +477,52 @@ int pea_unet_input_grads(void* h, void** d_ehs, void** d_text) {
   if (d_text) *d_text = (u->t_text >= 0 && u->tn[u->t_text].gw) ? u->tn[u->t_text].g : nullptr;
   return PEA_OK;
 }
+/* Parity instrumentation: the gradients of the two STACKED projections after the last backward pass, per layer.
+ * which 0: every cross-attention K|V projection (ONE GEMM over encoder_hidden_states): d(K|V) as fp32 [rows][cols], rows =
+ * differentiated samples x context length; which 1: every ResnetBlock2D.time_emb_proj (ONE GEMM over silu(emb)): the fp32
+ * per-sample column sums [differentiated samples][cols].  out may be NULL (sizes only).  pea_unet_stacked_layout names the
+ * column block of member i (diffusers weight key, e.g. `...attn2.to_k.weight`), PEA_E_NOTFOUND behind the last member. */
+static int stacked_op(Tape* u, int which, const Op** op) {
+  const int t = which == 0 ? u->t_kvall : u->t_tproj;
+  if (t < 0) { pea_set_error("pea_unet_stacked_*: this graph has no such projection"); return PEA_E_INVALID; }
+  for (const Op& o : u->ops)
+    if (o.out == t && o.fused >= 0) { *op = &o; return PEA_OK; }
+  pea_set_error("pea_unet_stacked_*: producer not found");
+  return PEA_E_STATE;
+}
+int pea_unet_stacked_grad(void* h, int which, float* out, long long* rows, int* cols, void* stream) {
+  NOTNULL(h, "pea_unet_stacked_grad");
+  Tape* u = (Tape*)h;
+  if (which != 0 && which != 1) { pea_set_error("pea_unet_stacked_grad: which=%d", which); return PEA_E_INVALID; }
+  const Op* op = nullptr;
+  { int rc = stacked_op(u, which, &op); if (rc != PEA_OK) return rc; }
+  const Tn& t = u->tn[op->out];
+  const int Bb = u->bwd_batch > 0 ? u->bwd_batch : u->B;
+  const long long r = t.rows / u->B * Bb;
+  if (rows) *rows = r;
+  if (cols) *cols = t.cols;
+  if (!out) return PEA_OK;
+  if (!u->needs_grad || !t.g || !u->tproj_grad) { pea_set_error("pea_unet_stacked_grad: no backward pass has run on this context"); return PEA_E_STATE; }
+  if (which == 0) return launch_cast_bf16_f32(t.g, out, r * t.cols, (hipStream_t)stream);
+  HIPCHK(hipMemcpyAsync(out, u->tproj_grad, sizeof(float) * (size_t)r * t.cols, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  return PEA_OK;
+}
+int pea_unet_stacked_layout(void* h, int which, int i, char* name, int name_len, int* col_off, int* cols) {
+  NOTNULL(h, "pea_unet_stacked_layout");
+  Tape* u = (Tape*)h;
+  const Op* op = nullptr;
+  { int rc = stacked_op(u, which, &op); if (rc != PEA_OK) return rc; }
+  int k = 0;
+  for (const WSlot& s : u->slots) {
+    if (s.fused_parent != op->fused || s.kind != W_LINEAR) continue;
+    if (k++ != i) continue;
+    if (name && name_len > 1) snprintf(name, name_len, "%s", s.name.c_str());
+    if (col_off) *col_off = s.row_off;
+    if (cols) *cols = s.st_n ? s.st_n : s.d0;
+    return PEA_OK;
+  }
+  return PEA_E_NOTFOUND;
+}
 int pea_unet_memory(void* h, long long* weight_bytes, long long* act_bytes, long long* grad_bytes, int* n_ops) {
   NOTNULL(h, "pea_unet_memory");
   Tape* u = (Tape*)h;
@@ -628,6 +674,16 @@ int pea_trainer_get_option(void* h, const char* name) {
     return (int)(by >> 20);
   }
   return PEA_E_INVALID;
+}
+/* the UNet context whose backward pass ran in the last step: the merged-pass context (teacher == student checkpoint), else the
+ * student's own (parity instrumentation: pea_unet_stacked_grad) */
+int pea_trainer_backward_context(void* h, void** unet) {
+  NOTNULL(h, "pea_trainer_backward_context");
+  NOTNULL(unet, "pea_trainer_backward_context");
+  Trainer* t = (Trainer*)h;
+  const bool mg = t->merge_passes && t->merge_state == 1;
+  *unet = mg ? (void*)(t->last_ctx ? t->last_ctx : t->merged) : (void*)t->student;
+  return PEA_OK;
 }
 int pea_trainer_export(void* h, int which, float* out, void* stream) {
   NOTNULL(h, "pea_trainer_export");

@@ -60,6 +60,26 @@ __device__ __forceinline__ void wait_vmcnt() {
 }
 
 // ---- epilogue shared by both kernels.  acc[ni][mi][4g+j] = D[n = 8g + 4h + j][m = lane&31]
+// Next-op weight prefetch (GemmP::pf_ptr): called by a DMA wave behind its last K-step -- nothing of the ring is waited for any
+// more, so the loads' place in the in-order vmcnt queue cannot hold up a stage.  `slot` of `nslots` (DMA waves of the whole grid)
+// takes the 8 KiB chunks slot, slot + nslots, ...: one global_load_dword per chunk, lane l touching line l (a line is fetched
+// whole whatever part of it is asked for).  The loads are inline assembly (invisible to hipcc's waitcnt pass), so their
+// destination must stay reserved until they have returned: ONE register, an in/out operand of every load and consumed behind
+// the final wait -- as a fresh "=v" output per load the allocator reused it for the next iteration's address while the previous
+// load was still in flight (a returning load then overwrote an address: memory access fault in the step).
+__device__ __forceinline__ void dma_prefetch_next(const GemmP& p, int slot, int nslots, int lane) {
+  if (!p.pf_ptr) return;
+  const char* const base = (const char*)p.pf_ptr;
+  const long long nchunk = (p.pf_bytes + 8191) >> 13;
+  unsigned sink = 0;
+  for (long long c = slot; c < nchunk; c += nslots) {
+    const long long off = (c << 13) + lane * 128;
+    if (off < p.pf_bytes) asm volatile("global_load_dword %0, %1, off" : "+v"(sink) : "v"(base + off) : "memory");
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  asm volatile("" ::"v"(sink));
+}
+
 template <int MI, int NI>
 __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x16 (&acc)[NI][MI], int m_base, int n_base, int frow,
                                               int fh) {
@@ -964,6 +984,7 @@ __global__ __launch_bounds__((WM * WN + LW) * 64, MINW) void gemm_lc_kernel(cons
       if (t + S < nt && !(p.debug & 1)) issue(cur, kb0 + (t + S) * BK);
       cur = cur + 1 == S ? 0 : cur + 1;
     }
+    dma_prefetch_next(p, (blockIdx.y * gridDim.x + blockIdx.x) * LW + lw, gridDim.x * gridDim.y * LW, lane);
     return;
   }
 
@@ -1409,6 +1430,7 @@ __global__ __launch_bounds__((WM * WN + LW + SW) * 64, (OCC == 2 ? 3 : 1)) void 
       if (g + S < G && !PEA_PROBE(1)) produce(cur);
       cur = cur + 1 == S ? 0 : cur + 1;
     }
+    dma_prefetch_next(p, blockIdx.x * LW + lw, gridDim.x * LW, lane);
     if (SW > 0) {
       __builtin_amdgcn_s_barrier();                            // barrier of the last K-step (staged form only)
       __builtin_amdgcn_s_barrier();                            // final barrier (store waves drain the last tile after it)
@@ -1733,6 +1755,13 @@ static int pick_variant(const GemmP& p) {
 
 int g_gemm_debug = 0;
 extern "C" void pea_debug_set_gemm_debug(int v) { g_gemm_debug = v; }
+// next-op weight prefetch: PEA_GEMM_PF=0 switches it off (A/B), PEA_GEMM_PF_MAX_MB caps what one launch touches (default 64);
+// pea_debug_set_gemm_prefetch arms the NEXT launch_gemm with a target (operator-level experiments: scripts/chain_probe.py)
+static const bool g_gemm_pf_on = !(getenv("PEA_GEMM_PF") && atoi(getenv("PEA_GEMM_PF")) == 0);
+static const long long g_gemm_pf_max = (getenv("PEA_GEMM_PF_MAX_MB") ? atoll(getenv("PEA_GEMM_PF_MAX_MB")) : 64) << 20;
+static const void* g_dbg_pf_ptr = nullptr;
+static long long g_dbg_pf_bytes = 0;
+extern "C" void pea_debug_set_gemm_prefetch(const void* p, long long bytes) { g_dbg_pf_ptr = p; g_dbg_pf_bytes = bytes; }
 
 int launch_gemm(const GemmP& p_in, hipStream_t stream) {
   const GemmP& p0 = p_in;
@@ -1764,6 +1793,9 @@ int launch_gemm(const GemmP& p_in, hipStream_t stream) {
   }
   GemmP p = p_in;
   p.debug = g_gemm_debug;
+  if (g_dbg_pf_ptr) { p.pf_ptr = g_dbg_pf_ptr; p.pf_bytes = g_dbg_pf_bytes; g_dbg_pf_ptr = nullptr; }
+  if (!g_gemm_pf_on || p.pf_bytes <= 0) { p.pf_ptr = nullptr; p.pf_bytes = 0; }
+  if (p.pf_bytes > g_gemm_pf_max) p.pf_bytes = g_gemm_pf_max;
   SHAPECHK(p.qscale_cols % 16 == 0 && p.qscale_cols >= 0 && p.qscale_cols <= p.N && (!p.qscale_cols || (!p.act && !p.geglu_y && !p.gbwd_pre && p.ksplit <= 1)),
            "gemm: qscale_cols=%d must be a multiple of 16 within N, on a plain (no activation / GEGLU / split-K) epilogue", p.qscale_cols);
   if (!g_num_cus) HIPCHK(gemm_query_cus());

@@ -190,6 +190,15 @@ struct Tape {
   int* cross_kvlen = nullptr;        // graph 0: per-sample valid context tokens of the cross-attention (merged passes with a shorter
                                      // student context; rows beyond it in t_ehs are zero padding), null = all L
   int exec_ops(size_t begin, size_t end, bool skip_cached, hipStream_t s);
+  // Next-op weight prefetch (GemmP::pf_ptr).  The GEMM / conv launches of a pass and their weight matrices form a fixed
+  // sequence per tape: the first forward (backward) pass records it, every later pass hands launch j the matrix of launch
+  // j + 1 (a launch whose weights do not match the record drops it; the next pass records again).
+  struct WSeq { std::vector<std::pair<const void*, long long>> w; size_t pos = 0; bool ready = false; };
+  WSeq wseq_fwd, wseq_bwd;
+  WSeq* wseq_cur = nullptr;
+  void wseq_begin(WSeq& q) { wseq_cur = &q; q.pos = 0; if (!q.ready) q.w.clear(); }
+  void wseq_end() { if (wseq_cur && !wseq_cur->ready && !wseq_cur->w.empty()) wseq_cur->ready = true; wseq_cur = nullptr; }
+  int gemm(GemmP& p, hipStream_t s);   // launch_gemm with the prefetch target filled in
   Tape* arena_donor = nullptr;       // activation / gradient arenas borrowed from this (larger) tape: the two are never live at once
   bool arena_borrowed = false;
   // bytes of each scratch buffer (ensure_acts) and which of them are the donor's (bit order: gn, cs, delta, ups, geglu, attn_part,

@@ -1157,9 +1157,27 @@ int Tape::forward(const float* x, const float* t, const void* ehs, int ehs_dtype
       }
     }
   }
-  RC(exec_ops(0, ops.size(), true, s));
+  if (graph == 0) wseq_begin(wseq_fwd);                              // (the UNet of the step / of the denoise loop)
+  const int rc_ops = exec_ops(0, ops.size(), true, s);
+  if (rc_ops == PEA_OK) wseq_end();
+  else wseq_cur = nullptr;
+  RC(rc_ops);
   if (graph == 2) ce_valid = true;
   return PEA_OK;
+}
+
+int Tape::gemm(GemmP& p, hipStream_t s) {
+  if (WSeq* q = wseq_cur) {
+    // contiguous weight matrices only (every Linear / conv / fused matrix of the tapes: ldw == K)
+    const long long bytes = (p.ldw == p.K && p.ksplit <= 1) ? (long long)p.N * p.K * 2 : 0;
+    if (!q->ready) q->w.push_back({(const void*)p.W, bytes});
+    else {
+      const size_t i = q->pos++;
+      if (i >= q->w.size() || q->w[i].first != (const void*)p.W) { q->ready = false; q->w.clear(); wseq_cur = nullptr; }
+      else if (i + 1 < q->w.size()) { p.pf_ptr = q->w[i + 1].first; p.pf_bytes = q->w[i + 1].second; }
+    }
+  }
+  return launch_gemm(p, s);
 }
 
 // ops [begin, end) of the tape in order; skip_cached: leave out the ControlNet conditioning embedding when it is valid
@@ -1197,11 +1215,11 @@ int Tape::exec_ops(size_t begin, size_t end, bool skip_cached, hipStream_t s) {
         }
         if (o.p3 == 3 && g_geglu_unfused && o.c >= 0 && o.fold < 0) {      // A/B switch for experiments
           p.geglu_y = nullptr; p.stash_rows = 0;
-          RC(launch_gemm(p, s));
+          RC(gemm(p, s));
           RC(launch_geglu_fwd_il(tn[o.c].d, out.d, out.rows, out.cols, s));
           break;
         }
-        RC(launch_gemm(p, s));
+        RC(gemm(p, s));
         break;
       }
       case OP_ATTN_MAT: {              // one head over all H*W tokens: S = Q K^T, row softmax, O = P V per image
@@ -1260,7 +1278,7 @@ int Tape::exec_ops(size_t begin, size_t end, bool skip_cached, hipStream_t s) {
         p.rows_per_batch = out.H * out.W; p.pad_off = o.p2;
         if (o.rv >= 0) { p.rowvec = tn[o.rv].d + o.rv_off; p.ldrv = tn[o.rv].cols; }
         if (o.res >= 0) { p.res = tn[o.res].d; p.ldres = tn[o.res].cols; }
-        RC(launch_gemm(p, s));
+        RC(gemm(p, s));
         break;
       }
       case OP_GN: {
@@ -1325,6 +1343,11 @@ int Tape::backward(const float* deps, hipStream_t s) {
   const int Bb = bwd_batch > 0 ? bwd_batch : B;
   auto rb = [&](const Tn& t) -> long long { return t.rows / B * Bb; };
   HIPCHK(hipMemsetAsync(tproj_grad, 0, sizeof(float) * Bb * tproj_total, s));
+  struct WSeqScope {                       // record / replay the pass's weight sequence (next-op prefetch); an error path drops it
+    Tape* t; bool ok = false;
+    ~WSeqScope() { if (ok) t->wseq_end(); else t->wseq_cur = nullptr; }
+  } wscope{this};
+  if (graph == 0) wseq_begin(wseq_bwd);
   // A residual connection hands its gradient on unchanged.  Instead of copying / adding it into the skip tensor's
   // buffer at once, the skip tensor remembers it as a PENDING alias (Tn::gpend) and the next kernel that writes that
   // tensor's gradient (LayerNorm / GroupNorm backward, dgrad GEMM) takes it as its addend: one launch and one
@@ -1378,7 +1401,7 @@ int Tape::backward(const float* deps, hipStream_t s) {
           p.A = out.g; p.lda = out.cols; p.M = (int)rb(out); p.K = out.cols; p.N = a.cols;
           p.W = f.wt; p.ldw = f.N; p.C = kv_part; p.ldc = a.cols; p.out_f32 = 1;
           p.ksplit = kv_nsplit; p.split_stride = rb(out) * a.cols;
-          RC(launch_gemm(p, s));
+          RC(gemm(p, s));
           RC(materialize(a));
           RC(launch_splitk_reduce(kv_part, kv_nsplit, p.split_stride, a.g, a.cols, (int)rb(a), a.cols, a.gw, s));
           a.gw = true;
@@ -1395,7 +1418,7 @@ int Tape::backward(const float* deps, hipStream_t s) {
           p.W = w.wt; p.ldw = w.ldwt; p.C = a.g; p.ldc = a.cols;
           SHAPECHK(p.W != nullptr, "unet: dgrad weights missing for op %d", oi);
           if (const bf16* ad = addend(a)) { p.res = ad; p.ldres = a.cols; }
-          RC(launch_gemm(p, s));
+          RC(gemm(p, s));
           a.gw = true;
           break;
         }
@@ -1415,13 +1438,13 @@ int Tape::backward(const float* deps, hipStream_t s) {
             SHAPECHK(prev->stash_form >= 0, "unet: GEGLU op %d has no stash from a forward pass", oi - 1);
             p.gbwd_pre = hg.d; p.ldgp = hg.cols; p.gbwd_form = prev->stash_form;
             p.C = geglu_tmp; p.ldc = hg.cols;
-            RC(launch_gemm(p, s));
+            RC(gemm(p, s));
             a.gw = true;
             dpre_of = o.a;
           } else {
             p.C = a.g; p.ldc = a.cols;
             if (const bf16* ad = addend(a)) { p.res = ad; p.ldres = a.cols; }
-            RC(launch_gemm(p, s));
+            RC(gemm(p, s));
             a.gw = true;
           }
         }
@@ -1461,14 +1484,14 @@ int Tape::backward(const float* deps, hipStream_t s) {
           p.N = a.cols; p.K = 9 * out.cols; p.zeros = zeros; p.stride = 1;
           if (o.p1) {            // upsample-folded conv: gradient at the upsampled resolution, then 2x2 sum
             p.Ho = out.H; p.Wo = out.W; p.M = (int)rb(out); p.C = ups_tmp; p.ldc = a.cols;
-            RC(launch_gemm(p, s));
+            RC(gemm(p, s));
             RC(materialize(a));
             RC(launch_sumpool2(ups_tmp, a.g, Bb, a.H, a.W, a.cols, a.gw, s));
           } else {
             if (o.p0 == 2) { p.shift = 1; p.parity = 1; }
             p.Ho = a.H; p.Wo = a.W; p.M = (int)rb(a); p.C = a.g; p.ldc = a.cols;
             if (const bf16* ad = addend(a)) { p.res = ad; p.ldres = a.cols; }
-            RC(launch_gemm(p, s));
+            RC(gemm(p, s));
           }
           a.gw = true;
         }
@@ -1526,6 +1549,7 @@ int Tape::backward(const float* deps, hipStream_t s) {
   }
   for (Tn& t : tn)
     if (t.rg) RC(materialize(t));              // graph inputs that only ever received a passed-on gradient
+  wscope.ok = true;
   return PEA_OK;
 }
 

@@ -50,6 +50,11 @@ struct GemmP {
   // softmax_scale * log2(e) -- ONE rounding from the fp32 accumulator -- so their scores leave the MFMA in the log2 domain.
   int qscale_cols; float qscale;
   int gbwd_form;                   // 0: gbwd_pre = (h, gate);  1: gbwd_pre = (gelu(gate), h * gelu'(gate))  (a stash_grad forward)
+  // Next-op weight prefetch: once a workgroup's DMA waves have issued their last K-step they touch their share of
+  // [pf_ptr, pf_ptr + pf_bytes) -- the weight matrix of the NEXT GEMM / conv on the stream -- one 4-byte load per 128-byte line,
+  // so that it sits in the 256 MiB Infinity Cache when that launch's cold prologue asks for it (the 2.57 B frozen weights are read
+  // once per pass: every launch otherwise streams its panel from HBM in 128-byte row pieces).  null / 0 = none.
+  const void* pf_ptr; long long pf_bytes;
 };
 int launch_splitk_reduce(const float* part, int nsplit, long long stride, bf16* out, int ldo, int M, int N, int accum,
                          hipStream_t s);
