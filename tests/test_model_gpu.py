@@ -15,11 +15,11 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-# Limits of the comparisons against the oracle in bf16-storage mode (oracle/bf16_store.py), about 3x what round 5 measured
-# (profiles/r05_new_parity_tests.log): tiny model eps / flat adapter gradient / worst single layer
-BF16_ST_EPS, BF16_ST_GRAD, BF16_ST_LAYER = 1.0e-2, 2.0e-2, 3.0e-2
+# check_against_storage_floor: the HIP path may deviate from the fp32 oracle by this factor times what bf16 storage alone does to
+# the same quantity (the oracle in bf16-storage mode, oracle/bf16_store.py); measured ratios: profiles/r05_new_parity_tests.log
+STORAGE_FLOOR_FACTOR = 1.5      # measured: 0.97-1.03 (eps), 0.97-1.22 (flat gradient), 1.06 (full SDXL) - 1.31 (tiny) worst single layer
 # 20-step trajectory (test_training_trajectory_vs_oracle): final parameters / accumulated update against the oracle's
-TRAJ_W_LIM, TRAJ_D_LIM = 2e-2, 1e-1
+TRAJ_W_LIM, TRAJ_D_LIM, TRAJ_LOSS_LIM = 7e-3, 4e-2, 2e-3      # measured 2.2e-3 / 1.1e-2 / 2.4e-4 (weights move by 20 %)
 
 
 @pytest.fixture(scope="module")
@@ -105,7 +105,41 @@ def check_layer_grads(tr, store, B, limit, tag=""):
     return worst
 
 
-def make_pair(cfg_fn, B, L, needs_grad, seed=0, hw=None):"""
+def check_against_storage_floor(tag, B, hip_eps, hip_grad, hip_layers, ref32, st16, factor=None):
+    """The adaptive form of the end-to-end tolerance.  `ref32` / `st16`: (eps_student, eps_teacher, flat adapter gradient,
+    per-layer gradient dict) of the fp32 oracle and of the SAME oracle in bf16-storage mode (oracle/bf16_store.py: values and
+    gradients rounded wherever the HIP path stores a tensor).  The distance between those two is what bf16 storage alone does
+    to each quantity -- the noise floor of this model, batch and size, measured in the run.  The HIP path may deviate from the
+    fp32 oracle by `factor` x that floor, no more: a missing or doubled term the size of the floor (one of 70 cross-attention
+    layers is 1.4 % of d ehs) lifts the HIP error to 1.4-2 x the floor and fails, where a fixed 2e-2 limit let it pass.
+    (Comparing HIP with the bf16-storage oracle directly does not sharpen anything: two bf16 realisations of ~900 chained ops
+    are as far from each other as each is from fp32 -- measured in round 5, profiles/EXPERIMENTS.md.)"""
+    factor = factor or STORAGE_FLOOR_FACTOR
+    rows = []
+    for name, h, a, b in (("eps_student", hip_eps[0], ref32[0], st16[0]), ("eps_teacher", hip_eps[1], ref32[1], st16[1]),
+                          ("flat adapter gradient", hip_grad, ref32[2], st16[2])):
+        rows.append((name, rel_l2(h, a), rel_l2(b, a)))
+    worst = (0.0, "", 0.0, 0.0)
+    for k, g32 in ref32[3].items():
+        h = hip_layers[k]
+        if k.endswith("time_emb_proj.weight"):
+            want, got, st = g32.reshape(B, -1), h, st16[3][k].reshape(B, -1)
+        else:
+            want = g32.reshape(B, -1, g32.shape[-1])
+            got = h.reshape(B, -1, h.shape[-1])[:, :want.shape[1]]
+            st = st16[3][k].reshape(want.shape)
+        e, f = rel_l2(got, want), rel_l2(st, want)
+        if e / max(f, 1e-12) > worst[0]:
+            worst = (e / max(f, 1e-12), k, e, f)
+        assert e <= factor * f + 1e-3, (tag, k, e, f)
+    print(f"   [{tag}] error vs fp32 oracle / bf16-storage noise floor: " +
+          "; ".join(f"{n} {e:.2e} / {f:.2e} = {e / f:.2f}" for n, e, f in rows) +
+          f"; worst single layer {worst[2]:.2e} / {worst[3]:.2e} = {worst[0]:.2f} ({worst[1]}); limit {factor:.2f} x floor")
+    for n, e, f in rows:
+        assert e <= factor * f + 1e-3, (tag, n, e, f)
+
+
+def make_pair(cfg_fn, B, L, needs_grad, seed=0, hw=None):
     from oracle.unet_ref import UNet2DConditionRef
     from pea_diffusion_amd import config as pc
     from pea_diffusion_amd.unet import HipUNet
@@ -376,10 +410,13 @@ def test_training_step_vs_oracle(gpu, B, L):
         print(f"   adapter grad {k}: rel_l2={e:.3e} |ref|={q.grad.norm():.3e}")
         assert e < 4e-2, k
     check_layer_grads(tr, store, B, 4e-2, f"B{B} L{L} vs fp32 oracle")
-    # the same step against the oracle in bf16-STORAGE mode (oracle/bf16_store.py: activations and gradients rounded where the
-    # HIP path stores them): the storage noise is common to both sides, what is left is kernel arithmetic -- limits at about
-    # three times the measured error instead of the 4e-2 the fp32 comparison needs
+    # the adaptive tolerance: what bf16 storage alone does to each of these quantities (the same oracle in bf16-storage mode) is
+    # the noise floor; the HIP path may deviate from the fp32 oracle by STORAGE_FLOOR_FACTOR x that, no more
     from oracle.bf16_store import bf16_storage
+    ref32 = (out_r["noise_pred"].detach().clone(), out_r["noise_pred_teacher"].detach().clone(),
+             torch.cat([p.grad.reshape(-1) for p in ad_ref.parameters()]).clone(), dict(store))
+    hip_layers = hip_layer_grads(tr)
+    hip_eps = (tr.export("eps_student").cpu(), tr.export("eps_teacher").cpu())
     g_hip = ad_hip.flat_grad.float().cpu().clone()
     store.clear()
     ad_ref.zero_grad()
@@ -388,13 +425,9 @@ def test_training_step_vs_oracle(gpu, B, L):
         out_q["loss"].backward()
     for h in handles:
         h.remove()
-    e_s = rel_l2(tr.export("eps_student"), out_q["noise_pred"])
-    e_t = rel_l2(tr.export("eps_teacher"), out_q["noise_pred_teacher"])
-    g_q = torch.cat([p.grad.reshape(-1) for p in ad_ref.parameters()])
-    e_g = rel_l2(g_hip, g_q)
-    print(f"   vs bf16-storage oracle: eps_student {e_s:.3e} eps_teacher {e_t:.3e} flat adapter grad {e_g:.3e}")
-    worst = check_layer_grads(tr, store, B, BF16_ST_LAYER, f"B{B} L{L} vs bf16-storage oracle")
-    assert e_s < BF16_ST_EPS and e_t < BF16_ST_EPS and e_g < BF16_ST_GRAD, (e_s, e_t, e_g, worst)
+    st16 = (out_q["noise_pred"].detach(), out_q["noise_pred_teacher"].detach(),
+            torch.cat([p.grad.reshape(-1) for p in ad_ref.parameters()]), dict(store))
+    check_against_storage_floor(f"tiny B{B} L{L}", B, hip_eps, g_hip, hip_layers, ref32, st16)
 
 
 def test_training_step_repeatable_and_optimizer(gpu):
@@ -461,7 +494,7 @@ def test_training_trajectory_vs_oracle(gpu):
     print(f"[trajectory {K} steps] loss hip {lh[0]:.5f} -> {lh[-1]:.5f}, oracle {lr_[0]:.5f} -> {lr_[-1]:.5f}; worst per-step "
           f"loss deviation {worst:.2e}; parameters rel_l2 {e_w:.2e}, accumulated update rel_l2 {e_d:.2e} "
           f"(|update| / |w| = {float((wK - w0).norm() / w0.norm()):.2e})")
-    assert worst < 2e-2, (lh, lr_)
+    assert worst < TRAJ_LOSS_LIM, (lh, lr_)
     assert e_w < TRAJ_W_LIM and e_d < TRAJ_D_LIM, (e_w, e_d)
     for j in range(4):                                      # the loss of each batch falls between its first and its last visit
         first, last = j, j + 4 * ((K - 1 - j) // 4)
@@ -844,7 +877,7 @@ def _fast_fill_(module, seed=0):
                 p.copy_(0.02 * buf[:p.numel()])
 
 
-def _sdxl_full_model_step_vs_oracle(hw, tag, eps_lim, grad_lim, layer_lim=2e-2, storage_limits=None):
+def _sdxl_full_model_step_vs_oracle(hw, tag, eps_lim, grad_lim, layer_lim=2e-2, storage_floor=False):
     import copy
     from oracle import unet_ref as ou
     from oracle.step_ref import AdapterRef, synthetic_batch, training_step_ref
@@ -906,21 +939,23 @@ def _sdxl_full_model_step_vs_oracle(hw, tag, eps_lim, grad_lim, layer_lim=2e-2, 
     # all 140 cross-attention K / V projections and all 17 time_emb_proj layers, each on its own
     assert len(store) == 2 * 70 + 17, len(store)
     check_layer_grads(tr, store, B, layer_lim, f"sdxl {tag} vs fp32 oracle")
-    if storage_limits is not None:
-        # once more against the oracle in bf16-storage mode (oracle/bf16_store.py): limits ~3x the measured error
+    if storage_floor:
+        # adaptive tolerance (check_against_storage_floor): the same oracle once more in bf16-storage mode gives the noise floor
         from oracle.bf16_store import bf16_storage
+        ref32 = (ref["noise_pred"].detach().clone(), ref["noise_pred_teacher"].detach().clone(), g_ref.clone(), dict(store))
+        hip_layers = hip_layer_grads(tr)
+        hip_eps = (tr.export("eps_student").cpu(), tr.export("eps_teacher").cpu())
+        g_hip = ad.flat_grad.float().cpu().clone()
         store.clear()
         ad_ref.zero_grad()
         t0 = time.time()
         with bf16_storage():
             ref = training_step_ref(ad_ref, us, ut, bq, ou.cast_hook_ref)
             ref["loss"].backward()
-        e_s, e_t = rel_l2(tr.export("eps_student"), ref["noise_pred"]), rel_l2(tr.export("eps_teacher"), ref["noise_pred_teacher"])
-        g_q = torch.cat([p.grad.reshape(-1) for p in ad_ref.parameters()])
-        eg = rel_l2(ad.flat_grad, g_q)
-        print(f"   vs bf16-storage oracle ({time.time() - t0:.0f} s): eps_student {e_s:.3e} eps_teacher {e_t:.3e} flat adapter grad {eg:.3e}")
-        worst = check_layer_grads(tr, store, B, storage_limits[2], f"sdxl {tag} vs bf16-storage oracle")
-        assert e_s < storage_limits[0] and e_t < storage_limits[0] and eg < storage_limits[1], (e_s, e_t, eg, worst)
+        st16 = (ref["noise_pred"].detach(), ref["noise_pred_teacher"].detach(),
+                torch.cat([p.grad.reshape(-1) for p in ad_ref.parameters()]), dict(store))
+        print(f"   (bf16-storage oracle {time.time() - t0:.0f} s)")
+        check_against_storage_floor(f"sdxl {tag}", B, hip_eps, g_hip, hip_layers, ref32, st16)
     for h in handles:
         h.remove()
 
@@ -929,7 +964,7 @@ def test_sdxl_full_model_step_vs_oracle_512(gpu):
     """The full 2.57 B-parameter SDXL UNet (BASELINE configs[1] model, 512x512 so the fp32 CPU oracle finishes in about a
     minute; batch 2 so both mask values occur): the whole KD step -- merged passes, since the teacher is the student
     checkpoint -- against the oracle: eps, the four logged scalars, the flat adapter gradient."""
-    _sdxl_full_model_step_vs_oracle(64, "512x512", 1.5e-2, 2e-2, storage_limits=(1.0e-2, 1.5e-2, 2e-2))       # measured 7.0e-3 / 8.1e-3 vs fp32
+    _sdxl_full_model_step_vs_oracle(64, "512x512", 1.5e-2, 2e-2, storage_floor=True)       # measured 7.0e-3 / 8.1e-3 vs fp32
 
 
 def test_sdxl_full_model_step_vs_oracle_1024(gpu):
