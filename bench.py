@@ -135,6 +135,9 @@ def cpu_baseline_worker(model_name, budget_s, faithful=False):
     # the time budget forbids the 1024 px step is the 512 px step reported (value stays null then: no extrapolation).
     res = {"value": round(1.0 / dt, 5) if full else None, "unit": "images/s", "cores": threads,
            "box_cores": os.cpu_count(), "kind": "port",
+           "cores_note": "64 of the box's cores are used: the oracle is torch CPU fp32 and its conv / GEMM / attention kernels at batch 1 "
+                         "stop scaling beyond one socket's worth of threads (128 and 256 threads measured no faster and noisier); "
+                         "`cores` is the thread count actually used, `box_cores` what the box has (BASELINE.md 3 asks for the count to be stated)",
            "sample": f"1 KD step (teacher fwd no_grad + student fwd + adapter-only backward), batch 1, {hw * 8}x{hw * 8} px "
                      f"(latent {hw}x{hw}), fp32 torch CPU oracle, teacher==student weights, {dt:.1f} s wall "
                      f"(model build {build_s:.0f} s not counted)" + ("" if full else "; 1024 px step skipped: over the CPU budget"),
@@ -727,8 +730,10 @@ def main():
                 "tolerances": "fp32-stored outputs rtol 1e-3 / atol 1e-4 vs the fp32 oracle; bf16-stored outputs 1 bf16 ulp "
                               "(2-4 ulp for multi-product attention gradients and folded LN->Linear) + rms-scaled atol "
                               "(tests/test_ops_gpu.py); end to end (hundreds of chained bf16-stored ops) relative L2: eps 6.8e-3 "
-                              "and flat adapter gradient 7.9e-3 at 1024x1024 vs the fp32 oracle (limits 1.5e-2 / 2e-2, "
-                              "tests/test_model_gpu.py)",
+                              "and flat adapter gradient 7.9e-3 at 1024x1024 vs the fp32 oracle (limits 1.5e-2 / 2e-2), every one of the "
+                              "140 cross-attention K / V projections and 17 time_emb_proj layers on its own (limit 2e-2), and an adaptive "
+                              "limit of 1.5 x the bf16-storage noise floor measured in the run (tests/test_model_gpu.py: "
+                              "check_against_storage_floor; measured ratio 0.97-1.06 at full SDXL size)",
                 "adapter_golden_rel_l2": {"measured_in_this_run": adapter_golden_rel_l2(), "limit": 1e-2,
                                           "what": "HIP adapter forward (pooled, tokens) vs the reference MLP's own outputs, "
                                                   "tests/golden/mlp_sdxl_6M.npz (one bf16 rounding of weights and activations)"}}
@@ -840,6 +845,13 @@ def main():
         dist.destroy_process_group()
     if rank == 0:
         mem = student.memory()
+        if roof is not None and TFLOP_PER_IMAGE.get(args.model) and args.student == "same":
+            # the WHOLE step against the spec peak (all families, all gaps): algorithmic TFLOP of the step / median step time
+            step_tf = B * TFLOP_PER_IMAGE[args.model] / (ms_median * 1e-3)
+            roof["step_achieved"] = round(step_tf, 1)
+            roof["step_frac"] = round(step_tf / MFMA_PEAK_TFLOPS, 4)
+            roof["step_frac_note"] = ("whole training step: 20.31 TFLOP per image x per-GPU batch / median step time, against the same 2.5 PFLOP/s "
+                                      "spec peak as `frac` (which is the GEMM + conv family alone, from its launch durations)")
         out = {
             "metric": "training images/sec (SDXL 1024px bf16, adapter-only bwd)", "value": round(ips, 4),
             "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

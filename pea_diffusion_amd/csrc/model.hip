@@ -1174,7 +1174,10 @@ int Tape::gemm(GemmP& p, hipStream_t s) {
     else {
       const size_t i = q->pos++;
       if (i >= q->w.size() || q->w[i].first != (const void*)p.W) { q->ready = false; q->w.clear(); wseq_cur = nullptr; }
-      else if (i + 1 < q->w.size()) { p.pf_ptr = q->w[i + 1].first; p.pf_bytes = q->w[i + 1].second; }
+      else {
+        static const int dist = getenv("PEA_GEMM_PF_DIST") ? atoi(getenv("PEA_GEMM_PF_DIST")) : 1;     // experiment: launches ahead
+        if (i + dist < q->w.size()) { p.pf_ptr = q->w[i + dist].first; p.pf_bytes = q->w[i + dist].second; }
+      }
     }
   }
   return launch_gemm(p, s);
