@@ -341,14 +341,23 @@ typedef __attribute__((ext_vector_type(2))) unsigned epi_u32x2;
 // load is still waited for -- otherwise hipcc carries it as pending into the next tile's K-loop (see above).  No instruction.
 template <typename T>
 __device__ __forceinline__ void epi_consumed(const T& v) { asm volatile("" :: "v"(v)); }
+// PEA_EPI_WT (experiment, one-tile kernels only): write-through (sc1) stores -- the lines leave the XCD's L2 as they are written
+// instead of at the end-of-kernel release
+#ifndef PEA_EPI_WT
+#define PEA_EPI_WT 0
+#endif
+template <bool WT = false>
 __device__ __forceinline__ void epi_store16(void* ptr, epi_u32x4 v) {
+  if constexpr (WT) { asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" :: "v"(ptr), "v"(v) : "memory"); return; }
 #if PEA_EPI_HIDDEN_STORES
   asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" :: "v"(ptr), "v"(v) : "memory");
 #else
   *(epi_u32x4*)ptr = v;
 #endif
 }
+template <bool WT = false>
 __device__ __forceinline__ void epi_store8(void* ptr, epi_u32x2 v) {
+  if constexpr (WT) { asm volatile("global_store_dwordx2 %0, %1, off sc1" :: "v"(ptr), "v"(v) : "memory"); return; }
 #if PEA_EPI_HIDDEN_STORES
   asm volatile("global_store_dwordx2 %0, %1, off" :: "v"(ptr), "v"(v) : "memory");
 #else
@@ -362,7 +371,7 @@ __device__ __forceinline__ void epi_store4(void* ptr, unsigned v) {
   *(unsigned*)ptr = v;
 #endif
 }
-template <int MT, int NT, int EK = 0>
+template <int MT, int NT, int EK = 0, bool WT = false>
 __device__ __forceinline__ void gemm_epilogue16_fast(const GemmP& p, f32x4 (&acc)[NT][MT], int m_base, int n_base, int r16,
                                                      int q4) {
   constexpr bool LNF = EK == 1;
@@ -585,7 +594,7 @@ __device__ __forceinline__ void gemm_epilogue16_fast(const GemmP& p, f32x4 (&acc
                 o.h[j] = (bf16)(lo[j] + (float)r8[j]);
                 o.h[4 + j] = (bf16)(hi[j] + (float)r8[4 + j]);
               }
-              epi_store16(crow + n_base + (nt + (q4 & 1)) * 16 + 8 * (q4 >> 1), o.u);
+              epi_store16<WT>(crow + n_base + (nt + (q4 & 1)) * 16 + 8 * (q4 >> 1), o.u);
             } else {
               union { bf16x4 h; unsigned u[2]; } a, b;
 #pragma unroll
@@ -596,7 +605,7 @@ __device__ __forceinline__ void gemm_epilogue16_fast(const GemmP& p, f32x4 (&acc
               const auto lo = __builtin_amdgcn_permlane16_swap(a.u[0], b.u[0], false, false);
               const auto hi = __builtin_amdgcn_permlane16_swap(a.u[1], b.u[1], false, false);
               const u32x4 o = {lo[0], hi[0], lo[1], hi[1]};
-              epi_store16(crow + n_base + (nt + (q4 & 1)) * 16 + 8 * (q4 >> 1), o);
+              epi_store16<WT>(crow + n_base + (nt + (q4 & 1)) * 16 + 8 * (q4 >> 1), o);
             }
           } else {                                                     // the single last tile of an odd nv
             union { bf16x4 h; u32x2 u; } o;
@@ -606,7 +615,7 @@ __device__ __forceinline__ void gemm_epilogue16_fast(const GemmP& p, f32x4 (&acc
               if constexpr (HR) v += (float)rs[mt][j];
               o.h[j] = (bf16)v;
             }
-            epi_store8(crow + n_base + nt * 16 + 4 * q4, o.u);
+            epi_store8<WT>(crow + n_base + nt * 16 + 4 * q4, o.u);
           }
         }
       }
@@ -799,7 +808,14 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t tile_rsrc(const GemmP& p, int 
 // tiles ahead (all S slots in flight).
 template <int MODE, int BM, int BN, int WM, int WN, int LW, int S, bool PROBE16 = false, bool M16 = false, int MINW = 1,
           bool LNF = false>
-__global__ __launch_bounds__((WM * WN + LW) * 64, MINW) void gemm_lc_kernel(const GemmP p) {
+__global__ __launch_bounds__((WM * WN + LW) * 64, MINW) void gemm_lc_kernel(const bf16* pl_A, const bf16* pl_W, int pl_lda, int pl_ldw, int pl_M,
+                                                                           int pl_N, int pl_K, int pl_ksplit, int pl_debug, const GemmP p_in) {
+  // Kernarg preload (-mllvm -amdgpu-kernarg-preload-count): the leading SCALAR parameters arrive in SGPRs with the wave, so the
+  // DMA waves' way to their first LDS-DMA issue (tile index, buffer resources, per-lane offsets) does not start with a scalar-load
+  // round trip to the 552-byte GemmP in the kernarg segment (a by-value struct is never preloaded); everything else is read from
+  // the struct as before.  The local copy costs nothing: its fields are loaded where they are used.
+  GemmP p = p_in;
+  p.A = pl_A; p.W = pl_W; p.lda = pl_lda; p.ldw = pl_ldw; p.M = pl_M; p.N = pl_N; p.K = pl_K; p.ksplit = pl_ksplit; p.debug = pl_debug;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int NWC = WM * WN;
   constexpr int STAGE = (BM + BN) * 128;
@@ -1069,7 +1085,7 @@ __global__ __launch_bounds__((WM * WN + LW) * 64, MINW) void gemm_lc_kernel(cons
       return;
     }
     if (p.epi_fast) {
-      gemm_epilogue16_fast<MT, NT>(p, acc, bm * BM + wr * (BM / WM), bn * BN + wc * (BN / WN), r16, q4);
+      gemm_epilogue16_fast<MT, NT, 0, PEA_EPI_WT != 0>(p, acc, bm * BM + wr * (BM / WM), bn * BN + wc * (BN / WN), r16, q4);
       return;
     }
     GemmP q = p;
@@ -1156,7 +1172,8 @@ static int launch_lc(const GemmP& p, hipStream_t stream) {
   }
   const int grid = cdiv(p.M, BM) * cdiv(p.N, BN);
   hipLaunchKernelGGL((gemm_lc_kernel<MODE, BM, BN, WM, WN, LW, S, PROBE16, M16, MINW, LNF>),
-                     dim3(grid, p.ksplit > 1 ? p.ksplit : 1), dim3((WM * WN + LW) * 64), lds, stream, p);
+                     dim3(grid, p.ksplit > 1 ? p.ksplit : 1), dim3((WM * WN + LW) * 64), lds, stream, p.A, p.W, p.lda, p.ldw, p.M, p.N, p.K,
+                     p.ksplit, p.debug, p);
   return PEA_OK;
 }
 
@@ -1184,6 +1201,8 @@ static int launch_lc(const GemmP& p, hipStream_t stream) {
 // per SIMD): the two run out of phase, so one's tile transition / DMA wait is the other's main loop.
 template <int MODE, int BM, int BN, int WM, int WN, int LW, int S, int SW = 0, int DF = 0, int EPI = 0, int OCC = 1>
 __global__ __launch_bounds__((WM * WN + LW + SW) * 64, (OCC == 2 ? 3 : 1)) void gemm_lcp_kernel(const GemmP p) {
+  // (no preloaded leading scalars here: measured no gain on the multi-tile launches, and the 256 x 160 instantiation's epilogue
+  // spills 16 instead of 8 registers with them)
   constexpr bool FASTONLY = EPI != 0;     // EPI 1: batched-load epilogue only; 2: the same with the folded LayerNorm; 3: with the fused GEGLU backward
   constexpr int PITCH = BN * 2 + 16;                            // staging row pitch: conflict-free 8-byte writes
   extern __shared__ __attribute__((aligned(16))) char smem[];

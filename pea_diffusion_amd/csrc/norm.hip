@@ -6,6 +6,9 @@
 // HBM-bound: every pass moves 16 bytes per lane, statistics are reduced per thread (fp32),
 // per block through LDS, and across blocks with fp64 atomics (one per group per block).
 #include "pea_kernels.h"
+#ifndef PEA_LN_WT
+#define PEA_LN_WT 0      // experiment: 1 = LayerNorm outputs leave as write-through (sc1) stores
+#endif
 
 #define GN_MAX_GROUPS 64
 
@@ -623,7 +626,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const bf16* __restrict__ x,
           o[j] = (bf16)(((float)v[r][i][j] - mean[r]) * rstd[r] * g0[STATS_ONLY ? 0 : i][j] + b0[STATS_ONLY ? 0 : i][j]);
           o[4 + j] = (bf16)(((float)v[r][i][4 + j] - mean[r]) * rstd[r] * g1[STATS_ONLY ? 0 : i][j] + b1[STATS_ONLY ? 0 : i][j]);
         }
-        *(bf16x8*)(y + (long long)(row0 + r) * C + ck * 8) = o;
+        store16<PEA_LN_WT != 0>(y + (long long)(row0 + r) * C + ck * 8, o);
       }
     }
   }
@@ -692,7 +695,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16* __restrict__ x,
           if (add) rr += (float)av[r][i][j];
           o[j] = (bf16)rr;
         }
-        *(bf16x8*)(dx + (long long)(row0 + r) * C + ck * 8) = o;
+        store16<PEA_LN_WT != 0>(dx + (long long)(row0 + r) * C + ck * 8, o);
       }
     }
   }

@@ -43,6 +43,20 @@ void pea_set_error(const char* fmt, ...);
     }                                                                                          \
   } while (0)
 
+// 16-byte store, write-through when WT (sc1: the line leaves the XCD's L2 as it is written instead of waiting there for the
+// end-of-kernel release).  Inline assembly: invisible to hipcc's vmcnt bookkeeping -- only for stores nothing in the kernel waits on.
+typedef __attribute__((ext_vector_type(4))) unsigned pea_u32x4;
+template <bool WT>
+__device__ __forceinline__ void store16(void* ptr, bf16x8 v) {
+  if constexpr (WT) {
+    union { bf16x8 h; pea_u32x4 u; } c;
+    c.h = v;
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(ptr), "v"(c.u) : "memory");
+  } else {
+    *(bf16x8*)ptr = v;
+  }
+}
+
 // erf by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7, i.e. fp32-epsilon level; every consumer rounds to bf16):
 // 1 v_rcp + 1 v_exp + 7 fma/mul instead of libm's two-branch erff -- the GELU sits in GEMM epilogues where the
 // VALU work is not hidden behind HBM
