@@ -7,7 +7,10 @@
 // per block through LDS, and across blocks with fp64 atomics (one per group per block).
 #include "pea_kernels.h"
 #ifndef PEA_LN_WT
-#define PEA_LN_WT 0      // experiment: 1 = LayerNorm outputs leave as write-through (sc1) stores
+#define PEA_LN_WT 1      // LayerNorm outputs leave as write-through (sc1) stores: a streaming kernel's last ~20 MB otherwise sit dirty in
+                         // the L2s until the end-of-kernel release writes them back with nothing else running (whole step, alternating
+                         // processes on one box: 101.24 / 101.14 ms -> 101.02 / 100.89; the same in the one-tile GEMM epilogue, where all
+                         // stores are one burst at the end, costs 1.8 ms: PEA_EPI_WT stays 0)
 #endif
 
 #define GN_MAX_GROUPS 64
