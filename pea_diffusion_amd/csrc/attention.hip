@@ -20,6 +20,9 @@
 #include "pea_kernels.h"
 
 #define TILE_BYTES 8192   // 64 rows x 128 bytes
+#ifndef PEA_ATTN_WT
+#define PEA_ATTN_WT 0     // experiment: O / dQ rows leave as write-through (sc1) stores (see norm.hip: PEA_LN_WT)
+#endif
 #ifndef PEA_ATTN_BWD_PREFETCH
 #define PEA_ATTN_BWD_PREFETCH 0   // 1: backward roles request each batch of LDS fragments one phase ahead of its MFMAs (A/B: 1 % slower, +40 registers)
 #endif
@@ -563,7 +566,7 @@ __device__ __forceinline__ void attn_q_body(const AttnP& p, char* smem, int blk_
 #pragma unroll
           for (int j = 0; j < 8; ++j) v[j] = (bf16)((float)v[j] + (float)old[j]);
         }
-        *(bf16x8*)dst = v;
+        store16<PEA_ATTN_WT != 0>(dst, v);
       }
     }
   }
@@ -998,7 +1001,7 @@ __global__ __launch_bounds__(256, 3) void xattn_fwd_kernel(const AttnP p, int up
       for (int i = 0; i < 4; ++i) {
         const int row = i * 8 + r8;
         const bf16x8 v = *(const bf16x8*)(ost + row * 144 + ch * 16);
-        if (q0w + row < p.Sq) *(bf16x8*)(Ob + (long long)(q0w + row) * p.ldo) = v;
+        if (q0w + row < p.Sq) store16<PEA_ATTN_WT != 0>(Ob + (long long)(q0w + row) * p.ldo, v);
       }
     }
   }

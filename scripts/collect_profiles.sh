@@ -3,7 +3,7 @@
 # per-family breakdown, rocprofv3 kernel stats of the same command, two PMC passes (FETCH_SIZE / WRITE_SIZE), the MFMA
 # utilisation pass, the per-launch profile and the GEMM / attention variant tables.  Everything lands in gpurun_out/ with the
 # round tag ($1, default r03); copy what should be judged into profiles/.
-T=${1:-r04}
+T=${1:-r05}
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out
 mkdir -p $O
