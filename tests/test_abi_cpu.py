@@ -71,3 +71,33 @@ def test_host_runtime_under_asan():
                        env=dict(os.environ, ASAN_OPTIONS="detect_leaks=0:abort_on_error=0"))
     assert r.returncode == 0 and "all host checks passed" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
     assert "AddressSanitizer" not in r.stderr
+
+
+def test_scratch_plan_runs_without_a_device():
+    """pea_unet_plan_scratch (round 5): what a context allocates beside its arenas, host only.  A dead-row context (B + n_t
+    samples, the same bwd_batch) never needs more of any buffer class in total than the 2B merged context it borrows from; an
+    inference context needs only the GroupNorm partials."""
+    import ctypes as C
+    from pea_diffusion_amd import config as pc
+    L = _lib.lib()
+    c = pc.to_c(pc.sdxl_config())
+
+    def scratch(B, flags, bwd):
+        v = C.c_longlong()
+        assert L.pea_unet_plan_scratch(C.byref(c), B, 128, 128, 77, flags, bwd, C.byref(v)) == 0, L.pea_last_error()
+        return v.value
+    full, dre, infer = scratch(8, 1, 4), scratch(6, 1, 4), scratch(8, 0, 0)
+    assert 0.3e9 < full < 4e9, full                    # the FF d(pre-activation) buffer alone is 4 x 4096 x 10240 x 2 bytes
+    assert dre <= full
+    assert 0 < infer < 64e6 and infer < full
+    assert L.pea_unet_plan_scratch(C.byref(c), 8, 128, 128, 77, 1, 4, None) == -1       # NULL output: argument error, not a crash
+
+
+def test_stacked_grad_entry_points_reject_null_handles():
+    import ctypes as C
+    L = _lib.lib()
+    rows, cols = C.c_longlong(), C.c_int()
+    assert L.pea_unet_stacked_grad(None, 0, None, C.byref(rows), C.byref(cols), None) == -1
+    assert L.pea_unet_stacked_layout(None, 0, 0, None, 0, None, None) == -1
+    assert L.pea_trainer_backward_context(None, None) == -1
+

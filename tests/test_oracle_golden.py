@@ -225,3 +225,21 @@ def test_ssd1b_layout_known_answers_and_config_json():
     assert [len(a.transformer_blocks) for a in m.up_blocks[0].attentions] == [4, 4, 10]
     assert [len(a.transformer_blocks) for a in m.up_blocks[1].attentions] == [2, 1, 1]
     assert [len(a.transformer_blocks) for a in m.down_blocks[2].attentions] == [4, 4]
+
+
+def test_bf16_storage_mode_is_identity_when_off_and_rounds_values_and_gradients_when_on():
+    """oracle/bf16_store.py: outside the context `st` must not change a single bit (every golden fixture was generated with the fp32
+    oracle); inside, the forward value and the gradient flowing back through the same point are bf16-rounded."""
+    import torch
+    from oracle.bf16_store import bf16_storage, enabled, st
+    x = (torch.randn(64, generator=torch.Generator().manual_seed(0)) * 3).requires_grad_(True)
+    assert not enabled() and st(x) is x
+    with bf16_storage():
+        assert enabled()
+        y = st(x)
+        assert torch.equal(y.detach(), x.detach().to(torch.bfloat16).float())
+        g = torch.randn(64, generator=torch.Generator().manual_seed(1))
+        y.backward(g)
+        assert torch.equal(x.grad, g.to(torch.bfloat16).float())
+    assert not enabled()
+
