@@ -51,7 +51,10 @@ __device__ __forceinline__ void store16(void* ptr, bf16x8 v) {
   if constexpr (WT) {
     union { bf16x8 h; pea_u32x4 u; } c;
     c.h = v;
-    asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(ptr), "v"(c.u) : "memory");
+    // s_nop 1: a 16-byte store reads its data registers for two more cycles -- the wait states hipcc pads before a following write
+    // of those registers when IT emits the store.  Without it the next chunk's values overwrote the data in flight (round 5: the
+    // first form of this helper stored garbage in the LayerNorm backward; caught by smoke(), not by the timing A/B).
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" :: "v"(ptr), "v"(c.u) : "memory");
   } else {
     *(bf16x8*)ptr = v;
   }
