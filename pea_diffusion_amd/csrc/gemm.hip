@@ -1764,7 +1764,8 @@ static int pick_variant(const GemmP& p) {
     if (r192 * 10 <= cur * 9) return t192 <= cus ? 39 : 40;
   }
   if (t128 <= cus) return lean ? 35 : 25;            // at most one 128x160 tile per CU
-  if (t256 <= cus) return t256 > cus * 3 / 4 ? 24 : (lean ? 35 : 28);
+  static const bool one_round_persistent = getenv("PEA_GEMM_ONE_ROUND_PERSISTENT") != nullptr;   // experiment: 27 instead of 24
+  if (t256 <= cus) return t256 > cus * 3 / 4 ? (one_round_persistent ? 27 : 24) : (lean ? 35 : 28);
   // more than one 256x160 tile per CU: the large tile wins (less L2 -> LDS traffic per flop) unless its tile count
   // leaves the last round of CUs mostly idle (e.g. 384 tiles = 1.5 rounds), then the 128x160 form balances better
   const int rounds = cdiv(t256, cus);
