@@ -13,7 +13,10 @@ def timeit(fn, iters=20):
     for _ in range(iters): fn()
     e.record(); torch.cuda.synchronize()
     return s.elapsed_time(e) / iters * 1e3
-for (M, N, K, v) in [(8192, 10240, 1280, 27), (8192, 10240, 1280, 28), (32768, 5120, 640, 27), (8192, 8192, 8192, 27)]:
+shapes = [(8192, 10240, 1280, 27), (8192, 10240, 1280, 28), (32768, 5120, 640, 27), (8192, 8192, 8192, 27)]
+if len(sys.argv) > 1 and sys.argv[1] == "oneround":      # the one-round 128 x 160 shapes of the backward on the persistent 4 x 2-wave kernel
+    shapes = [(4096, 1280, 10240, 28), (4096, 1280, 3840, 28), (4096, 1280, 1280, 28), (4096, 1280, 10240, 29)]
+for (M, N, K, v) in shapes:
     a = torch.randn(M, K, device="cuda").to(BF); w = (torch.randn(N, K, device="cuda") * K ** -0.5).to(BF)
     out = torch.empty(M, N, device="cuda", dtype=BF)
     L.pea_debug_set_gemm_variant(v)
