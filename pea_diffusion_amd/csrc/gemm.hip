@@ -67,17 +67,23 @@ __device__ __forceinline__ void wait_vmcnt() {
 // destination must stay reserved until they have returned: ONE register, an in/out operand of every load and consumed behind
 // the final wait -- as a fresh "=v" output per load the allocator reused it for the next iteration's address while the previous
 // load was still in flight (a returning load then overwrote an address: memory access fault in the step).
-__device__ __forceinline__ void dma_prefetch_next(const GemmP& p, int slot, int nslots, int lane) {
-  if (!p.pf_ptr) return;
+__device__ __forceinline__ unsigned dma_prefetch_issue(const GemmP& p, int slot, int nslots, int lane) {
+  unsigned sink = 0;
+  if (!p.pf_ptr) return sink;
   const char* const base = (const char*)p.pf_ptr;
   const long long nchunk = (p.pf_bytes + 8191) >> 13;
-  unsigned sink = 0;
   for (long long c = slot; c < nchunk; c += nslots) {
     const long long off = (c << 13) + lane * 128;
     if (off < p.pf_bytes) asm volatile("global_load_dword %0, %1, off" : "+v"(sink) : "v"(base + off) : "memory");
   }
+  return sink;
+}
+__device__ __forceinline__ void dma_prefetch_wait(unsigned sink) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   asm volatile("" ::"v"(sink));
+}
+__device__ __forceinline__ void dma_prefetch_next(const GemmP& p, int slot, int nslots, int lane) {
+  dma_prefetch_wait(dma_prefetch_issue(p, slot, nslots, lane));
 }
 
 template <int MI, int NI>
@@ -806,9 +812,16 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t tile_rsrc(const GemmP& p, int 
 //   consumer t: sub-steps 0..2 of tile t, lgkmcnt(0) -> barrier_t -> prefetch (t+1, 0), sub-step 3 of tile t
 // After barrier_t every consumer has issued and retired all reads of tile t's LDS slot, so the ring runs S
 // tiles ahead (all S slots in flight).
+// KSW: INTRA-WORKGROUP K SPLIT (one-round launches with a long K on the 128 x 160 tile).  The eight consumer waves of the plain
+// form own 32 x 80 each and read 14 fragments per 20 MFMAs -- the fragment reads are the largest adder on top of the bare MFMA
+// stream there (profiles/r05_gemm_loop_probe_oneround.log: 64 -> 80 us on K = 10240).  With KSW the wave grid is WM x WN x 2: wave
+// (wr, wc, wk) owns a (BM / WM) x (BN / WN) = 64 x 80 tile like the 256 x 160 kernel's waves (9 reads per 20 MFMAs) but only the
+// k32 half wk of every K-step; behind the loop the two halves of a tile swap half of their accumulators through the (free) ring
+// and each wave finishes 32 x 80 -- the same epilogue, the same stores as the plain form.  fp32 sum of the two halves in the
+// order (half 0) + (half 1) on both sides: deterministic.
 template <int MODE, int BM, int BN, int WM, int WN, int LW, int S, bool PROBE16 = false, bool M16 = false, int MINW = 1,
-          bool LNF = false>
-__global__ __launch_bounds__((WM * WN + LW) * 64, MINW) void gemm_lc_kernel(const bf16* pl_A, const bf16* pl_W, int pl_lda, int pl_ldw, int pl_M,
+          bool LNF = false, bool KSW = false>
+__global__ __launch_bounds__((WM * WN * (KSW ? 2 : 1) + LW) * 64, MINW) void gemm_lc_kernel(const bf16* pl_A, const bf16* pl_W, int pl_lda, int pl_ldw, int pl_M,
                                                                            int pl_N, int pl_K, int pl_ksplit, int pl_debug, const GemmP p_in) {
   // Kernarg preload (-mllvm -amdgpu-kernarg-preload-count): the leading SCALAR parameters arrive in SGPRs with the wave, so the
   // DMA waves' way to their first LDS-DMA issue (tile index, buffer resources, per-lane offsets) does not start with a scalar-load
@@ -817,7 +830,7 @@ __global__ __launch_bounds__((WM * WN + LW) * 64, MINW) void gemm_lc_kernel(cons
   GemmP p = p_in;
   p.A = pl_A; p.W = pl_W; p.lda = pl_lda; p.ldw = pl_ldw; p.M = pl_M; p.N = pl_N; p.K = pl_K; p.ksplit = pl_ksplit; p.debug = pl_debug;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int NWC = WM * WN;
+  constexpr int NWC = WM * WN * (KSW ? 2 : 1);
   constexpr int STAGE = (BM + BN) * 128;
   constexpr int A_BYTES = BM * 128;
   constexpr int PA = BM / 8 / LW, PB = BN / 8 / LW;
@@ -1000,11 +1013,104 @@ __global__ __launch_bounds__((WM * WN + LW) * 64, MINW) void gemm_lc_kernel(cons
       if (t + S < nt && !(p.debug & 1)) issue(cur, kb0 + (t + S) * BK);
       cur = cur + 1 == S ? 0 : cur + 1;
     }
-    dma_prefetch_next(p, (blockIdx.y * gridDim.x + blockIdx.x) * LW + lw, gridDim.x * gridDim.y * LW, lane);
+    const unsigned pf_sink = dma_prefetch_issue(p, (blockIdx.y * gridDim.x + blockIdx.x) * LW + lw, gridDim.x * gridDim.y * LW, lane);
+    if constexpr (KSW) {                                       // the consumers' accumulator exchange: two workgroup barriers
+      __builtin_amdgcn_s_barrier();                            // (the prefetch loads are in flight across them)
+      __builtin_amdgcn_s_barrier();
+    }
+    dma_prefetch_wait(pf_sink);
     return;
   }
 
   // ================================ consumer waves
+  if constexpr (KSW) {
+    constexpr int MT = BM / WM / 16, NT = BN / WN / 16, MH = MT / 2;
+    static_assert(MT % 2 == 0 && M16 && !LNF, "K-split consumers: even row-fragment count, 16x16x32 form");
+    const int wk = wave / (WM * WN), w4 = wave % (WM * WN);
+    const int wr = w4 / WN, wc = w4 % WN;
+    const int r16 = lane & 15, q4 = lane >> 4;
+    const int a_row0 = wr * (BM / WM) + r16, w_row0 = wc * (BN / WN) + r16;
+    f32x4 acc[NT][MT];
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+#pragma unroll
+      for (int j = 0; j < MT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    bf16x8 af[2][MT], wf[2][NT];
+    // this wave's k32 half of a stage: chunks 4 wk .. 4 wk + 3; rows 16 apart share the swizzle term, so TWO per-lane offsets
+    // + compile-time multiples of 2048 address all nine fragments
+    const int a_off = swz_off(a_row0, 4 * wk + q4), w_off = A_BYTES + swz_off(w_row0, 4 * wk + q4);
+    auto load_frags = [&](int which, const char* tile) {
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) af[which][mt] = *(const bf16x8*)(tile + a_off + mt * 2048);
+#pragma unroll
+      for (int n_ = 0; n_ < NT; ++n_) wf[which][n_] = *(const bf16x8*)(tile + w_off + n_ * 2048);
+    };
+    __builtin_amdgcn_s_barrier();                              // prologue barrier
+    load_frags(0, smem);
+    int cur = 0;
+    // one K-step: wait for its fragments, barrier_t (K-step t + 1 landed, slot t free), request K-step t + 1's fragments into the
+    // OTHER register set interleaved with this step's MFMAs.  Two steps per loop iteration in straight-line code (nt is even:
+    // launch_gemm only takes this form then) -- a register set picked by the parity of a loop counter made hipcc shuffle and
+    // spill fragments inside the loop.  Behind the last K-step the read is a harmless one of a stale slot.
+    auto kstep = [&](auto set_c, int t) {
+      constexpr int P = decltype(set_c)::value;
+      const int nxt = cur + 1 == S ? 0 : cur + 1;
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if (t + 1 < nt) __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      load_frags(P ^ 1, smem + nxt * STAGE);
+#pragma unroll
+      for (int n_ = 0; n_ < NT; ++n_)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+          acc[n_][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[P][n_], af[P][mt], acc[n_][mt], 0, 0, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, PEA_GEMM_ILV_HEAD, 0);
+#pragma unroll
+      for (int i = 0; i < MT + NT; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, PEA_GEMM_ILV_M, 0);
+      }
+      __builtin_amdgcn_sched_group_barrier(0x008, MT * NT, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      cur = nxt;
+    };
+    for (int t = 0; t < nt; t += 2) {
+      kstep(std::integral_constant<int, 0>{}, t);
+      kstep(std::integral_constant<int, 1>{}, t + 1);
+    }
+    // ---- accumulator exchange through the ring (every wave is past its last fragment read behind the first barrier).  The half
+    // a wave hands over / keeps is a compile-time index on either side of a wave-uniform branch (a runtime index into the
+    // accumulator array would go through scratch).
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    char* const mine = smem + (size_t)wave * (MH * NT * 1024) + lane * 16;
+    const char* const theirs = smem + (size_t)(wk == 0 ? wave + WM * WN : wave - WM * WN) * (MH * NT * 1024) + lane * 16;
+    f32x4 fin[NT][MH];
+    auto xchg = [&](auto give_c, auto keep_c) {
+      constexpr int G0 = decltype(give_c)::value, K0 = decltype(keep_c)::value;
+#pragma unroll
+      for (int j = 0; j < MH; ++j)
+#pragma unroll
+        for (int n_ = 0; n_ < NT; ++n_) *(f32x4*)(mine + (j * NT + n_) * 1024) = acc[n_][G0 + j];
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+#pragma unroll
+      for (int j = 0; j < MH; ++j)
+#pragma unroll
+        for (int n_ = 0; n_ < NT; ++n_) {
+          const f32x4 o = *(const f32x4*)(theirs + (j * NT + n_) * 1024);
+          const f32x4 a = acc[n_][K0 + j];
+          // (half 0) + (half 1) on both sides: the same bits whichever wave finishes these rows
+          if constexpr (K0 == 0) fin[n_][j] = (f32x4){a[0] + o[0], a[1] + o[1], a[2] + o[2], a[3] + o[3]};
+          else fin[n_][j] = (f32x4){o[0] + a[0], o[1] + a[1], o[2] + a[2], o[3] + a[3]};
+        }
+    };
+    if (wk == 0) xchg(std::integral_constant<int, MH>{}, std::integral_constant<int, 0>{});
+    else xchg(std::integral_constant<int, 0>{}, std::integral_constant<int, MH>{});
+    const int keep0 = wk == 0 ? 0 : MH;
+    gemm_epilogue16_fast<MH, NT>(p, fin, bm * BM + wr * (BM / WM) + keep0 * 16, bn * BN + wc * (BN / WN), r16, q4);
+    return;
+  }
   if constexpr (M16) {
     // 16x16x32 MFMAs (sustain a higher clock than 32x32x16 on this chip) with a (BM/WM) x (BN/WN) wave tile built
     // from 16-row fragments: e.g. 2 x 2 waves of 64 x 80 on the 128 x 160 tile -> 9 fragment reads per 20 MFMAs
@@ -1160,20 +1266,22 @@ __global__ __launch_bounds__((WM * WN + LW) * 64, MINW) void gemm_lc_kernel(cons
 }
 
 template <int MODE, int BM, int BN, int WM, int WN, int LW, int S, bool PROBE16 = false, bool M16 = false, int MINW = 1,
-          bool LNF = false>
+          bool LNF = false, bool KSW = false>
 static int launch_lc(const GemmP& p, hipStream_t stream) {
   constexpr int lds = S * (BM + BN) * 128;
   static_assert(lds <= 160 * 1024, "LDS budget");
+  static_assert(!KSW || WM * WN * 2 * (BM / WM / 32) * (BN / WN / 16) * 1024 <= lds, "K-split exchange fits the ring");
   static bool attr_set = false;
   if (!attr_set) {
-    HIPCHK(hipFuncSetAttribute((const void*)gemm_lc_kernel<MODE, BM, BN, WM, WN, LW, S, PROBE16, M16, MINW, LNF>,
+    HIPCHK(hipFuncSetAttribute((const void*)gemm_lc_kernel<MODE, BM, BN, WM, WN, LW, S, PROBE16, M16, MINW, LNF, KSW>,
                                hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     attr_set = true;
   }
+  SHAPECHK(!KSW || (p.epi_fast && p.ksplit <= 1), "gemm: the K-split form needs the batched-load epilogue");
   const int grid = cdiv(p.M, BM) * cdiv(p.N, BN);
-  hipLaunchKernelGGL((gemm_lc_kernel<MODE, BM, BN, WM, WN, LW, S, PROBE16, M16, MINW, LNF>),
-                     dim3(grid, p.ksplit > 1 ? p.ksplit : 1), dim3((WM * WN + LW) * 64), lds, stream, p.A, p.W, p.lda, p.ldw, p.M, p.N, p.K,
-                     p.ksplit, p.debug, p);
+  hipLaunchKernelGGL((gemm_lc_kernel<MODE, BM, BN, WM, WN, LW, S, PROBE16, M16, MINW, LNF, KSW>),
+                     dim3(grid, p.ksplit > 1 ? p.ksplit : 1), dim3((WM * WN * (KSW ? 2 : 1) + LW) * 64), lds, stream, p.A, p.W, p.lda, p.ldw,
+                     p.M, p.N, p.K, p.ksplit, p.debug, p);
   return PEA_OK;
 }
 
@@ -1719,6 +1827,7 @@ extern "C" void pea_debug_set_gemm_variant(int v) { g_gemm_variant = v; }
     case 35: rc = launch_lcp<MODE, 128, 160, 4, 2, 4, 3, 0, 1>(p, stream); break; /* deferred epilogue */ \
     case 39: rc = launch_lc<MODE, 192, 160, 4, 2, 4, 3, false, true>(p, stream); break; /* 48 x 80 wave tiles: row counts that leave 128- / 256-row tiles a partial round */ \
     case 40: rc = launch_lcp<MODE, 192, 160, 4, 2, 4, 3, 0, 0, 1>(p, stream); break; \
+    case 41: rc = launch_lc<MODE, 128, 160, 2, 2, 4, 3, false, true, 1, false, true>(p, stream); break; /* intra-workgroup K split */ \
     case 36: rc = launch_lcp<MODE, 128, 160, 2, 2, 2, 2, 0, 0, 1, 2>(p, stream); break; /* two workgroups per CU */ \
     case 37: rc = launch_lcp<MODE, 128, 128, 2, 2, 2, 2, 0, 0, 1, 2>(p, stream); break; \
     default: rc = launch_lc<MODE, 128, 128, 2, 2, 4, 4, false, true>(p, stream); break; \
@@ -1763,6 +1872,9 @@ static int pick_variant(const GemmP& p) {
                                                        : (t256 * 100 >= cdiv(t256, cus) * cus * 85 ? r256 : r128));
     if (r192 * 10 <= cur * 9) return t192 <= cus ? 39 : 40;
   }
+  // one round of 128 x 160 tiles with a long K: the K-split form (41); PEA_GEMM_KSW_MINK sets the threshold (0 = never)
+  static const int ksw_mink = getenv("PEA_GEMM_KSW_MINK") ? atoi(getenv("PEA_GEMM_KSW_MINK")) : 0;
+  if (t128 <= cus && ksw_mink > 0 && p.K >= ksw_mink && (p.K / BK) % 2 == 0 && p.epi_fast && p.ksplit <= 1 && p.mode == 0 && t128 > cus * 5 / 8) return 41;
   if (t128 <= cus) return lean ? 35 : 25;            // at most one 128x160 tile per CU
   static const bool one_round_persistent = getenv("PEA_GEMM_ONE_ROUND_PERSISTENT") != nullptr;   // experiment: 27 instead of 24
   if (t256 <= cus) return t256 > cus * 3 / 4 ? (one_round_persistent ? 27 : 24) : (lean ? 35 : 28);

@@ -151,6 +151,31 @@ def test_gemm_every_variant_ragged_shapes(ops, variant):
         L.pea_debug_set_gemm_variant(-1)
 
 
+def test_gemm_intra_workgroup_k_split_variant(ops):
+    """Variant 41 (opt-in, PEA_GEMM_KSW_MINK): eight consumer waves of 64 x 80 over half a K-step each on the 128 x 160 one-tile
+    kernel, accumulators exchanged through the ring behind the loop.  Batched-load epilogue only (bf16 output; bias / residual),
+    an even number of K-steps; ragged M and N, fewer and more tiles than CUs, a deep K."""
+    from pea_diffusion_amd._lib import lib
+    L = lib()
+    g = torch.Generator().manual_seed(41)
+    try:
+        for (M, N, K) in [(4096, 1280, 1280), (1000, 336, 256), (300, 160, 128), (4100, 1296, 384), (520, 1280, 10240)]:
+            a = torch.randn(M, K, generator=g).to(BF)
+            w = (torch.randn(N, K, generator=g) * K ** -0.5).to(BF)
+            bias = torch.randn(N, generator=g)
+            res = torch.randn(M, N, generator=g).to(BF)
+            ref = a.float() @ w.float().T
+            L.pea_debug_set_gemm_variant(41)
+            close_bf16(f"v41 plain {M}x{N}x{K}", ops.gemm(a.cuda(), w.cuda()), ref)
+            close_bf16(f"v41 bias {M}x{N}x{K}", ops.gemm(a.cuda(), w.cuda(), bias=bias.cuda()), ref + bias)
+            out = ops.gemm(a.cuda(), w.cuda(), bias=bias.cuda(), res=res.cuda())
+            close_bf16(f"v41 bias+res {M}x{N}x{K}", out, ref + bias + res.float())
+            again = ops.gemm(a.cuda(), w.cuda(), bias=bias.cuda(), res=res.cuda())
+            assert torch.equal(out, again), "K-split GEMM is not bit-reproducible"
+    finally:
+        L.pea_debug_set_gemm_variant(-1)
+
+
 # ------------------------------------------------------------------------------------ conv
 def _nhwc(x_nchw):
     return x_nchw.permute(0, 2, 3, 1).contiguous()
