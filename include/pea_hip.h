@@ -348,7 +348,8 @@ int pea_unet_input_grads(void* unet, void** d_ehs, void** d_text);
  * cross-attention to_k / to_v projections (one GEMM over encoder_hidden_states; diffusers Attention.to_k/to_v of every
  * BasicTransformerBlock under train_sdxl_zh.py:397): d(K|V) fp32 [rows][cols], rows = differentiated samples x context length;
  * which 1: all ResnetBlock2D.time_emb_proj layers (one GEMM over silu(emb)): fp32 [differentiated samples][cols].  out may be
- * NULL (sizes only).  pea_unet_stacked_layout: diffusers weight key and column block of member i; PEA_E_NOTFOUND past the end. */
+ * NULL (sizes only; PEA_E_NOTFOUND for which 1 with a buffer on a graph whose time embedding receives no gradient, e.g. SD1.5).
+ * pea_unet_stacked_layout: diffusers weight key and column block of member i; PEA_E_NOTFOUND past the end. */
 int pea_unet_stacked_grad(void* unet, int which, float* out, long long* rows, int* cols, void* stream);
 int pea_unet_stacked_layout(void* unet, int which, int i, char* name, int name_len, int* col_off, int* cols);
 int pea_unet_memory(void* unet, long long* weight_bytes, long long* act_bytes, long long* grad_bytes, int* n_ops);

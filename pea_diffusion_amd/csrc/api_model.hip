@@ -502,6 +502,10 @@ int pea_unet_stacked_grad(void* h, int which, float* out, long long* rows, int* 
   if (rows) *rows = r;
   if (cols) *cols = t.cols;
   if (!out) return PEA_OK;
+  if (which == 1 && !t.rg) {           /* e.g. SD1.5: no text_time conditioning, the adapter's outputs never reach the time embedding */
+    pea_set_error("pea_unet_stacked_grad: the time embedding receives no gradient on this graph");
+    return PEA_E_NOTFOUND;
+  }
   if (!u->needs_grad || !t.g || !u->tproj_grad) { pea_set_error("pea_unet_stacked_grad: no backward pass has run on this context"); return PEA_E_STATE; }
   if (which == 0) return launch_cast_bf16_f32(t.g, out, r * t.cols, (hipStream_t)stream);
   HIPCHK(hipMemcpyAsync(out, u->tproj_grad, sizeof(float) * (size_t)r * t.cols, hipMemcpyDeviceToDevice, (hipStream_t)stream));

@@ -67,7 +67,10 @@ def hip_layer_grads(tr):
         rows, cols = ctypes.c_longlong(), ctypes.c_int()
         check(L_.pea_unet_stacked_grad(ctx, which, None, ctypes.byref(rows), ctypes.byref(cols), stream_ptr()))
         buf = torch.empty(rows.value, cols.value, device="cuda")
-        check(L_.pea_unet_stacked_grad(ctx, which, ptr(buf), ctypes.byref(rows), ctypes.byref(cols), stream_ptr()))
+        rc = L_.pea_unet_stacked_grad(ctx, which, ptr(buf), ctypes.byref(rows), ctypes.byref(cols), stream_ptr())
+        if which == 1 and rc == -5:              # PEA_E_NOTFOUND: the time embedding receives no gradient on this graph (SD1.5)
+            continue
+        check(rc)
         torch.cuda.synchronize()
         i = 0
         while True:
@@ -80,11 +83,28 @@ def hip_layer_grads(tr):
     return res
 
 
-def check_layer_grads(tr, store, B, limit, tag=""):
+def _unpad_heads(h, C):
+    """HIP stores heads whose width is not a multiple of 64 zero-padded (SD1.5: 40 / 80 / 160 -> 64 / 128 / 192): drop the
+    padding columns of a [rows][heads * dp] block so that it lines up with the oracle's [rows][heads * d]"""
+    Cp = h.shape[-1]
+    if Cp == C:
+        return h
+    for heads in (8, 5, 10, 20, 4, 2, 1, 16):
+        if C % heads == 0 and Cp % heads == 0 and Cp // heads == 64 * ((C // heads + 63) // 64):
+            d, dp = C // heads, Cp // heads
+            pad = h.reshape(h.shape[0], heads, dp)
+            assert float(pad[:, :, d:].abs().max()) == 0.0, "gradient in the padding columns of a padded head"
+            return pad[:, :, :d].reshape(h.shape[0], C)
+    raise AssertionError((Cp, C))
+
+
+def check_layer_grads(tr, store, B, limit, tag="", kv_only=False):
     """every cross-attention layer's dK and dV and every resnet's time-embedding gradient, EACH against the oracle's: a layer
     that contributes nothing (or twice) to d(encoder_hidden_states) / d(text_embeds) fails here although it would move the
     flat adapter gradient by a percent or two only"""
     hip = hip_layer_grads(tr)
+    if kv_only:                                  # (a model whose time embedding receives no gradient: SD1.5)
+        hip = {k: v for k, v in hip.items() if not k.endswith("time_emb_proj.weight")}
     assert sorted(hip.keys()) == sorted(store.keys()), (sorted(set(hip) ^ set(store))[:6], len(hip), len(store))
     worst = {"kv": (0.0, ""), "temb": (0.0, "")}
     for k, g in store.items():
@@ -93,7 +113,8 @@ def check_layer_grads(tr, store, B, limit, tag=""):
             want, got, fam = g.reshape(B, -1), h, "temb"
         else:
             want = g.reshape(B, -1, g.shape[-1])
-            got = h.reshape(B, -1, h.shape[-1])[:, :want.shape[1]]              # (a merged context is as long as the teacher's)
+            got = _unpad_heads(h, g.shape[-1])
+            got = got.reshape(B, -1, got.shape[-1])[:, :want.shape[1]]          # (a merged context is as long as the teacher's)
             fam = "kv"
         e = rel_l2(got, want)
         if e > worst[fam][0]:
@@ -742,8 +763,32 @@ def _sd15_step_check(cfg_name, B, L, hw, enc_dim, hidden, tol_fwd, tol_grad):
     bq = dict(batch)
     for k in ("enc", "enc_uncond", "teacher_ehs", "teacher_neg"):
         bq[k] = batch[k].to(torch.bfloat16).float()
+    store, handles = layer_grad_hooks(us)
     ref = training_step_ref(ad_ref, us, ut, bq, ou.cast_hook_ref, nan_guard=True)
     ref["loss"].backward()
+    # every cross-attention K / V projection on its own (SD1.5 has no text_time conditioning: no gradient reaches the time
+    # embedding, the oracle holds none for time_emb_proj and the HIP path computes none), held to the bf16-storage noise floor
+    # of that layer: the deepest levels are 8 x 8 tokens (tiny15: 2 x 2), where a layer's dK / dV is a sum over few queries
+    # and a fixed limit would be wrong by an order of magnitude either way (measured: 2.7e-2 on mid_block ... to_v at full size)
+    assert store and all(not k.endswith("time_emb_proj.weight") for k in store)
+    from oracle.bf16_store import bf16_storage
+    ref32 = (ref["noise_pred"].detach().clone(), ref["noise_pred_teacher"].detach().clone(),
+             torch.cat([p.grad.reshape(-1) for p in ad_ref.parameters()]).clone(), dict(store))
+    hip_layers = {k: _unpad_heads(v, store[k].shape[-1]) for k, v in hip_layer_grads(tr).items() if k in store}
+    assert sorted(hip_layers) == sorted(store)
+    hip_eps = (tr.export("eps_student").cpu(), tr.export("eps_teacher").cpu())
+    g_hip = ad.flat_grad.float().cpu().clone()
+    store.clear()
+    ad_ref.zero_grad()
+    with bf16_storage():
+        rq = training_step_ref(ad_ref, us, ut, bq, ou.cast_hook_ref, nan_guard=True)
+        rq["loss"].backward()
+    for h in handles:
+        h.remove()
+    st16 = (rq["noise_pred"].detach(), rq["noise_pred_teacher"].detach(),
+            torch.cat([p.grad.reshape(-1) for p in ad_ref.parameters()]), dict(store))
+    check_against_storage_floor(f"{cfg_name}", B, hip_eps, g_hip, hip_layers, ref32, st16,
+                                factor=2.0 if cfg_name.startswith("tiny") else None)
     assert len(ref["taps_s"]) == 2 * len(cfg.block_out_channels) + 1 == hs.num_taps
     e = rel_l2(tr.export("eps_student"), ref["noise_pred"])
     print(f"[{cfg_name} step] eps_student rel_l2={e:.3e}")
@@ -755,7 +800,7 @@ def _sd15_step_check(cfg_name, B, L, hw, enc_dim, hidden, tol_fwd, tol_grad):
         # teacher == student checkpoint: the KD terms are small differences of nearly equal bf16 tensors, so they
         # carry an absolute noise floor; 2 % relative + 0.5 % of the total loss
         assert abs(h - r) <= 2e-2 * abs(r) + 5e-3 * total, k
-    g_ref = torch.cat([p.grad.reshape(-1) for p in ad_ref.parameters()])
+    g_ref = ref32[2]                                # the fp32 oracle's flat adapter gradient
     eg = rel_l2(ad.flat_grad, g_ref)
     print(f"   adapter grad rel_l2={eg:.3e}")
     assert eg < tol_grad
