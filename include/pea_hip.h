@@ -89,6 +89,23 @@ int pea_op_conv3x3(const void* x, const void* w, void* y, int B, int Hs, int Ws,
 /* torch conv weight [Co][Ci][3][3] fp32 -> bf16 packed; dgrad=1 gives the flipped/transposed
  * weights w'[ci][(2-ky,2-kx,co)] whose forward conv is the data gradient.                        */
 int pea_op_pack_conv(const float* w, void* out, int Co, int Ci, int dgrad, void* stream);
+/* conv3x3(interpolate(x, 2x nearest)) -- diffusers Upsample2D, the UNet's up_blocks[i].upsamplers[0] -- in its sub-pixel
+ * form: per output parity (y&1, x&1) a 2 x 2 kernel of summed taps over the SOURCE (16 tap products per source pixel and
+ * channel pair instead of the 36 of a 3 x 3 gather over the upsampled image).
+ *   pea_op_pack_conv_subpixel: [Co][Ci][3][3] fp32 -> bf16 [4][Co][4 Ci] (dgrad = 0) or [Ci][16 Co] (dgrad = 1), 16 Co Ci elements
+ *   pea_op_upconv_subpixel:    x NHWC [B][Hs][Ws][Cin] -> y depth-to-space [B][Hs][Ws][(y&1)*2+(x&1)][Cout]  (+ bias)
+ *   pea_op_upconv_subpixel_dgrad: dy (that layout) -> dx NHWC [B][Hs][Ws][Cin] (+ res, may alias dx)                     */
+int pea_op_pack_conv_subpixel(const float* w, void* out, int Co, int Ci, int dgrad, void* stream);
+/* torch.cat([a, b], dim=1) on NHWC rows (unet_2d_blocks.py: the skip concatenation of every up-block resnet) and its backward
+ * (da (+)= dy[:, :C1], db (+)= dy[:, C1:]; NULL = skip).  aH, aW != 0: a / da are stored depth-to-space at full resolution
+ * aH x aW (an upsampler output in its sub-pixel form); the result rows are plain NHWC.                                   */
+int pea_op_concat2(const void* a, int C1, const void* b, int C2, void* y, long long rows, int aH, int aW, void* stream);
+int pea_op_split2(const void* dy, int C1, int C2, void* da, int accum_a, void* db, int accum_b, long long rows, int aH,
+                  int aW, void* stream);
+int pea_op_upconv_subpixel(const void* x, const void* w, void* y, int B, int Hs, int Ws, int Cin, int Cout,
+                           const float* bias, void* stream);
+int pea_op_upconv_subpixel_dgrad(const void* dy, const void* wt, void* dx, int B, int Hs, int Ws, int Cin, int Cout,
+                                 const void* res, void* stream);
 int pea_op_conv_in(const float* x_nchw, const float* w, const float* bias, void* y_nhwc, int B, int Cin, int H,
                    int W, int Cout, void* stream);
 int pea_op_conv_out(const void* x_nhwc, const float* w_packed, const float* bias, float* y_nchw, int B, int Cin,
@@ -338,6 +355,14 @@ int pea_unet_num_taps(void* unet);
 int pea_unet_tap_name(void* unet, int k, char* name, int name_len);
 int pea_unet_tap_info(void* unet, int k, void** data, void** grad, int* B, int* H, int* W, int* C);
 int pea_unet_tap_export_nchw(void* unet, int k, int grad, float* out, void* stream);
+/* Storage layout behind pea_unet_tap_info's pointers: 0 = NHWC [B][H][W][C]; 1 = depth-to-space [B][H/2][W/2][(y&1)*2+(x&1)][C]
+ * (the output of an upsampler conv in its sub-pixel form -- Upsample2D = interpolate(2x nearest) + conv, diffusers
+ * resnet.py; reference call site: the u<i> hooks of train_sdxl_zh.py:79-84).  -1 = bad handle / index.  The NCHW export above
+ * and the import below hide the layout; only callers that touch the raw pointers need it.                                  */
+int pea_unet_tap_layout(void* unet, int k);
+/* write a gradient seed for tap k (fp32 NCHW [B or bwd_batch][C][H][W]) into the tap's gradient buffer in its storage layout;
+ * then pass bit k in pea_unet_backward's tap_seed_mask                                                                   */
+int pea_unet_tap_import_grad_nchw(void* unet, int k, const float* src, void* stream);
 /* reverse pass: d(loss)/d(eps) in `deps` (fp32 NCHW, may be NULL) plus tap gradient seeds already
  * written into the tap grad buffers for every k with bit k set in tap_seed_mask.  Results:
  * pea_unet_input_grads -> bf16 d(ehs) [B][L][cross], d(text_embeds) [B][pooled].                 */

@@ -8,7 +8,9 @@ oracle runs in fp32 throughout, so an end-to-end comparison against it carries t
 (measured 6-8e-3 relative L2) and cannot see a defect smaller than that.  Inside `with bf16_storage():` the restatements
 round a tensor to bf16 wherever the product stores one -- forward value and, through autograd, the gradient that flows back
 through the same point -- and keep fp32 wherever the product fuses (conv + bias + time-embedding row, projection + bias +
-residual, GroupNorm + SiLU, GEGLU from the fp32 accumulators).  Outside the context `st()` is the identity: the fp32 oracle
+residual, GroupNorm + SiLU, GEGLU from the fp32 accumulators).  One WEIGHT tensor is part of it: the upsampler convs are
+stored as four 2 x 2 kernels of summed taps (sub-pixel form), each sum rounded to bf16 -- unet_ref.Upsample2D._subpixel
+restates exactly that in this mode.  Outside the context `st()` is the identity: the fp32 oracle
 and every golden fixture generated from it are bit-for-bit what they were.
 
 What the mode does NOT model (left in the tightened tolerances): the order of fp32 accumulation inside a kernel, the flash

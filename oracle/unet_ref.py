@@ -29,9 +29,9 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 try:                                               # (imported as oracle.unet_ref by the tests, as a plain module by scripts)
-    from .bf16_store import bf16_storage, st as _st  # noqa: F401  (identity unless inside `with bf16_storage():`)
+    from .bf16_store import bf16_storage, enabled as _bf16_on, st as _st  # noqa: F401  (identity unless inside `with bf16_storage():`)
 except ImportError:                                # pragma: no cover
-    from bf16_store import bf16_storage, st as _st  # noqa: F401
+    from bf16_store import bf16_storage, enabled as _bf16_on, st as _st  # noqa: F401
 
 
 @dataclass
@@ -268,7 +268,26 @@ class Upsample2D(nn.Module):
         self.conv = nn.Conv2d(c, c, 3, padding=1)
 
     def forward(self, x):
+        if _bf16_on():
+            return _st(self._subpixel(x))
         return _st(self.conv(F.interpolate(x, scale_factor=2.0, mode="nearest")))
+
+    def _subpixel(self, x):
+        """bf16-storage mode only: the product STORES this conv's weights as four 2 x 2 kernels of summed taps, one per output
+        parity (output row 2s + py reads source rows {s-1: w0, s: w1 + w2} for py = 0 and {s: w0 + w1, s+1: w2} for py = 1; the
+        same along x), each sum rounded to bf16 (pea_diffusion_amd/csrc/elementwise.hip: pack_conv_subpix_kernel).  In exact
+        arithmetic this equals conv(interpolate(x)); here the merged taps carry their storage rounding."""
+        w, b = self.conv.weight, self.conv.bias
+        B, _, H, W = x.shape
+        y = x.new_empty(B, w.shape[0], 2 * H, 2 * W)
+        taps = {0: ((0,), (1, 2)), 1: ((0, 1), (2,))}
+        for py in (0, 1):
+            for px in (0, 1):
+                k = torch.stack([torch.stack([sum(w[:, :, ky, kx] for ky in taps[py][dy] for kx in taps[px][dx])
+                                              for dx in (0, 1)], -1) for dy in (0, 1)], -2)          # [Co][Ci][dy][dx]
+                xp = F.pad(x, (1 - px, px, 1 - py, py))                                               # (left, right, top, bottom)
+                y[:, :, py::2, px::2] = F.conv2d(xp, _st(k), b)
+        return y
 
 
 class DownBlock(nn.Module):

@@ -460,7 +460,26 @@ int pea_unet_tap_export_nchw(void* h, int k, int grad, float* out, void* stream)
   const bf16* src = grad ? t.g : t.d;
   NOTNULL(src, "pea_unet_tap_export_nchw(grad)");
   const int nb = (grad && u->bwd_batch > 0) ? u->bwd_batch : t.B;    // gradients exist for the differentiated samples only
-  return launch_nhwc_to_nchw_f32(src, out, nb, t.H * t.W, t.cols, (hipStream_t)stream);
+  return launch_nhwc_to_nchw_f32(src, out, nb, t.H * t.W, t.cols, (hipStream_t)stream, t.d2s ? t.H : 0, t.d2s ? t.W : 0);
+}
+int pea_unet_tap_layout(void* h, int k) {
+  Tape* u = (Tape*)h;
+  if (!u || k < 0 || k >= (int)u->taps.size()) return -1;
+  return u->tn[u->taps[k]].d2s ? 1 : 0;
+}
+int pea_unet_tap_import_grad_nchw(void* h, int k, const float* src, void* stream) {
+  NOTNULL(h, "pea_unet_tap_import_grad_nchw");
+  NOTNULL(src, "pea_unet_tap_import_grad_nchw");
+  Tape* u = (Tape*)h;
+  if (k < 0 || k >= (int)u->taps.size()) {
+    pea_set_error("pea_unet_tap_import_grad_nchw: tap %d out of range", k);
+    return PEA_E_INVALID;
+  }
+  { int rc = u->ensure_acts(); if (rc != PEA_OK) return rc; }
+  const Tn& t = u->tn[u->taps[k]];
+  NOTNULL(t.g, "pea_unet_tap_import_grad_nchw(no gradient buffer)");
+  const int nb = u->bwd_batch > 0 ? u->bwd_batch : t.B;
+  return launch_nchw_f32_to_nhwc(src, t.g, nb, t.H * t.W, t.cols, (hipStream_t)stream, t.d2s ? t.H : 0, t.d2s ? t.W : 0);
 }
 int pea_unet_backward(void* h, const float* deps, unsigned tap_seed_mask, void* stream) {
   NOTNULL(h, "pea_unet_backward");

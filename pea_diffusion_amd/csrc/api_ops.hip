@@ -142,6 +142,51 @@ int pea_op_conv3x3(const void* x, const void* w, void* y, int B, int Hs, int Ws,
   return launch_gemm(p, (hipStream_t)stream);
 }
 
+// conv3x3(nearest_2x(x)) in its sub-pixel form (elementwise.hip: pack_conv_subpix_kernel; the tape's OP_CONV3 p1 == 2):
+// x [B][Hs][Ws][Cin] -> y depth-to-space [B][Hs][Ws][4][Cout];  w = pea_op_pack_conv_subpixel(dgrad = 0)
+int pea_op_upconv_subpixel(const void* x, const void* w, void* y, int B, int Hs, int Ws, int Cin, int Cout,
+                           const float* bias, void* stream) {
+  GemmP p;
+  memset(&p, 0, sizeof(p));
+  p.mode = 1; p.A = (const bf16*)x; p.ldw = 4 * Cin; p.ldc = 4 * Cout;
+  p.Hs = Hs; p.Ws = Ws; p.Cin = Cin; p.Ho = Hs; p.Wo = Ws; p.stride = 1; p.kside = 2;
+  p.M = B * Hs * Ws; p.N = Cout; p.K = 4 * Cin; p.alpha = 1.f; p.bias = bias; p.rows_per_batch = Hs * Ws;
+  int rc = pea_zero_page(&p.zeros);
+  if (rc) return rc;
+  for (int pl = 0; pl < 4; ++pl) {
+    p.W = (const bf16*)w + (size_t)pl * Cout * 4 * Cin;
+    p.C = (bf16*)y + (size_t)pl * Cout;
+    p.pad_off = pl >> 1; p.pad_dx = (pl & 1) - (pl >> 1);
+    rc = launch_gemm(p, (hipStream_t)stream);
+    if (rc) return rc;
+  }
+  return PEA_OK;
+}
+// its data gradient: dy depth-to-space [B][Hs][Ws][4][Cout] -> dx [B][Hs][Ws][Cin] (+ res);  wt = pea_op_pack_conv_subpixel(dgrad = 1)
+int pea_op_upconv_subpixel_dgrad(const void* dy, const void* wt, void* dx, int B, int Hs, int Ws, int Cin, int Cout,
+                                 const void* res, void* stream) {
+  GemmP p;
+  memset(&p, 0, sizeof(p));
+  p.mode = 1; p.A = (const bf16*)dy; p.W = (const bf16*)wt; p.ldw = 16 * Cout; p.C = dx; p.ldc = Cin;
+  p.Hs = Hs; p.Ws = Ws; p.Cin = Cout; p.pix = 4 * Cout; p.kside = 4; p.Ho = Hs; p.Wo = Ws; p.stride = 1; p.pad_off = 1;
+  p.M = B * Hs * Ws; p.N = Cin; p.K = 16 * Cout; p.alpha = 1.f; p.rows_per_batch = Hs * Ws;
+  p.res = (const bf16*)res; p.ldres = Cin;
+  int rc = pea_zero_page(&p.zeros);
+  if (rc) return rc;
+  return launch_gemm(p, (hipStream_t)stream);
+}
+// channel concat / its backward; aH, aW != 0: the FIRST operand is stored depth-to-space at full resolution aH x aW
+int pea_op_concat2(const void* a, int C1, const void* b, int C2, void* y, long long rows, int aH, int aW, void* stream) {
+  return launch_concat2((const bf16*)a, C1, (const bf16*)b, C2, (bf16*)y, rows, (hipStream_t)stream, aH, aW);
+}
+int pea_op_split2(const void* dy, int C1, int C2, void* da, int accum_a, void* db, int accum_b, long long rows, int aH,
+                  int aW, void* stream) {
+  return launch_split2((const bf16*)dy, C1, C2, (bf16*)da, accum_a, (bf16*)db, accum_b, rows, (hipStream_t)stream, aH, aW);
+}
+int pea_op_pack_conv_subpixel(const float* w, void* out, int Co, int Ci, int dgrad, void* stream) {
+  return launch_pack_conv_subpix(w, (bf16*)out, Co, Ci, dgrad, (hipStream_t)stream);
+}
+
 int pea_op_pack_conv(const float* w, void* out, int Co, int Ci, int dgrad, void* stream) {
   return dgrad ? launch_pack_conv_dgrad(w, (bf16*)out, Co, Ci, (hipStream_t)stream)
                : launch_pack_conv_fwd(w, (bf16*)out, Co, Ci, (hipStream_t)stream);

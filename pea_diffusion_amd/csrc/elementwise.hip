@@ -105,18 +105,29 @@ int launch_gelu_bwd(const bf16* x, const bf16* dy, bf16* dx, long long n, int ac
 }
 
 // ---- concat / split along the channel (last) dimension
+// Depth-to-space storage of an upsampler output (the sub-pixel form of the upsample-folded conv, model.hip OP_CONV3 p1 == 2):
+// [B][H/2][W/2][4 = (y & 1) * 2 + (x & 1)][C] instead of [B][H][W][C].  Seen as rows of C elements, full-resolution pixel row r
+// lives at row d2s_row(r).  The first operand of concat2 / split2 may be stored that way (H, W = the full resolution; 0 = plain).
+__device__ __forceinline__ long long d2s_row(long long r, int H, int W) {
+  const long long t = r / W;
+  const int x = (int)(r - t * W);
+  const long long b = t / H;
+  const int y = (int)(t - b * H);
+  return (((b * (H >> 1) + (y >> 1)) * (W >> 1) + (x >> 1)) << 2) + ((y & 1) << 1) + (x & 1);
+}
 __global__ void concat2_kernel(const bf16* __restrict__ a, int C1, const bf16* __restrict__ b, int C2,
-                               bf16* __restrict__ y, long long rows) {
+                               bf16* __restrict__ y, long long rows, int aH, int aW) {
   const int ck = (C1 + C2) / 8, k1 = C1 / 8;
   EW_LOOP(i, rows * ck) {
     const long long r = i / ck;
     const int c = (int)(i - r * ck);
-    const bf16x8 v = c < k1 ? *(const bf16x8*)(a + r * C1 + c * 8) : *(const bf16x8*)(b + r * C2 + (c - k1) * 8);
+    const long long ra = aW ? d2s_row(r, aH, aW) : r;
+    const bf16x8 v = c < k1 ? *(const bf16x8*)(a + ra * C1 + c * 8) : *(const bf16x8*)(b + r * C2 + (c - k1) * 8);
     *(bf16x8*)(y + r * (C1 + C2) + c * 8) = v;
   }
 }
 __global__ void split2_kernel(const bf16* __restrict__ dy, int C1, int C2, bf16* __restrict__ da, int accum_a,
-                              bf16* __restrict__ db, int accum_b, long long rows) {
+                              bf16* __restrict__ db, int accum_b, long long rows, int aH, int aW) {
   const int ck = (C1 + C2) / 8, k1 = C1 / 8;
   EW_LOOP(i, rows * ck) {
     const long long r = i / ck;
@@ -124,7 +135,7 @@ __global__ void split2_kernel(const bf16* __restrict__ dy, int C1, int C2, bf16*
     bf16x8 v = *(const bf16x8*)(dy + r * (C1 + C2) + c * 8);
     bf16* dst;
     int acc;
-    if (c < k1) { dst = da ? da + r * C1 + c * 8 : nullptr; acc = accum_a; }
+    if (c < k1) { dst = da ? da + (aW ? d2s_row(r, aH, aW) : r) * C1 + c * 8 : nullptr; acc = accum_a; }
     else { dst = db ? db + r * C2 + (c - k1) * 8 : nullptr; acc = accum_b; }
     if (!dst) continue;
     if (acc) {
@@ -135,20 +146,22 @@ __global__ void split2_kernel(const bf16* __restrict__ dy, int C1, int C2, bf16*
     *(bf16x8*)dst = v;
   }
 }
-int launch_concat2(const bf16* a, int C1, const bf16* b, int C2, bf16* y, long long rows, hipStream_t s) {
+int launch_concat2(const bf16* a, int C1, const bf16* b, int C2, bf16* y, long long rows, hipStream_t s, int aH, int aW) {
   SHAPECHK(C1 % 8 == 0 && C2 % 8 == 0, "concat: C %% 8");
+  SHAPECHK(!aW || (aH % 2 == 0 && aW % 2 == 0 && rows % ((long long)aH * aW) == 0), "concat: depth-to-space operand %d x %d", aH, aW);
   PROF_BEGIN(6, 0.0, 4.0 * rows * (C1 + C2), s);
-  hipLaunchKernelGGL(concat2_kernel, dim3(EW_GRID(rows * ((C1 + C2) / 8))), dim3(256), 0, s, a, C1, b, C2, y, rows);
+  hipLaunchKernelGGL(concat2_kernel, dim3(EW_GRID(rows * ((C1 + C2) / 8))), dim3(256), 0, s, a, C1, b, C2, y, rows, aH, aW);
   PROF_END(s);
   HIPCHK(hipGetLastError());
   return PEA_OK;
 }
 int launch_split2(const bf16* dy, int C1, int C2, bf16* da, int accum_a, bf16* db, int accum_b, long long rows,
-                  hipStream_t s) {
+                  hipStream_t s, int aH, int aW) {
   SHAPECHK(C1 % 8 == 0 && C2 % 8 == 0, "split: C %% 8");
+  SHAPECHK(!aW || (aH % 2 == 0 && aW % 2 == 0 && rows % ((long long)aH * aW) == 0), "split: depth-to-space operand %d x %d", aH, aW);
   PROF_BEGIN(6, 0.0, 4.0 * rows * (C1 + C2), s);
   hipLaunchKernelGGL(split2_kernel, dim3(EW_GRID(rows * ((C1 + C2) / 8))), dim3(256), 0, s, dy, C1, C2, da, accum_a,
-                     db, accum_b, rows);
+                     db, accum_b, rows, aH, aW);
   PROF_END(s);
   HIPCHK(hipGetLastError());
   return PEA_OK;
@@ -232,17 +245,37 @@ int launch_transpose_f32_bf16(const float* x, bf16* y, int R, int C, int ldy, hi
   return PEA_OK;
 }
 
-__global__ void nhwc_to_nchw_f32_kernel(const bf16* __restrict__ x, float* __restrict__ y, int B, int HW, int C) {
+__global__ void nhwc_to_nchw_f32_kernel(const bf16* __restrict__ x, float* __restrict__ y, int B, int HW, int C, int dH, int dW) {
   const long long total = (long long)B * HW * C;
   EW_LOOP(i, total) {
     const int p = (int)(i % HW);
     const int c = (int)((i / HW) % C);
     const int b = (int)(i / ((long long)HW * C));
-    y[i] = (float)x[((long long)b * HW + p) * C + c];
+    const long long r = (long long)b * HW + p;
+    y[i] = (float)x[(dW ? d2s_row(r, dH, dW) : r) * C + c];
   }
 }
-int launch_nhwc_to_nchw_f32(const bf16* x, float* y, int B, int HW, int C, hipStream_t s) {
-  hipLaunchKernelGGL(nhwc_to_nchw_f32_kernel, dim3(EW_GRID((long long)B * HW * C)), dim3(256), 0, s, x, y, B, HW, C);
+// dH, dW != 0: x is stored depth-to-space (see d2s_row) at full resolution dH x dW (HW = dH * dW)
+int launch_nhwc_to_nchw_f32(const bf16* x, float* y, int B, int HW, int C, hipStream_t s, int dH, int dW) {
+  SHAPECHK(!dW || (long long)dH * dW == HW, "nhwc_to_nchw: depth-to-space %d x %d vs HW=%d", dH, dW, HW);
+  hipLaunchKernelGGL(nhwc_to_nchw_f32_kernel, dim3(EW_GRID((long long)B * HW * C)), dim3(256), 0, s, x, y, B, HW, C, dH, dW);
+  HIPCHK(hipGetLastError());
+  return PEA_OK;
+}
+// the inverse, fp32 NCHW -> the bf16 storage layout (gradient seeds of a feature tap)
+__global__ void nchw_f32_to_nhwc_kernel(const float* __restrict__ x, bf16* __restrict__ y, int B, int HW, int C, int dH, int dW) {
+  const long long total = (long long)B * HW * C;
+  EW_LOOP(i, total) {
+    const int p = (int)(i % HW);
+    const int c = (int)((i / HW) % C);
+    const int b = (int)(i / ((long long)HW * C));
+    const long long r = (long long)b * HW + p;
+    y[(dW ? d2s_row(r, dH, dW) : r) * C + c] = (bf16)x[i];
+  }
+}
+int launch_nchw_f32_to_nhwc(const float* x, bf16* y, int B, int HW, int C, hipStream_t s, int dH, int dW) {
+  SHAPECHK(!dW || (long long)dH * dW == HW, "nchw_to_nhwc: depth-to-space %d x %d vs HW=%d", dH, dW, HW);
+  hipLaunchKernelGGL(nchw_f32_to_nhwc_kernel, dim3(EW_GRID((long long)B * HW * C)), dim3(256), 0, s, x, y, B, HW, C, dH, dW);
   HIPCHK(hipGetLastError());
   return PEA_OK;
 }
@@ -275,6 +308,36 @@ int launch_pack_conv_dgrad(const float* w, bf16* y, int Co, int Ci, hipStream_t 
 }
 int launch_pack_conv_out(const float* w, float* y, int Co, int Ci, hipStream_t s) {
   hipLaunchKernelGGL(pack_conv_kernel, dim3(EW_GRID(9LL * Co * Ci)), dim3(256), 0, s, w, nullptr, y, Co, Ci, 2, Ci);
+  HIPCHK(hipGetLastError());
+  return PEA_OK;
+}
+
+// Sub-pixel form of conv3x3(nearest_2x(x)) (diffusers Upsample2D: interpolate, then conv).  Output pixel (2s + py) reads the
+// upsampled rows 2s + py - 1 .. 2s + py + 1, i.e. the SOURCE rows  py = 0: {s-1: w0, s: w1 + w2},  py = 1: {s: w0 + w1, s+1: w2}
+// (and the same along x): per output parity pl = py * 2 + px a 2 x 2 kernel of summed taps over the source -- 16 tap products per
+// source pixel and output channel where the folded 3 x 3 form executes 36.  The sums are taken in fp32 and rounded once.
+//   mode 0 (forward):  y[pl][co][(dy * 2 + dx) * Ci + ci]            window origin of parity pl: source (s - 1 + py, s - 1 + px)
+//   mode 1 (dgrad):    y[ci][(pl * 4 + ty * 2 + tx) * Co + co] = forward[pl][co][(1 - ty, 1 - tx)][ci]   (GemmP::kside == 4)
+__global__ void pack_conv_subpix_kernel(const float* __restrict__ w, bf16* __restrict__ y, int Co, int Ci, int mode) {
+  const long long total = 16LL * Co * Ci;
+  EW_LOOP(i, total) {
+    const int ci = (int)(i % Ci);
+    const int co = (int)((i / Ci) % Co);
+    const int t = (int)(i / ((long long)Ci * Co));       // pl * 4 + dy * 2 + dx
+    const int pl = t >> 2, dy = (t >> 1) & 1, dx = t & 1, py = pl >> 1, px = pl & 1;
+    // taps of the 3-wide kernel that fall on source offset d of parity q:  q=0: d=0 {0}, d=1 {1,2};  q=1: d=0 {0,1}, d=1 {2}
+    const int y0 = py == 0 ? (dy == 0 ? 0 : 1) : (dy == 0 ? 0 : 2), y1 = py == 0 ? (dy == 0 ? 0 : 2) : (dy == 0 ? 1 : 2);
+    const int x0 = px == 0 ? (dx == 0 ? 0 : 1) : (dx == 0 ? 0 : 2), x1 = px == 0 ? (dx == 0 ? 0 : 2) : (dx == 0 ? 1 : 2);
+    const float* src = w + ((long long)co * Ci + ci) * 9;
+    float acc = 0.f;
+    for (int ky = y0; ky <= y1; ++ky)
+      for (int kx = x0; kx <= x1; ++kx) acc += src[ky * 3 + kx];
+    if (mode == 0) y[((long long)pl * Co + co) * 4 * Ci + (dy * 2 + dx) * Ci + ci] = (bf16)acc;
+    else y[(long long)ci * 16 * Co + (pl * 4 + (1 - dy) * 2 + (1 - dx)) * Co + co] = (bf16)acc;
+  }
+}
+int launch_pack_conv_subpix(const float* w, bf16* y, int Co, int Ci, int dgrad, hipStream_t s) {
+  hipLaunchKernelGGL(pack_conv_subpix_kernel, dim3(EW_GRID(16LL * Co * Ci)), dim3(256), 0, s, w, y, Co, Ci, dgrad ? 1 : 0);
   HIPCHK(hipGetLastError());
   return PEA_OK;
 }

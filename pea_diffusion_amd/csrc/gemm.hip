@@ -779,6 +779,19 @@ __device__ __forceinline__ void gemm_epilogue16_lean(const GemmP& p, f32x4 (&acc
   }
 }
 
+// Conv gather (mode 1): elements per source pixel, and tap -> (window offset, channel-block offset).
+//   kside 0 / 3: 3 x 3 window, tap = ky * 3 + kx
+//   kside 2:     2 x 2 window, tap = ky * 2 + kx      (one output parity of an upsample-folded conv in its sub-pixel form)
+//   kside 4:     16 taps = 4 parity blocks x 2 x 2 over a depth-to-space source [B][Hs][Ws][4][Cin] (pix = 4 Cin): block pl = (py, px)
+//                reads the window shifted by (-py, -px) at channel offset pl * Cin -- the data gradient of the sub-pixel form
+__device__ __forceinline__ int conv_pix(const GemmP& p) { return p.pix ? p.pix : p.Cin; }
+__device__ __forceinline__ void conv_tap(const GemmP& p, int tap, int& ky, int& kx, int& cblk) {
+  cblk = 0;
+  if (p.kside == 2) { ky = tap >> 1; kx = tap & 1; }
+  else if (p.kside == 4) { const int pl = tap >> 2; ky = ((tap >> 1) & 1) - (pl >> 1); kx = (tap & 1) - (pl & 1); cblk = pl * p.Cin; }
+  else { ky = tap / 3; kx = tap - ky * 3; }
+}
+
 #if PEA_GEMM_BUFFER_DMA && defined(__HIP_DEVICE_COMPILE__)
 // Buffer resource of one row-tile's A operand.  The resource starts at the tile's first row (plain GEMM) or at the first
 // sample the tile touches (conv gather), so the per-lane 32-bit offsets only span one tile / a couple of samples and the
@@ -794,7 +807,7 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t tile_rsrc(const GemmP& p, int 
     left = (long long)(p.M - org) * p.lda;
   } else {
     const int hw = p.Ho * p.Wo;
-    const long long sample = (long long)p.Hs * p.Ws * p.Cin;
+    const long long sample = (long long)p.Hs * p.Ws * conv_pix(p);
     org = __builtin_amdgcn_readfirstlane((bm * BM) / hw);
     first = org * sample;
     left = (p.M / hw - org) * sample;
@@ -892,8 +905,8 @@ __global__ __launch_bounds__((WM * WN * (KSW ? 2 : 1) + LW) * 64, MINW) void gem
         const int rem = gm - b * hw;
         const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
         a_iy0[j] = oy * p.stride - 1 + p.pad_off;
-        a_ix0[j] = ox * p.stride - 1 + p.pad_off;
-        a_off[j] = ((b - org) * p.Hs * p.Ws * p.Cin + chunk * 8) * 2;
+        a_ix0[j] = ox * p.stride - 1 + p.pad_off + p.pad_dx;
+        a_off[j] = ((b - org) * p.Hs * p.Ws * conv_pix(p) + chunk * 8) * 2;
       }
     }
 #pragma unroll
@@ -915,14 +928,16 @@ __global__ __launch_bounds__((WM * WN * (KSW ? 2 : 1) + LW) * 64, MINW) void gem
         c0 = k0 - tap * p.Cin;
         if (tap != tap_cur) {
           tap_cur = tap;
-          const int ky = tap / 3, kx = tap - ky * 3;
+          int ky, kx, cblk;
+          conv_tap(p, tap, ky, kx, cblk);
+          const int pix = conv_pix(p);
 #pragma unroll
           for (int j = 0; j < PA; ++j) {
             const int iy = a_iy0[j] + ky, ix = a_ix0[j] + kx;
             bool ok = ((unsigned)iy < (unsigned)Hv) && ((unsigned)ix < (unsigned)Wv);
             if (p.parity) ok = ok && (((iy | ix) & 1) == 0);
             const int sy = iy >> p.shift, sx = ix >> p.shift;
-            tap_off[j] = ok ? a_off[j] + (sy * p.Ws + sx) * p.Cin * 2 : 0x7f000000;
+            tap_off[j] = ok ? a_off[j] + ((sy * p.Ws + sx) * pix + cblk) * 2 : 0x7f000000;
           }
         }
       }
@@ -956,8 +971,8 @@ __global__ __launch_bounds__((WM * WN * (KSW ? 2 : 1) + LW) * 64, MINW) void gem
         const int rem = gm - b * hw;
         const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
         a_iy0[j] = oy * p.stride - 1 + p.pad_off;
-        a_ix0[j] = ox * p.stride - 1 + p.pad_off;
-        a_src[j] = p.A + (long long)b * p.Hs * p.Ws * p.Cin + chunk * 8;
+        a_ix0[j] = ox * p.stride - 1 + p.pad_off + p.pad_dx;
+        a_src[j] = p.A + (long long)b * p.Hs * p.Ws * conv_pix(p) + chunk * 8;
       }
     }
 #pragma unroll
@@ -974,9 +989,9 @@ __global__ __launch_bounds__((WM * WN * (KSW ? 2 : 1) + LW) * 64, MINW) void gem
       int ky = 0, kx = 0, c0 = 0;
       if (MODE == 1) {
         const int tap = k0 / p.Cin;
-        c0 = k0 - tap * p.Cin;
-        ky = tap / 3;
-        kx = tap - ky * 3;
+        int cblk;
+        conv_tap(p, tap, ky, kx, cblk);
+        c0 = k0 - tap * p.Cin + cblk;
       }
 #pragma unroll
       for (int j = 0; j < PA; ++j) {
@@ -988,7 +1003,7 @@ __global__ __launch_bounds__((WM * WN * (KSW ? 2 : 1) + LW) * 64, MINW) void gem
           bool ok = ((unsigned)iy < (unsigned)Hv) && ((unsigned)ix < (unsigned)Wv);
           if (p.parity) ok = ok && (((iy | ix) & 1) == 0);
           const int sy = iy >> p.shift, sx = ix >> p.shift;
-          src = ok ? a_src[j] + ((long long)sy * p.Ws + sx) * p.Cin + c0 : p.zeros;
+          src = ok ? a_src[j] + ((long long)sy * p.Ws + sx) * conv_pix(p) + c0 : p.zeros;
         }
         __builtin_amdgcn_global_load_lds(PEA_GLB(src), PEA_LDS(base + (lw * PA + j) * 1024), 16, 0, 0);
       }
@@ -1422,8 +1437,8 @@ __global__ __launch_bounds__((WM * WN + LW + SW) * 64, (OCC == 2 ? 3 : 1)) void 
           const int rem = gm - b * hw;
           const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
           a_iy0[j] = oy * p.stride - 1 + p.pad_off;
-          a_ix0[j] = ox * p.stride - 1 + p.pad_off;
-          a_off[j] = ((b - org) * p.Hs * p.Ws * p.Cin + chunk * 8) * 2;
+          a_ix0[j] = ox * p.stride - 1 + p.pad_off + p.pad_dx;
+          a_off[j] = ((b - org) * p.Hs * p.Ws * conv_pix(p) + chunk * 8) * 2;
         }
       }
 #pragma unroll
@@ -1446,14 +1461,16 @@ __global__ __launch_bounds__((WM * WN + LW + SW) * 64, (OCC == 2 ? 3 : 1)) void 
         c0 = k0 - tap * p.Cin;
         if (tap != tap_cur) {
           tap_cur = tap;
-          const int ky = tap / 3, kx = tap - ky * 3;
+          int ky, kx, cblk;
+          conv_tap(p, tap, ky, kx, cblk);
+          const int pix = conv_pix(p);
 #pragma unroll
           for (int j = 0; j < PA; ++j) {
             const int iy = a_iy0[j] + ky, ix = a_ix0[j] + kx;
             bool ok = ((unsigned)iy < (unsigned)Hv) && ((unsigned)ix < (unsigned)Wv);
             if (p.parity) ok = ok && (((iy | ix) & 1) == 0);
             const int sy = iy >> p.shift, sx = ix >> p.shift;
-            tap_off[j] = ok ? a_off[j] + (sy * p.Ws + sx) * p.Cin * 2 : 0x7f000000;     // out of range: the load returns zeros
+            tap_off[j] = ok ? a_off[j] + ((sy * p.Ws + sx) * pix + cblk) * 2 : 0x7f000000;     // out of range: the load returns zeros
           }
         }
       }
@@ -1490,8 +1507,8 @@ __global__ __launch_bounds__((WM * WN + LW + SW) * 64, (OCC == 2 ? 3 : 1)) void 
           const int rem = gm - b * hw;
           const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
           a_iy0[j] = oy * p.stride - 1 + p.pad_off;
-          a_ix0[j] = ox * p.stride - 1 + p.pad_off;
-          a_src[j] = p.A + (long long)b * p.Hs * p.Ws * p.Cin + chunk * 8;
+          a_ix0[j] = ox * p.stride - 1 + p.pad_off + p.pad_dx;
+          a_src[j] = p.A + (long long)b * p.Hs * p.Ws * conv_pix(p) + chunk * 8;
         }
       }
 #pragma unroll
@@ -1509,9 +1526,9 @@ __global__ __launch_bounds__((WM * WN + LW + SW) * 64, (OCC == 2 ? 3 : 1)) void 
       int ky = 0, kx = 0, c0 = 0;
       if (MODE == 1) {
         const int tap = k0 / p.Cin;
-        c0 = k0 - tap * p.Cin;
-        ky = tap / 3;
-        kx = tap - ky * 3;
+        int cblk;
+        conv_tap(p, tap, ky, kx, cblk);
+        c0 = k0 - tap * p.Cin + cblk;
       }
 #pragma unroll
       for (int j = 0; j < PA; ++j) {
@@ -1523,7 +1540,7 @@ __global__ __launch_bounds__((WM * WN + LW + SW) * 64, (OCC == 2 ? 3 : 1)) void 
           bool ok = ((unsigned)iy < (unsigned)Hv) && ((unsigned)ix < (unsigned)Wv);
           if (p.parity) ok = ok && (((iy | ix) & 1) == 0);
           const int sy = iy >> p.shift, sx = ix >> p.shift;
-          src = ok ? a_src[j] + ((long long)sy * p.Ws + sx) * p.Cin + c0 : p.zeros;
+          src = ok ? a_src[j] + ((long long)sy * p.Ws + sx) * conv_pix(p) + c0 : p.zeros;
         }
         __builtin_amdgcn_global_load_lds(PEA_GLB(src), PEA_LDS(base + (lw * PA + j) * 1024), 16, 0, 0);
       }
@@ -1904,22 +1921,27 @@ int launch_gemm(const GemmP& p_in, hipStream_t stream) {
   if (p0.mode == 0) {
     SHAPECHK(p0.lda % 8 == 0, "gemm: lda=%d must be a multiple of 8", p0.lda);
   } else {
-    SHAPECHK(p0.Cin % BK == 0 && p0.K == 9 * p0.Cin, "conv: Cin=%d must be a multiple of %d and K=9*Cin", p0.Cin, BK);
+    const int ntaps = p0.kside == 2 ? 4 : (p0.kside == 4 ? 16 : 9);
+    SHAPECHK(p0.kside == 0 || p0.kside == 2 || p0.kside == 3 || p0.kside == 4, "conv: kside=%d", p0.kside);
+    SHAPECHK(p0.Cin % BK == 0 && p0.K == ntaps * p0.Cin, "conv: Cin=%d must be a multiple of %d and K=%d*Cin", p0.Cin, BK, ntaps);
+    SHAPECHK(p0.pix == 0 || (p0.pix % 8 == 0 && p0.pix >= (p0.kside == 4 ? 4 : 1) * p0.Cin), "conv: pixel stride %d vs Cin=%d", p0.pix, p0.Cin);
+    SHAPECHK(p0.kside < 4 || (!p0.shift && !p0.parity && p0.stride == 1), "conv: the 16-tap form is stride 1 on a plain source");
     SHAPECHK(p0.zeros != nullptr, "conv: zero page missing");
     SHAPECHK(p0.M % (p0.Ho * p0.Wo) == 0, "conv: M=%d not a multiple of Ho*Wo", p0.M);
   }
   {
     // 32-bit buffer offsets of the DMA loaders (tile_rsrc): relative to the row tile for A, to the tensor for W
     const long long hw = p0.mode ? (long long)p0.Ho * p0.Wo : 1;
-    const long long span = p0.mode ? (256 / hw + 2) * (long long)p0.Hs * p0.Ws * p0.Cin * 2 : 256LL * p0.lda * 2;
-    const long long whole = p0.mode ? (p0.M / hw) * (long long)p0.Hs * p0.Ws * p0.Cin * 2 : (long long)p0.M * p0.lda * 2;
+    const long long pix = p0.pix ? p0.pix : p0.Cin;
+    const long long span = p0.mode ? (256 / hw + 2) * (long long)p0.Hs * p0.Ws * pix * 2 : 256LL * p0.lda * 2;
+    const long long whole = p0.mode ? (p0.M / hw) * (long long)p0.Hs * p0.Ws * pix * 2 : (long long)p0.M * p0.lda * 2;
     SHAPECHK((span < whole ? span : whole) <= 0x7f000000LL, "gemm: one row tile of A spans %lld bytes (limit 0x7f000000)", span);
     SHAPECHK((long long)p0.N * p0.ldw * 2 <= 0x7fffffffLL, "gemm: W of %d x %d exceeds the 2 GB buffer range", p0.N, p0.ldw);
   }
   {
     // algorithmic work: 2*M*N*K; a transposed (zero-stuffed) conv only has 1/4 of its taps real
     double fl = 2.0 * p0.M * (double)p0.N * p0.K * (p0.parity ? 0.25 : 1.0);
-    double by = 2.0 * ((double)p0.M * p0.N + (double)p0.N * p0.K + (p0.mode ? (double)p0.M * p0.K / 9.0 : (double)p0.M * p0.K));
+    double by = 2.0 * ((double)p0.M * p0.N + (double)p0.N * p0.K + (p0.mode ? (double)p0.M * p0.K / (p0.kside == 2 ? 4.0 : (p0.kside == 4 ? 4.0 : 9.0)) : (double)p0.M * p0.K));
     if (g_prof_on) { g_prof_tag[0] = p0.M; g_prof_tag[1] = p0.N; g_prof_tag[2] = p0.K; g_prof_tag[3] = (p0.res ? 1 : 0) | (p0.bias ? 2 : 0) | (p0.rowvec ? 4 : 0); }
     PROF_BEGIN(p0.mode ? 1 : 0, fl, by, stream);
   }

@@ -58,6 +58,7 @@ struct WSlot {
   bf16* wt = nullptr; int ldwt = 0;      // dgrad layout    [K][N] (conv: [Ci][9*Co] flipped)
   bool need_wt = false;
   bool loaded = false;
+  bool subpix = false;       // CONV3 of an upsampler in its sub-pixel form: w = [4 parities][Co][4 Ci], wt = [Ci][16 Co] (launch_pack_conv_subpix)
   // arena bookkeeping
   size_t off_f32 = (size_t)-1, off_w = (size_t)-1, off_wt = (size_t)-1;
   int fused_parent = -1;     // index of the fused matrix this slot is a row block of
@@ -100,6 +101,8 @@ struct Tn {
   const bf16* gpend = nullptr;   // gradient passed on by a residual, not yet added into g (Tape::backward)
   size_t off_d = 0, off_g = 0;
   bool external = false;     // no buffer of its own
+  bool d2s = false;          // stored depth-to-space, [B][H/2][W/2][(y&1)*2 + (x&1)][cols]: the output of a sub-pixel upsampler conv
+                             // (OP_CONV3 p1 == 2).  Readers: OP_CONCAT's first operand, the KD-loss taps (elementwise per sample)
 };
 
 enum OpKind { OP_CONV_IN, OP_CONV3, OP_LINEAR, OP_GN, OP_LN, OP_ATTN, OP_GEGLU, OP_CONCAT, OP_SILU, OP_TEMB,

@@ -20,6 +20,13 @@ int pea_zero_page(const bf16** out);
 
 // ============================================================================ graph construction
 namespace {
+// The UNet's upsampler convs run in their sub-pixel form (Builder::conv, ups == 2) unless PEA_UPCONV_SUBPIXEL=0 (A/B switch:
+// the nearest-2x upsample folded into a 3 x 3 gather over the virtual image, 2.25 x the tap products).
+static bool upconv_subpixel() {
+  static const bool on = !(getenv("PEA_UPCONV_SUBPIXEL") && atoi(getenv("PEA_UPCONV_SUBPIXEL")) == 0);
+  return on;
+}
+
 struct Builder {
   Tape& u;
   explicit Builder(Tape& un) : u(un) {}
@@ -121,6 +128,9 @@ struct Builder {
     o.a = x; o.out = out;
     return out;
   }
+  // ups: 1 = nearest-2x upsample folded into the 3 x 3 gather;  2 = the same conv in its sub-pixel form (four 2 x 2 kernels of
+  // summed taps, one per output parity: 16 tap products per source pixel instead of 36) -- the output tensor is stored
+  // depth-to-space (Tn::d2s), which only concat() and the feature taps may read
   int conv(int x, const std::string& pfx, int Cout, int stride, int ups, int rv = -1, int rv_off = 0, int res = -1) {
     const Tn& t = u.tn[x];
     const int Hv = ups ? t.H * 2 : t.H, Wv = ups ? t.W * 2 : t.W;
@@ -128,6 +138,7 @@ struct Builder {
     const int w = conv3(pfx + ".weight", Cout, t.cols);
     const int b = vec(pfx + ".bias", Cout);
     const int out = T((long long)t.B * Ho * Wo, Cout, t.B, Ho, Wo);
+    if (ups == 2) { u.slots[w].subpix = true; u.tn[out].d2s = true; }
     Op& o = push(OP_CONV3);
     o.a = x; o.w = w; o.bias = b; o.out = out; o.p0 = stride; o.p1 = ups; o.rv = rv; o.rv_off = rv_off; o.res = res;
     return out;
@@ -690,7 +701,7 @@ int Tape::build() {
       x = bd.resnet(x, p + ".resnets." + std::to_string(j), c.block_out[lvl]);
       if (c.up_cross[i]) x = bd.transformer(x, p + ".attentions." + std::to_string(j), c.heads[lvl], c.depth_up[i][j]);
     }
-    if (i != n - 1) x = bd.conv(x, p + ".upsamplers.0.conv", c.block_out[lvl], 1, 1);
+    if (i != n - 1) x = bd.conv(x, p + ".upsamplers.0.conv", c.block_out[lvl], 1, upconv_subpixel() ? 2 : 1);
     taps.push_back(x);
     tap_names.push_back("u" + std::to_string(i));
   }
@@ -766,6 +777,14 @@ void Tape::tag_q_prescale() {
 
 int Tape::alloc() {
   tag_q_prescale();
+  // a depth-to-space tensor (sub-pixel upsampler output) is only understood by concat's first operand and the feature taps
+  for (const Op& o : ops) {
+    const int in[5] = {o.a, o.kind == OP_LINEAR || o.kind == OP_EMBED ? -1 : o.b, o.kind == OP_LINEAR || o.kind == OP_EMBED ? -1 : o.c, o.res, o.rv};
+    for (int k = 0; k < 5; ++k) {
+      if (in[k] < 0 || in[k] >= (int)tn.size() || !tn[in[k]].d2s) continue;
+      SHAPECHK(o.kind == OP_CONCAT && k == 0 && o.a != o.b, "tape: op kind %d reads a depth-to-space tensor", o.kind);
+    }
+  }
   // ---- weights
   size_t off = 0;
   size_t max_numel = 0;
@@ -781,7 +800,8 @@ int Tape::alloc() {
       if (s.kind == W_VEC || s.kind == W_CONV_IN || s.kind == W_CONV_OUT) { s.off_f32 = off; off += al256(s.numel * 4); }
       else {
         const size_t st = s.kind == W_LINEAR ? (size_t)s.st_n * s.st_k
-                          : (s.kind == W_CONV3 && s.pad_dp ? (size_t)s.d0 * 9 * s.pad_dp : (size_t)s.numel);
+                          : (s.kind == W_CONV3 && s.subpix ? (size_t)16 * s.d0 * s.d1
+                          : (s.kind == W_CONV3 && s.pad_dp ? (size_t)s.d0 * 9 * s.pad_dp : (size_t)s.numel));
         s.off_w = off; off += al256(st * 2);
         if (s.need_wt) { s.off_wt = off; off += al256(st * 2); }
       }
@@ -812,11 +832,11 @@ int Tape::alloc() {
       if (s.off_f32 != (size_t)-1) s.f32 = (float*)(warena + s.off_f32);
       if (s.off_w != (size_t)-1) {
         s.w = (bf16*)(warena + s.off_w);
-        s.ldw = s.kind == W_CONV3 ? 9 * (s.pad_dp ? s.pad_dp : s.d1) : s.st_k;
+        s.ldw = s.kind == W_CONV3 ? (s.subpix ? 4 * s.d1 : 9 * (s.pad_dp ? s.pad_dp : s.d1)) : s.st_k;
       }
       if (s.off_wt != (size_t)-1) {
         s.wt = (bf16*)(warena + s.off_wt);
-        s.ldwt = s.kind == W_CONV3 ? 9 * s.d0 : s.st_n;
+        s.ldwt = s.kind == W_CONV3 ? (s.subpix ? 16 : 9) * s.d0 : s.st_n;
       }
     }
     for (LnFold& f : folds) {
@@ -855,7 +875,7 @@ void Tape::scratch_needs(size_t need[8]) {
       if (bwd_batch > 0) part_bytes = std::max(part_bytes, attention_bwd_scratch_bytes(bwd_batch, o.p0, o.p1, o.p2, o.p3));
     }
     if (o.kind == OP_LINEAR && o.p3 == 3 && o.c >= 0) geglu_elems = std::max(geglu_elems, (size_t)tn[o.c].rows * tn[o.c].cols);
-    if (o.kind == OP_CONV3 && o.p1 && tn[o.a].rg)
+    if (o.kind == OP_CONV3 && o.p1 == 1 && tn[o.a].rg)
       ups_elems = std::max(ups_elems, (size_t)tn[o.out].rows * tn[o.a].cols);
   }
   size_t gn_bytes = 256, cs_bytes = 256;
@@ -1046,6 +1066,11 @@ int Tape::load_weight(const char* name, const float* src, long long numel, hipSt
       }
       break;
     case W_CONV3:
+      if (w.subpix) {
+        RC(launch_pack_conv_subpix(src, w.w, w.d0, w.d1, 0, s));
+        if (w.wt) RC(launch_pack_conv_subpix(src, w.wt, w.d0, w.d1, 1, s));
+        break;
+      }
       RC(launch_pack_conv_fwd(src, w.w, w.d0, w.d1, s, w.pad_dp));
       if (w.wt) RC(launch_pack_conv_dgrad(src, w.wt, w.d0, w.d1, s));
       break;
@@ -1259,7 +1284,8 @@ int Tape::exec_ops(size_t begin, size_t end, bool skip_cached, hipStream_t s) {
         RC(launch_silu_fwd(tn[o.a].d, tn[o.out].d, tn[o.a].rows * tn[o.a].cols, s));
         break;
       case OP_CONCAT:
-        RC(launch_concat2(tn[o.a].d, tn[o.a].cols, tn[o.b].d, tn[o.b].cols, tn[o.out].d, tn[o.a].rows, s));
+        RC(launch_concat2(tn[o.a].d, tn[o.a].cols, tn[o.b].d, tn[o.b].cols, tn[o.out].d, tn[o.a].rows, s,
+                          tn[o.a].d2s ? tn[o.a].H : 0, tn[o.a].d2s ? tn[o.a].W : 0));
         break;
       case OP_CONV_IN:
         if (o.src == 1) {              // ControlNet conditioning image -> first (channel-padded) embedding tensor
@@ -1281,6 +1307,21 @@ int Tape::exec_ops(size_t begin, size_t end, bool skip_cached, hipStream_t s) {
         p.rows_per_batch = out.H * out.W; p.pad_off = o.p2;
         if (o.rv >= 0) { p.rowvec = tn[o.rv].d + o.rv_off; p.ldrv = tn[o.rv].cols; }
         if (o.res >= 0) { p.res = tn[o.res].d; p.ldres = tn[o.res].cols; }
+        if (o.p1 == 2) {
+          // sub-pixel form: one 2 x 2 conv over the SOURCE per output parity, written into that parity's channel block of the
+          // depth-to-space output (row stride 4 Cout).  pack_conv_subpix_kernel has the tap sums.
+          SHAPECHK(o.rv < 0 && o.res < 0 && !o.p3 && !o.p2 && o.p0 == 1, "unet: sub-pixel upsampler conv with an epilogue operand");
+          const int Cout = slots[o.w].d0;
+          p.shift = 0; p.kside = 2; p.Ho = a.H; p.Wo = a.W; p.M = (int)a.rows; p.K = 4 * a.cols; p.ldc = 4 * Cout;
+          p.rows_per_batch = a.H * a.W;
+          for (int pl = 0; pl < 4; ++pl) {
+            p.W = slots[o.w].w + (size_t)pl * Cout * 4 * a.cols;
+            p.C = out.d + (size_t)pl * Cout;
+            p.pad_off = pl >> 1; p.pad_dx = (pl & 1) - (pl >> 1);
+            RC(gemm(p, s));
+          }
+          break;
+        }
         RC(gemm(p, s));
         break;
       }
@@ -1472,7 +1513,8 @@ int Tape::backward(const float* deps, hipStream_t s) {
         }
         if (a.rg) RC(materialize(a));
         if (b.rg) RC(materialize(b));
-        RC(launch_split2(out.g, a.cols, b.cols, a.rg ? a.g : nullptr, a.gw, b.rg ? b.g : nullptr, b.gw, rb(a), s));
+        RC(launch_split2(out.g, a.cols, b.cols, a.rg ? a.g : nullptr, a.gw, b.rg ? b.g : nullptr, b.gw, rb(a), s,
+                         a.d2s ? a.H : 0, a.d2s ? a.W : 0));
         if (a.rg) a.gw = true;
         if (b.rg) b.gw = true;
         break;
@@ -1485,7 +1527,12 @@ int Tape::backward(const float* deps, hipStream_t s) {
           GemmP p; fill_gemm(p);
           p.mode = 1; p.A = out.g; p.W = w.wt; p.ldw = w.ldwt; p.Hs = out.H; p.Ws = out.W; p.Cin = out.cols;
           p.N = a.cols; p.K = 9 * out.cols; p.zeros = zeros; p.stride = 1;
-          if (o.p1) {            // upsample-folded conv: gradient at the upsampled resolution, then 2x2 sum
+          if (o.p1 == 2) {       // sub-pixel form: 16 taps (4 parity blocks x 2 x 2) over the depth-to-space d out, one launch
+            p.W = w.wt; p.ldw = w.ldwt; p.Hs = a.H; p.Ws = a.W; p.pix = 4 * out.cols; p.kside = 4; p.K = 16 * out.cols;
+            p.pad_off = 1; p.Ho = a.H; p.Wo = a.W; p.M = (int)rb(a); p.C = a.g; p.ldc = a.cols;
+            if (const bf16* ad = addend(a)) { p.res = ad; p.ldres = a.cols; }
+            RC(gemm(p, s));
+          } else if (o.p1) {     // upsample-folded conv: gradient at the upsampled resolution, then 2x2 sum
             p.Ho = out.H; p.Wo = out.W; p.M = (int)rb(out); p.C = ups_tmp; p.ldc = a.cols;
             RC(gemm(p, s));
             RC(materialize(a));

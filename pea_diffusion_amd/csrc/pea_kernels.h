@@ -26,6 +26,9 @@ struct GemmP {
   int pad_off;                     // 0: padding 1 on every side; 1: the VAE downsampler's (0,1,0,1) padding
   int shift;                       // virtual input = source upsampled by 2^shift (nearest) / zero-stuffed
   int parity;                      // 1: only even virtual coordinates are real (transposed stride-2 conv)
+  int kside;                       // tap window: 0 / 3 = 3 x 3;  2 = 2 x 2 (K = 4 Cin);  4 = 16 taps over a depth-to-space source (gemm.hip: conv_tap)
+  int pad_dx;                      // extra x offset of the tap window (pad_off moves both axes)
+  int pix;                         // elements per source pixel (0 = Cin)
   const bf16* zeros;               // >= 16 bytes of zeros (out-of-bounds taps)
   int debug;                       // timing experiments only (scripts/gemm_loop_probe.py)
   // fused GEGLU: the weight rows are interleaved (h_i, gate_i) so a lane's 4 consecutive columns are two pairs;
@@ -128,21 +131,25 @@ int launch_silu_bwd(const bf16* x, const bf16* dy, bf16* dx, long long n, int ac
 int launch_gelu_fwd(const bf16* x, bf16* y, long long n, hipStream_t s);
 int launch_gelu_bwd(const bf16* x, const bf16* dy, bf16* dx, long long n, int accum, hipStream_t s);
 // concat along channels: y[r][0:C1] = a[r], y[r][C1:C1+C2] = b[r]
-int launch_concat2(const bf16* a, int C1, const bf16* b, int C2, bf16* y, long long rows, hipStream_t s);
+// aH, aW != 0: the FIRST operand is stored depth-to-space at full resolution aH x aW (elementwise.hip: d2s_row)
+int launch_concat2(const bf16* a, int C1, const bf16* b, int C2, bf16* y, long long rows, hipStream_t s, int aH = 0, int aW = 0);
 // split-add (backward of concat): da[r] (+)= dy[r][0:C1]; db[r] (+)= dy[r][C1:]
 int launch_split2(const bf16* dy, int C1, int C2, bf16* da, int accum_a, bf16* db, int accum_b, long long rows,
-                  hipStream_t s);
+                  hipStream_t s, int aH = 0, int aW = 0);
 // 2x2 sum pooling NHWC (backward of nearest 2x upsample): x [B][2H][2W][C] -> y [B][H][W][C]
 int launch_sumpool2(const bf16* x, bf16* y, int B, int H, int W, int C, int accum, hipStream_t s);
 int launch_cast_f32_bf16(const float* x, bf16* y, long long n, hipStream_t s);
 int launch_cast_bf16_f32(const bf16* x, float* y, long long n, hipStream_t s);
 int launch_transpose_bf16(const bf16* x, bf16* y, int R, int C, int ldy, hipStream_t s);   // y[c][r] = x[r][c]
 int launch_transpose_f32_bf16(const float* x, bf16* y, int R, int C, int ldy, hipStream_t s);
-int launch_nhwc_to_nchw_f32(const bf16* x, float* y, int B, int HW, int C, hipStream_t s);
+int launch_nhwc_to_nchw_f32(const bf16* x, float* y, int B, int HW, int C, hipStream_t s, int dH = 0, int dW = 0);   // dH, dW: depth-to-space source
+int launch_nchw_f32_to_nhwc(const float* x, bf16* y, int B, int HW, int C, hipStream_t s, int dH = 0, int dW = 0);
 // conv weight repacks (fp32 torch layout [Co][Ci][3][3]) -> bf16
 int launch_pack_conv_fwd(const float* w, bf16* y, int Co, int Ci, hipStream_t s, int Cip = 0);   // Cip: stored (zero-padded) Ci          // y[co][(ky,kx,ci)]
 int launch_pack_conv_dgrad(const float* w, bf16* y, int Co, int Ci, hipStream_t s);        // y[ci][(2-ky,2-kx,co)]
 int launch_pack_conv_out(const float* w, float* y, int Co, int Ci, hipStream_t s);         // y[co][ky][kx][ci] fp32
+// sub-pixel form of conv3x3(nearest_2x(x)): forward y[4][Co][4 Ci], dgrad y[Ci][16 Co]  (elementwise.hip)
+int launch_pack_conv_subpix(const float* w, bf16* y, int Co, int Ci, int dgrad, hipStream_t s);
 // sinusoidal timestep embedding (cos|sin), out bf16 [n][dim]; t given as fp32 values
 int launch_timestep_embed(const float* t, bf16* y, int n, int dim, hipStream_t s);
 // x_t = sqrt(ac[t]) x0 + sqrt(1-ac[t]) eps   (fp32 NCHW), ac table fp32[1000]

@@ -95,6 +95,60 @@ def conv3x3(x, w_packed, bias=None, stride=1, upsample2x=False, transposed2=Fals
     return y
 
 
+def pack_conv_subpixel(w_fp32, dgrad=False):
+    """[Co,Ci,3,3] fp32 -> the sub-pixel form of conv3x3(nearest_2x(.)): [4,Co,4*Ci] (forward) or [Ci,16*Co] (data gradient)"""
+    Co, Ci = w_fp32.shape[:2]
+    out = torch.empty((Ci, 16 * Co) if dgrad else (4, Co, 4 * Ci), device=w_fp32.device, dtype=BF)
+    check(lib().pea_op_pack_conv_subpixel(ptr(w_fp32.contiguous()), ptr(out), Co, Ci, int(dgrad), stream_ptr()))
+    return out
+
+
+def upconv_subpixel(x, w_packed, bias=None):
+    """x [B,H,W,Cin] -> conv3x3(nearest_2x(x)) stored depth-to-space [B,H,W,4,Cout] (block (y&1)*2 + (x&1))"""
+    B, H, W, Cin = x.shape
+    Cout = w_packed.shape[1]
+    y = torch.empty(B, H, W, 4, Cout, device=x.device, dtype=BF)
+    check(lib().pea_op_upconv_subpixel(ptr(x), ptr(w_packed), ptr(y), B, H, W, Cin, Cout, ptr(bias), stream_ptr()))
+    return y
+
+
+def upconv_subpixel_dgrad(dy_d2s, wt_packed, res=None):
+    """dy [B,H,W,4,Cout] (depth-to-space) -> dx [B,H,W,Cin] (+ res)"""
+    B, H, W, _, Cout = dy_d2s.shape
+    Cin = wt_packed.shape[0]
+    dx = torch.empty(B, H, W, Cin, device=dy_d2s.device, dtype=BF)
+    check(lib().pea_op_upconv_subpixel_dgrad(ptr(dy_d2s), ptr(wt_packed), ptr(dx), B, H, W, Cin, Cout, ptr(res), stream_ptr()))
+    return dx
+
+
+def d2s_to_nhwc(y):
+    """[B,H,W,4,C] depth-to-space -> [B,2H,2W,C]"""
+    B, H, W, _, C = y.shape
+    return y.view(B, H, W, 2, 2, C).permute(0, 1, 3, 2, 4, 5).reshape(B, 2 * H, 2 * W, C)
+
+
+def nhwc_to_d2s(y):
+    """[B,2H,2W,C] -> [B,H,W,4,C]"""
+    B, H2, W2, C = y.shape
+    return y.view(B, H2 // 2, 2, W2 // 2, 2, C).permute(0, 1, 3, 2, 4, 5).reshape(B, H2 // 2, W2 // 2, 4, C).contiguous()
+
+
+def concat2(a, b, d2s_hw=None):
+    """rows-wise channel concat; d2s_hw = (H, W): `a` is stored depth-to-space at that full resolution"""
+    C1, C2 = a.shape[-1], b.shape[-1]
+    rows = b.numel() // C2
+    y = torch.empty(rows, C1 + C2, device=a.device, dtype=BF)
+    H, W = d2s_hw if d2s_hw else (0, 0)
+    check(lib().pea_op_concat2(ptr(a), C1, ptr(b), C2, ptr(y), rows, H, W, stream_ptr()))
+    return y
+
+
+def split2(dy, C1, C2, da=None, db=None, accum_a=False, accum_b=False, d2s_hw=None):
+    rows = dy.numel() // (C1 + C2)
+    H, W = d2s_hw if d2s_hw else (0, 0)
+    check(lib().pea_op_split2(ptr(dy), C1, C2, ptr(da), int(accum_a), ptr(db), int(accum_b), rows, H, W, stream_ptr()))
+
+
 def conv_in(x_nchw, w, bias):
     B, Cin, H, W = x_nchw.shape
     Cout = w.shape[0]

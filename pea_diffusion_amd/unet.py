@@ -224,6 +224,16 @@ class HipUNet:
         check(lib().pea_unet_tap_export_nchw(self._h, k, int(grad), ptr(out), stream_ptr()))
         return out
 
+    def set_tap_grad(self, k: int, seed: torch.Tensor):
+        """write a gradient seed (NCHW, the tap's shape) into tap k's gradient buffer in its storage layout; pass bit k in
+        `backward(..., tap_seed_mask)` afterwards"""
+        s = seed.detach().to(self.device, torch.float32).contiguous()
+        check(lib().pea_unet_tap_import_grad_nchw(self._h, k, ptr(s), stream_ptr()))
+
+    def tap_layout(self, k: int) -> int:
+        """0 = NHWC, 1 = depth-to-space (include/pea_hip.h: pea_unet_tap_layout)"""
+        return int(lib().pea_unet_tap_layout(self._h, k))
+
     def tap_pointers(self, k: int):
         d, g = ctypes.c_void_p(), ctypes.c_void_p()
         B, H, W, C = ctypes.c_int(), ctypes.c_int(), ctypes.c_int(), ctypes.c_int()

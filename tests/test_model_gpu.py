@@ -266,9 +266,7 @@ def _unet_backward_tiny(mode):
     hip(x.cuda(), t.cuda(), ehs.cuda(), added_cond_kwargs={k: v.cuda() for k, v in added.items()})
     mask = 0
     for i, k in enumerate(names):
-        _, gptr, (b, h, w, c) = hip.tap_pointers(i)
-        s = seeds[k].permute(0, 2, 3, 1).contiguous().cuda()
-        check(lib().pea_op_cast_f32_bf16(ptr(s), ctypes.c_void_p(gptr), s.numel(), stream_ptr()))
+        hip.set_tap_grad(i, seeds[k])        # (an upsampler tap is stored depth-to-space: the import hides the layout)
         mask |= 1 << i
     d_ehs, d_text = hip.backward(d_eps.cuda(), mask)
     e1, e2 = rel_l2(d_ehs, ehs_r.grad), rel_l2(d_text, te_r.grad)

@@ -33,6 +33,11 @@ def bfr(*shape, seed=0, scale=1.0):
     return (torch.randn(*shape, generator=g) * scale).to(BF)
 
 
+def rel_l2(got, ref):
+    got, ref = got.detach().float().cpu(), ref.detach().float().cpu()
+    return ((got - ref).pow(2).sum().sqrt() / (ref.pow(2).sum().sqrt() + 1e-30)).item()
+
+
 def close_bf16(name, got, ref, ulps=1.0):
     got = got.detach().float().cpu()
     ref = ref.detach().float()
@@ -245,6 +250,45 @@ def test_conv3x3_dgrad(ops, stride, ups):
     else:
         dx = ops.conv3x3(dyn, wd)
     close_bf16(f"conv3x3 dgrad s{stride} ups{ups}", dx, _nhwc(x.grad), ulps=2.0)
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout", [(2, 8, 8, 64, 128), (1, 16, 12, 128, 64), (3, 10, 14, 64, 64), (2, 32, 32, 320, 320)])
+def test_upconv_subpixel_fwd_dgrad(ops, B, H, W, Cin, Cout):
+    """conv3x3(interpolate(x, 2x nearest)) in its sub-pixel form (four 2 x 2 kernels of summed taps, depth-to-space output)
+    against F.conv2d on the upsampled image, forward and data gradient; the merged taps are bf16 roundings of fp32 sums, so the
+    comparison carries the weight-rounding term (2^-9 relative per merged tap) on top of the output rounding"""
+    x = bfr(B, Cin, H, W, seed=1).float().requires_grad_(True)
+    wq = (torch.randn(Cout, Cin, 3, 3, generator=torch.Generator().manual_seed(2)) * (9 * Cin) ** -0.5).to(BF).float()
+    bias = torch.randn(Cout, generator=torch.Generator().manual_seed(3))
+    ref = F.conv2d(F.interpolate(x, scale_factor=2.0, mode="nearest"), wq, bias, padding=1)
+    dy = bfr(*ref.shape, seed=7)
+    ref.backward(dy.float())
+    wp = ops.pack_conv_subpixel(wq.cuda())
+    y = ops.upconv_subpixel(_nhwc(x.detach().to(BF)).cuda(), wp, bias=bias.cuda())
+    e = rel_l2(ops.d2s_to_nhwc(y).float(), _nhwc(ref.detach()).cuda())
+    wd = ops.pack_conv_subpixel(wq.cuda(), dgrad=True)
+    res = bfr(B, H, W, Cin, seed=9)
+    dx = ops.upconv_subpixel_dgrad(ops.nhwc_to_d2s(_nhwc(dy).cuda()), wd, res=res.cuda())
+    e2 = rel_l2(dx.float(), (_nhwc(x.grad) + res.float()).cuda())
+    # against the folded 3 x 3 form of the same operator (the two differ by the weight roundings of the merged taps only)
+    y3 = ops.conv3x3(_nhwc(x.detach().to(BF)).cuda(), ops.pack_conv(wq.cuda()), bias=bias.cuda(), upsample2x=True)
+    e3 = rel_l2(ops.d2s_to_nhwc(y).float(), y3.float())
+    print(f"[upconv subpixel B{B} {H}x{W} {Cin}->{Cout}] fwd rel_l2={e:.2e} dgrad rel_l2={e2:.2e} vs 3x3 form {e3:.2e}")
+    assert e < 4e-3 and e2 < 5e-3 and e3 < 5e-3
+
+
+def test_concat_split_depth_to_space_operand(ops):
+    B, H, W, C1, C2 = 2, 6, 10, 64, 32
+    a, b = bfr(B, H, W, C1, seed=1).cuda(), bfr(B, H, W, C2, seed=2).cuda()
+    y = ops.concat2(ops.nhwc_to_d2s(a), b, d2s_hw=(H, W))
+    assert torch.equal(y.view(B, H, W, C1 + C2), torch.cat([a, b], dim=-1))
+    dy = bfr(B * H * W, C1 + C2, seed=3).cuda()
+    da0 = bfr(B, H // 2, W // 2, 4, C1, seed=4).cuda()
+    da, db = da0.clone(), torch.empty(B * H * W, C2, device="cuda", dtype=BF)
+    ops.split2(dy, C1, C2, da=da, db=db, accum_a=True, d2s_hw=(H, W))
+    want = (ops.d2s_to_nhwc(da0).float() + dy[:, :C1].view(B, H, W, C1).float()).to(BF)
+    assert torch.equal(ops.d2s_to_nhwc(da), want)
+    assert torch.equal(db, dy[:, C1:].contiguous())
 
 
 def test_conv_in_out(ops):

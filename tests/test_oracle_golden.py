@@ -243,3 +243,22 @@ def test_bf16_storage_mode_is_identity_when_off_and_rounds_values_and_gradients_
         assert torch.equal(x.grad, g.to(torch.bfloat16).float())
     assert not enabled()
 
+
+def test_oracle_subpixel_upsampler_restatement_is_exact():
+    """The bf16-storage mode of the oracle restates Upsample2D's conv as four 2 x 2 kernels of summed taps (what the HIP path
+    stores and executes: elementwise.hip pack_conv_subpix_kernel, gemm.hip conv_tap).  In float64 that restatement must equal
+    conv3x3(interpolate(x, 2x nearest)) to rounding, forward and input gradient, on ragged sizes."""
+    import torch
+    from oracle.unet_ref import Upsample2D
+    torch.manual_seed(0)
+    for (B, C, H, W) in [(2, 8, 5, 7), (1, 4, 1, 1), (3, 6, 2, 9)]:
+        m = Upsample2D(C).double()
+        x = torch.randn(B, C, H, W, dtype=torch.double, requires_grad=True)
+        y0, y1 = m(x), m._subpixel(x)
+        assert y0.shape == y1.shape == (B, C, 2 * H, 2 * W)
+        assert (y0 - y1).abs().max().item() < 1e-12
+        s = torch.randn_like(y0)
+        g0, = torch.autograd.grad((y0 * s).sum(), x)
+        g1, = torch.autograd.grad((y1 * s).sum(), x)
+        assert (g0 - g1).abs().max().item() < 1e-12
+
