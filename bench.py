@@ -727,6 +727,9 @@ def main():
                 "launches_per_step": g_n // nprof, "avg_launch_us": round(g_ms * 1e3 / max(g_n, 1), 2),
                 "gflop_per_launch": round(g_fl / max(g_n, 1) / 1e9, 3),
                 "ms_per_step_single_stream": round(g_ms / nprof, 2),
+                "flops_counted": "2*M*N*K of each launch as EXECUTED: a transposed stride-2 dgrad counts its real quarter of the taps, the "
+                                 "upsampler convs in sub-pixel form count 4 Cin (not 9 Cin) per output pixel -- 1.6 TFLOP per step fewer "
+                                 "than SURVEY 8d's formulation, which `step_frac` keeps using",
                 "method": "hip events around every launch on the launch stream; instrumented single-stream replay of the timed "
                           "steps (the timed region overlaps teacher and student passes on two streams)",
                 "families": family_rooflines(fams, nprof, sustained),
