@@ -297,3 +297,18 @@ def test_layernorm_fold_opt_in_matches_oracle(gpu):
                        capture_output=True, text=True, timeout=900, env=dict(os.environ, PEA_LN_FOLD="1"), cwd=root)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert " passed" in r.stdout and "failed" not in r.stdout
+
+
+def test_upconv_folded_form_opt_out_matches_oracle(gpu):
+    """PEA_UPCONV_SUBPIXEL=0 (read once per process -> child process): the upsampler convs as a 3 x 3 gather over the
+    nearest-2x virtual image with NHWC taps -- the form the sub-pixel default replaced -- must still meet the oracle, and the
+    tap import / export must behave the same through both layouts."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_model_gpu.py"), "-m", "gpu", "-x", "-q",
+                        "-k", "unet_forward_tiny or unet_backward_tiny or training_step_vs_oracle or merged_passes"],
+                       capture_output=True, text=True, timeout=900, env=dict(os.environ, PEA_UPCONV_SUBPIXEL="0"), cwd=root)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout and "failed" not in r.stdout
+

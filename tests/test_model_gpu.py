@@ -226,6 +226,15 @@ def test_unet_forward_tiny(gpu, B, L):
         print(f"   tap {k}: shape {tuple(got[k].shape)} rel_l2={ek:.3e}")
         assert got[k].shape == taps[k].shape and ek < 2e-2, k
     assert e < 2e-2
+    # storage layout behind the raw tap pointers: an up block that ends in an upsampler hands out the sub-pixel conv's
+    # depth-to-space tensor (1) unless PEA_UPCONV_SUBPIXEL=0; everything else is NHWC (0).  The export above hid it.
+    import os
+    subpixel = os.environ.get("PEA_UPCONV_SUBPIXEL", "1") != "0"
+    names = tap_names(cfg)
+    for i, k in enumerate(names):
+        ends_in_upsampler = k.startswith("u") and int(k[1:]) != n - 1
+        assert hip.tap_layout(i) == (1 if (ends_in_upsampler and subpixel) else 0), (k, hip.tap_layout(i))
+    assert hip.tap_layout(len(names)) == -1
 
 
 @pytest.mark.parametrize("geglu_bwd_fused", [1, 0])
