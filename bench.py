@@ -23,6 +23,14 @@ sys.path.insert(0, ROOT)
 # kernel arguments in device memory: the default of this ROCm stack (measured: unset = 1; 0 costs 3.3 ms per step over the ~2300
 # launches, profiles/r05_ab_dev_kernarg.log) -- stated here so that a box with another default runs the same configuration
 os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")    # dmabuf IPC: RCCL across processes on this host driver (before any HIP call)
+
+# exit codes of a rank (the launcher relays the first non-zero one): 2 usage, 3 the HBM plan does not fit, 4 the native RCCL
+# communicator failed under --collective native, 5 its rendezvous timed out, 124 the launcher's own deadline
+RC_COMM_FAILED, RC_COMM_TIMEOUT = 4, 5
+# keys every N-rank result line carries (asserted on the CPU dry-run line and on the GPU line: tests/test_dp_cpu.py, test_dist_gpu.py)
+NRANK_KEYS = ("n_gpus", "rccl_ranks", "collective", "control_plane", "allreduce_ms", "allreduce_exposed_ms", "allreduce_bytes",
+              "single_gpu_equivalent", "hbm_plan_gb_per_rank", "cores_per_rank")
 
 import torch  # noqa: E402
 
@@ -229,10 +237,15 @@ def launch_ranks(n, argv, timeout_s):
                 procs[i].kill()             # exactly the children started above
             break
         time.sleep(0.2)
+    reported = rc != 0
     for p in procs:
         p.wait()
         if p.returncode != 0 and rc == 0:
             rc = p.returncode
+    if rc != 0 and not reported:            # every rank had exited before the loop above saw a failure
+        failed = [i for i, p in enumerate(procs) if p.returncode != 0]
+        print(f"bench.py: rank(s) {failed} exited with {rc}", file=sys.stderr)
+        tails(failed)
     rd.join(timeout=10)
     line = (out[0] if out else b"").decode()
     if rc == 0 and line.strip():
@@ -384,7 +397,11 @@ def dry_run_collective(args, rank, world, json_fd):
     import torch.distributed as dist
     from pea_diffusion_amd import dist as pdist
     if world > 1:
-        assert pdist.init_from_env("gloo") == world
+        assert pdist.init_control_plane(timeout_s=args.rendezvous_timeout) == world
+    if args.inject_comm_failure:
+        # the failure path of the GPU run without a GPU: what main() does when NativeComm.from_env() raises
+        e = pdist.CommTimeout("injected: rendezvous not complete") if args.inject_comm_failure == "timeout" else RuntimeError("injected")
+        comm_failure_exit(e, rank)
     B = args.batch or (4 if world == 1 else 8)
     cores_per_rank = pin_rank_to_cores(int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("LOCAL_WORLD_SIZE", str(world))))
     plan_gb = None
@@ -398,22 +415,20 @@ def dry_run_collective(args, rank, world, json_fd):
     flat = mine.sum(0).repeat(64).contiguous()                             # this rank's "gradient"
     last = [None]
     count = [0]
+    ar_s = [0.0]
+    local_only = [False]
 
     def step(marks):
         f = flat.clone()
-        pdist.allreduce_mean_(f)
-        last[0] = f
+        if not local_only[0]:
+            t0 = time.perf_counter()
+            pdist.allreduce_mean_(f)
+            ar_s[0] = time.perf_counter() - t0
+            last[0] = f
         count[0] += 1
 
     def barrier():
-        if world > 1:
-            dist.barrier()
-
-    def allreduce_max(dt):
-        t = torch.tensor([dt], dtype=torch.float64)
-        if world > 1:
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        return float(t.item())
+        pdist.control_barrier()
 
     def instrument(step_fn):
         for _ in range(min(args.steps, 3)):
@@ -421,7 +436,16 @@ def dry_run_collective(args, rank, world, json_fd):
         return {"replayed_steps": min(args.steps, 3)}
 
     args.no_cpu_baseline = True
-    tmax, _ = run_protocol(args, rank, world, step, barrier, allreduce_max)
+    tmax, _ = run_protocol(args, rank, world, step, barrier, pdist.control_max)
+    # the single-GPU-equivalent block of the GPU run: the same steps with the collective switched off, symmetric on all ranks
+    barrier()
+    local_only[0] = True
+    t0 = time.perf_counter()
+    for _ in range(3):
+        step(None)
+    solo_s = (time.perf_counter() - t0) / 3
+    local_only[0] = False
+    barrier()
     roof, _ = after_timing(args, rank, world, step, instrument, barrier)
     want = glob.view(world, B, 16).sum(1).mean(0).repeat(64)
     err = float((last[0] - want).abs().max())
@@ -431,8 +455,26 @@ def dry_run_collective(args, rank, world, json_fd):
         out = {"metric": "launcher dry run (no kernels; not a benchmark)", "value": None, "unit": None, "n_gpus": world,
                "ranks": world, "global_batch": world * B, "per_gpu_batch": B, "allreduce_max_abs_err": err,
                "seconds_max_over_ranks": tmax, "dry_run": True, "steps_run_per_rank": count[0],
-               "replay": roof, "hbm_plan_gb_per_rank": plan_gb, "hbm_capacity_gb": 288.0, "cores_per_rank": cores_per_rank}
+               "replay": roof, "hbm_plan_gb_per_rank": plan_gb, "hbm_capacity_gb": 288.0, "cores_per_rank": cores_per_rank,
+               # the N-rank schema of the GPU line (NRANK_KEYS), with what a CPU run can fill in
+               "rccl_ranks": 0, "collective": "gloo all_reduce on CPU tensors (dry run: no RCCL communicator exists here)",
+               "control_plane": "gloo", "allreduce_ms": round(ar_s[0] * 1e3, 4), "allreduce_exposed_ms": None,
+               "allreduce_bytes": int(flat.numel() * 4),
+               "single_gpu_equivalent": {"ms_per_step": round(solo_s * 1e3, 4), "what": "dry run: the step with the collective off"}}
+        assert all(k in out for k in NRANK_KEYS)
         os.write(json_fd, (json.dumps(out) + "\n").encode())
+
+
+def comm_failure_exit(e, rank):
+    """--collective native and the library's communicator could not be built: that is the run's collective, so the rank
+    stops with a code of its own (never a silent fall-back to another collective).  os._exit: after a rendezvous timeout a
+    detached thread is still inside RCCL's bootstrap, and interpreter shutdown must not run library destructors beside it."""
+    from pea_diffusion_amd import dist as pdist
+    timeout = isinstance(e, pdist.CommTimeout)
+    print(f"bench.py: rank {rank}: native RCCL communicator {'rendezvous timed out' if timeout else 'failed'}: {e}\n"
+          "bench.py: --collective native makes this fatal (use --collective torch to run torch.distributed's collective instead)",
+          file=sys.stderr, flush=True)
+    os._exit(RC_COMM_TIMEOUT if timeout else RC_COMM_FAILED)
 
 
 FAMILY_BOUND = {"gemm_lc[p]_kernel<plain>": "mfma", "gemm_lc[p]_kernel<conv3x3>": "mfma", "attn_fwd": "mfma",
@@ -542,6 +584,10 @@ def main():
                          "stream, enqueued between training_step and optimizer_step so that it overlaps the gradient "
                          "all-reduce; not the default: BASELINE's metric starts from latents (SURVEY 8d)")
     ap.add_argument("--single-stream", action="store_true", help="analysis only: teacher and student passes on ONE stream")
+    ap.add_argument("--rendezvous-timeout", type=float, default=300.0,
+                    help="seconds a rank waits for the others: in the gloo control plane's rendezvous and in the RCCL "
+                         "communicator's (pea_comm_init_timeout); past it the rank exits non-zero instead of hanging")
+    ap.add_argument("--inject-comm-failure", default="", choices=["", "error", "timeout"], help=argparse.SUPPRESS)
     ap.add_argument("--launch-timeout", type=float, default=0.0,
                     help="seconds the self-launched ranks (--gpus N without torch.distributed.run) may take in all; "
                          "default 900 + 2 s per step")
@@ -574,13 +620,22 @@ def main():
         dry_run_collective(args, rank, world, json_fd)
         return
     use_dist = world > 1 or args.force_collective        # --force-collective: exercise the RCCL path with one rank
+    from pea_diffusion_amd import dist as pdist
+    control_plane = None
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.collective == "native":
+            # control plane on gloo (CPU tensors): ncclUniqueId broadcast, barriers, max of wall times.  The library's
+            # communicator (below) is then the ONLY RCCL communicator of this process: one bootstrap, one set of rings.
+            assert pdist.init_control_plane(timeout_s=args.rendezvous_timeout) == world
+            control_plane = "gloo"
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            control_plane = "nccl (torch.distributed)"
         assert dist.get_world_size() == world
     dev = torch.device("cuda", local_rank if use_dist else 0)
     torch.cuda.set_device(dev)
@@ -620,19 +675,16 @@ def main():
 
     comm, collective = None, None
     if use_dist:
-        from pea_diffusion_amd import dist as pdist
         if args.collective == "native":
             try:
-                comm = pdist.NativeComm.from_env()            # ncclUniqueId from rank 0 through the torch group
-                trainer.attach_comm(comm)
-                collective = "RCCL all-reduce on the communicator's own HIP stream (libpea_hip.so pea_allreduce_grads)"
-            except Exception as e:                            # still RCCL: torch.distributed's nccl backend
-                print(f"bench.py: native communicator failed ({e}); using torch.distributed", file=sys.stderr)
-        if comm is None:
-            collective = "torch.distributed all_reduce (nccl backend = RCCL), async on ProcessGroupNCCL's stream"
-        if comm is not None:
+                comm = pdist.NativeComm.from_env(timeout_s=args.rendezvous_timeout)   # ncclUniqueId from rank 0 over gloo
+            except Exception as e:                            # the run's collective is missing: fatal, own exit code
+                comm_failure_exit(e, rank)
+            trainer.attach_comm(comm)
+            collective = "RCCL all-reduce on the communicator's own HIP stream (libpea_hip.so pea_allreduce_grads)"
             comm.broadcast_(adapter.flat_param, 0)                # identical replicas
         else:
+            collective = "torch.distributed all_reduce (nccl backend = RCCL), async on ProcessGroupNCCL's stream"
             pdist.broadcast_params_(adapter.flat_param, src=0)
         adapter.mark_updated()
 
@@ -670,11 +722,19 @@ def main():
             marks.append(e)
 
     def barrier():
-        if use_dist:
-            dist.barrier()
+        # device work of this rank done, THEN the ranks meet (a rank must not leave the barrier with kernels of the timed
+        # region still running), then once more after the meeting for the nccl control plane's own barrier kernel
         torch.cuda.synchronize()
+        if use_dist:
+            if control_plane == "gloo":
+                pdist.control_barrier()
+            else:
+                dist.barrier()
+                torch.cuda.synchronize()
 
     def allreduce_max(dt):
+        if use_dist and control_plane == "gloo":
+            return pdist.control_max(dt)
         if use_dist:
             tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -773,7 +833,7 @@ def main():
     if comm is not None:
         allreduce_ms = round(comm.last_ms(), 4)      # device time of the last step's all-reduce + 1/world scale (comm stream)
         allreduce_exposed_ms = round(comm.last_exposed_ms(), 4)   # how long AdamW's stream stood still for it
-    rccl_ranks = dist.get_world_size() if use_dist else 1
+    rccl_ranks = (comm.world if comm is not None else dist.get_world_size()) if use_dist else 1
 
     # N > 1: the same per-GPU batch with the collective switched off, on every rank (symmetric: no rank waits for another),
     # measured in this run -- the single-GPU number the N-rank value is weak scaling against (the driver's N = 1 line runs
@@ -890,7 +950,7 @@ def main():
             "passes": ("merged: teacher == student checkpoint, one forward over 2B samples + backward on the first B"
                        if lib().pea_trainer_get_option(trainer._h, b"merge_state") == 1 else
                        "teacher forward on a side HIP stream beside the student forward"),
-            "rccl_ranks": rccl_ranks, "collective": collective, "allreduce_ms": allreduce_ms,
+            "rccl_ranks": rccl_ranks, "collective": collective, "control_plane": control_plane, "allreduce_ms": allreduce_ms,
             "allreduce_exposed_ms": allreduce_exposed_ms,
             "allreduce_bytes": int(adapter.flat_grad.numel() * 4) if use_dist else 0,
             "single_gpu_equivalent": ({"ms_per_step": round(solo_ms, 3), "images_per_s": round(B / solo_ms * 1e3, 3),
@@ -902,6 +962,7 @@ def main():
             "gpu": sampler.summary() if sampler is not None else None,
             "roofline": roof, "cpu_baseline": cpu,
         }
+        assert all(k in out for k in NRANK_KEYS)
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(out) + "\n").encode())
 

@@ -29,6 +29,7 @@ extern "C" {
 #define PEA_E_SHAPE (-3)
 #define PEA_E_STATE (-4)
 #define PEA_E_NOTFOUND (-5)
+#define PEA_E_TIMEOUT (-6)
 
 const char* pea_last_error(void);
 int pea_version(void);
@@ -438,7 +439,13 @@ int pea_trainer_export(void* tr, int which, float* out, void* stream);
  * all-gather, train_sdxl_zh.sh:22,87 and utils/model_utils.py:57-67): one process per GPU, ONE RCCL all-reduce (sum, then
  * x 1/world) over the flat fp32 adapter gradient per step, on a dedicated HIP stream owned by the communicator.
  *   pea_comm_unique_id: rank 0 creates the 128-byte ncclUniqueId; the caller ships it to the other ranks (TCP store / file).
- *   pea_comm_init:      BLOCKING rendezvous (ncclCommInitRank) on the calling thread's current HIP device.
+ *   pea_comm_init:      BLOCKING rendezvous (ncclCommInitRank) on the calling thread's current HIP device, bounded:
+ *                       pea_comm_init_timeout waits at most `timeout_s` seconds (<= 0: forever) for all `world` ranks and
+ *                       returns PEA_E_TIMEOUT past that (the reference's deadline is torch.distributed.run's rendezvous,
+ *                       train_sdxl_zh.sh:108-113); the rendezvous thread cannot be cancelled, so after PEA_E_TIMEOUT the process
+ *                       must exit (non-zero).  pea_comm_init = the same with PEA_COMM_TIMEOUT_S from the environment (600).
+ *                       A process holds ONE trainer / communicator at a time: the RCCL binding and the profiler tables are
+ *                       process-global.
  *   pea_allreduce_grads: asynchronous.  The comm stream first waits for everything enqueued on `compute_stream` so far
  *                        (the adapter wgrad), then all-reduces `grads` in place and scales by 1/world.
  *   pea_comm_join:      makes `stream` wait for the last all-reduce (call before the optimizer reads `grads`).
@@ -448,6 +455,7 @@ int pea_trainer_export(void* tr, int which, float* out, void* stream);
  *   pea_comm_broadcast: parameter broadcast from `root` (identical replicas at start), enqueued on `stream`.      */
 int pea_comm_unique_id(void* out128);
 int pea_comm_init(int rank, int world, const void* unique_id128, void** comm_out);
+int pea_comm_init_timeout(int rank, int world, const void* unique_id128, double timeout_s, void** comm_out);
 int pea_comm_destroy(void* comm);
 int pea_comm_world(void* comm);
 int pea_comm_rank(void* comm);

@@ -11,7 +11,14 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <string.h>
+
+#include <chrono>
+#include <condition_variable>
+#include <memory>
+#include <mutex>
+#include <thread>
 
 #include "../../include/pea_hip.h"
 #include "pea_common.h"
@@ -105,7 +112,30 @@ int pea_comm_unique_id(void* out128) {
   return PEA_OK;
 }
 
-int pea_comm_init(int rank, int world, const void* unique_id128, void** out) {
+// Bounded rendezvous.  ncclCommInitRank blocks until all `world` ranks have arrived; if one never does (a rank that died
+// in its own start-up, a wrong WORLD_SIZE) it blocks forever and RCCL offers no cancel for a BLOCKING communicator.  The
+// reference gets its deadline from torch.distributed.run's rendezvous (train_sdxl_zh.sh:108-113).  Here the call runs on a
+// helper thread bound to the caller's device and the caller waits for it with a deadline: past it the function returns
+// PEA_E_TIMEOUT and the helper is left behind, detached, still inside RCCL's bootstrap -- the process is expected to exit
+// with a non-zero status (bench.py does); the state the helper touches is kept alive by a shared_ptr, so a late return of
+// ncclCommInitRank releases the communicator it then holds and nothing else.
+namespace {
+struct InitJob {
+  std::mutex mu;
+  std::condition_variable cv;
+  bool done = false, abandoned = false;
+  ncclResult_t res = ncclSuccess;
+  ncclComm_t comm = nullptr;
+  hipError_t dev_err = hipSuccess;
+};
+double comm_default_timeout_s() {
+  const char* e = getenv("PEA_COMM_TIMEOUT_S");      // <= 0: wait forever (the pre-round-6 behaviour)
+  if (e && *e) return atof(e);
+  return 600.0;
+}
+}  // namespace
+
+int pea_comm_init_timeout(int rank, int world, const void* unique_id128, double timeout_s, void** out) {
   if (!out || !unique_id128) { pea_set_error("pea_comm_init: null argument"); return PEA_E_INVALID; }
   SHAPECHK(world >= 1 && rank >= 0 && rank < world, "pea_comm_init: rank %d of %d", rank, world);
   int rc = load_rccl();
@@ -119,12 +149,51 @@ int pea_comm_init(int rank, int world, const void* unique_id128, void** out) {
   }
   ncclUniqueId id;
   memcpy(id.internal, unique_id128, NCCL_UNIQUE_ID_BYTES);
-  ncclResult_t r = g_rccl.CommInitRank(&c->comm, world, id, rank);      // blocking rendezvous of all ranks
-  if (r != ncclSuccess) {
-    pea_set_error("pea_comm_init: ncclCommInitRank failed: %s", g_rccl.GetErrorString(r));
+  auto job = std::make_shared<InitJob>();
+  const int device = c->device;
+  const Rccl api = g_rccl;
+  std::thread([job, api, id, world, rank, device]() {
+    ncclComm_t comm = nullptr;
+    ncclResult_t r = ncclSuccess;
+    const hipError_t de = hipSetDevice(device);                        // the helper thread starts on device 0
+    if (de == hipSuccess) r = api.CommInitRank(&comm, world, id, rank);  // blocking rendezvous of all ranks
+    std::unique_lock<std::mutex> lk(job->mu);
+    job->dev_err = de;
+    job->res = r;
+    job->comm = comm;
+    job->done = true;
+    if (job->abandoned && comm) (void)api.CommDestroy(comm);           // nobody is waiting any more
+    lk.unlock();
+    job->cv.notify_all();
+  }).detach();
+  {
+    std::unique_lock<std::mutex> lk(job->mu);
+    if (timeout_s > 0) {
+      const auto dl = std::chrono::steady_clock::now() + std::chrono::duration_cast<std::chrono::steady_clock::duration>(
+                                                             std::chrono::duration<double>(timeout_s));
+      if (!job->cv.wait_until(lk, dl, [&] { return job->done; })) {
+        job->abandoned = true;
+        lk.unlock();
+        delete c;
+        pea_set_error("pea_comm_init: rendezvous of %d ranks not complete after %.1f s (rank %d waited in ncclCommInitRank; "
+                      "a rank is missing or never reached it) -- exit this process", world, timeout_s, rank);
+        return PEA_E_TIMEOUT;
+      }
+    } else {
+      job->cv.wait(lk, [&] { return job->done; });
+    }
+  }
+  if (job->dev_err != hipSuccess) {
+    pea_set_error("pea_comm_init: hipSetDevice(%d) failed on the rendezvous thread: %s", device, hipGetErrorString(job->dev_err));
     delete c;
     return PEA_E_HIP;
   }
+  if (job->res != ncclSuccess) {
+    pea_set_error("pea_comm_init: ncclCommInitRank failed: %s", g_rccl.GetErrorString(job->res));
+    delete c;
+    return PEA_E_HIP;
+  }
+  c->comm = job->comm;
   // any failure past the rendezvous goes through pea_comm_destroy (communicator, stream and events released)
   hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_ready, hipEventDisableTiming);
@@ -139,6 +208,10 @@ int pea_comm_init(int rank, int world, const void* unique_id128, void** out) {
   }
   *out = c;
   return PEA_OK;
+}
+
+int pea_comm_init(int rank, int world, const void* unique_id128, void** out) {
+  return pea_comm_init_timeout(rank, world, unique_id128, comm_default_timeout_s(), out);
 }
 
 int pea_comm_destroy(void* h) {

@@ -21,6 +21,7 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 #define PEA_E_SHAPE (-3)
 #define PEA_E_STATE (-4)
 #define PEA_E_NOTFOUND (-5)
+#define PEA_E_TIMEOUT (-6)
 
 // thread-local last error text (C-ABI: pea_last_error)
 void pea_set_error(const char* fmt, ...);

@@ -7,8 +7,11 @@ runs over `gloo` on CPU tensors (tests/test_dp_cpu.py).
 
 On the GPU the collective is `NativeComm`: an RCCL communicator owned by libpea_hip.so (C ABI `pea_comm_*`,
 include/pea_hip.h) with its own HIP stream -- the all-reduce is launched right after the adapter wgrad, the compute
-stream never waits for it, and the optimizer joins it.  torch.distributed only carries the 128-byte ncclUniqueId to the
-other ranks (and the bench's barrier / max-over-ranks timing).
+stream never waits for it, and the optimizer joins it.  The CONTROL PLANE is a `gloo` group on CPU tensors
+(`init_control_plane`): it carries the 128-byte ncclUniqueId to the other ranks, the bench's barriers and its
+max-over-ranks of wall times, so the library's communicator is the only RCCL communicator in the process (one
+bootstrap, one set of xGMI rings).  The rendezvous of that communicator is bounded (`pea_comm_init_timeout`): a
+missing rank turns into `CommTimeout` on the ranks that did arrive, never into a hang.
 
 Every rank computes the reference's local-batch mean loss (train_sdxl_zh.py:405,417,429: masks are not
 renormalised), so averaging the per-rank gradients equals the gradient of the global-batch mean when
@@ -22,6 +25,53 @@ import ctypes
 
 import torch
 import torch.distributed as dist
+
+
+class CommTimeout(RuntimeError):
+    """the RCCL rendezvous did not complete in time (pea_comm_init_timeout -> PEA_E_TIMEOUT): the process must exit"""
+
+
+def _single_node_env_defaults():
+    """one node, rendezvous over loopback: make the socket bootstraps of gloo and RCCL use `lo` unless the caller chose
+    an interface (the container's hostname need not resolve, and a loopback bootstrap cannot be filtered; the data path
+    is xGMI / shared memory either way).  Must run before the first process group / communicator is created."""
+    addr = os.environ.get("MASTER_ADDR", "127.0.0.1")
+    if addr in ("127.0.0.1", "localhost", "::1"):
+        os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
+        os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC (RCCL across processes on this host driver)
+
+
+def init_control_plane(timeout_s: float = 600.0) -> int:
+    """gloo process group from RANK / WORLD_SIZE / MASTER_* (torch.distributed.run or bench.py's own launcher): the
+    control plane of an N-rank run -- id broadcast, barriers, scalar reductions on CPU tensors.  Never touches the GPU.
+    Returns world.  A rank that does not arrive within `timeout_s` raises (gloo's store timeout) instead of hanging."""
+    import datetime
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if dist.is_initialized():
+        return dist.get_world_size()
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29511")
+    os.environ.setdefault("RANK", "0")
+    os.environ.setdefault("WORLD_SIZE", "1")
+    _single_node_env_defaults()
+    dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=timeout_s))
+    assert dist.get_world_size() == world
+    return world
+
+
+def control_barrier():
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.barrier()
+
+
+def control_max(x: float) -> float:
+    """max over ranks of a host scalar (CPU tensor: works on gloo and needs no device)"""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return float(x)
+    t = torch.tensor([x], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
 
 
 def init_from_env(backend: Optional[str] = None) -> int:
@@ -83,12 +133,18 @@ class NativeComm:
     """RCCL communicator + dedicated comm stream inside libpea_hip.so (`pea_comm_init`, `pea_allreduce_grads`,
     `pea_comm_join`).  One per process / GPU."""
 
-    def __init__(self, rank_: int, world: int, unique_id: bytes):
-        from ._lib import check, lib
+    def __init__(self, rank_: int, world: int, unique_id: bytes, timeout_s: Optional[float] = None):
+        from ._lib import PeaError, lib
         assert len(unique_id) == 128
         self._h = ctypes.c_void_p()
         self.rank, self.world = rank_, world
-        check(lib().pea_comm_init(rank_, world, unique_id, ctypes.byref(self._h)))
+        if timeout_s is None:
+            timeout_s = float(os.environ.get("PEA_COMM_TIMEOUT_S", "600"))
+        rc = lib().pea_comm_init_timeout(rank_, world, unique_id, ctypes.c_double(timeout_s), ctypes.byref(self._h))
+        if rc == -6:                                   # PEA_E_TIMEOUT: the rendezvous thread is still inside RCCL -- exit
+            raise CommTimeout(lib().pea_last_error().decode())
+        if rc != 0:
+            raise PeaError(f"pea error {rc}: {lib().pea_last_error().decode()}")
 
     @staticmethod
     def new_unique_id() -> bytes:
@@ -98,15 +154,17 @@ class NativeComm:
         return buf.raw
 
     @classmethod
-    def from_env(cls) -> "NativeComm":
-        """rank 0 creates the ncclUniqueId; an initialised torch.distributed group (any backend) ships it."""
+    def from_env(cls, timeout_s: Optional[float] = None) -> "NativeComm":
+        """rank 0 creates the ncclUniqueId; an initialised torch.distributed group (the gloo control plane; any backend
+        works) ships it.  The caller has bound its HIP device (torch.cuda.set_device) before this."""
+        _single_node_env_defaults()
         if dist.is_available() and dist.is_initialized():
             r, w = dist.get_rank(), dist.get_world_size()
             box = [cls.new_unique_id() if r == 0 else None]
             if w > 1:
                 dist.broadcast_object_list(box, src=0)
-            return cls(r, w, box[0])
-        return cls(0, 1, cls.new_unique_id())
+            return cls(r, w, box[0], timeout_s)
+        return cls(0, 1, cls.new_unique_id(), timeout_s)
 
     def allreduce_mean_async(self, flat_grad: torch.Tensor, compute_stream=None):
         """comm stream: wait for `compute_stream`'s work so far, all-reduce(sum) in place, x 1/world.  Returns at once."""

@@ -46,6 +46,31 @@ def test_native_comm_world1_allreduce_broadcast_streams(gpu):
     comm.close()
 
 
+def test_comm_rendezvous_timeout_returns_instead_of_hanging(gpu):
+    """pea_comm_init_timeout with a rank that never arrives (world 2, only rank 0 present): PEA_E_TIMEOUT after the
+    deadline, with a message naming the rank and the world -- ncclCommInitRank itself would block forever.  In a child
+    process: the abandoned rendezvous thread stays inside RCCL's bootstrap, which is why the caller must exit."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import ctypes, os, sys, time; sys.path.insert(0, %r)\n"
+            "import torch; torch.cuda.set_device(0); torch.zeros(1, device='cuda')\n"
+            "from pea_diffusion_amd._lib import lib\n"
+            "from pea_diffusion_amd.dist import NativeComm, CommTimeout\n"
+            "uid = NativeComm.new_unique_id()\n"
+            "t0 = time.time()\n"
+            "try:\n"
+            "    NativeComm(0, 2, uid, timeout_s=4.0)\n"
+            "except CommTimeout as e:\n"
+            "    print('TIMEOUT %%.1f %%s' %% (time.time() - t0, e), flush=True); os._exit(5)\n"
+            "os._exit(0)\n" % root)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 5, (r.returncode, r.stdout[-500:], r.stderr[-1500:])
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("TIMEOUT")][0]
+    waited = float(line.split()[1])
+    assert 3.5 <= waited < 30.0 and "rendezvous of 2 ranks not complete" in line and "rank 0" in line
+
+
 def test_comm_argument_errors(gpu):
     from pea_diffusion_amd._lib import lib
     L = lib()
@@ -126,6 +151,11 @@ def test_bench_subprocess_with_collective_and_side_stream_vae(gpu):
     assert len(lines) == 1, r.stdout
     out = json.loads(lines[0])
     assert out["rccl_ranks"] == 1 and "libpea_hip.so" in out["collective"]
+    # round 6: the control plane is gloo -- the library's communicator is the only RCCL communicator of the process -- and the
+    # N-rank schema is the one the CPU dry run asserts (bench.NRANK_KEYS)
+    sys.path.insert(0, root)
+    import bench
+    assert out["control_plane"] == "gloo" and all(k in out for k in bench.NRANK_KEYS)
     assert out["config"]["loss"] == out["config"]["loss"] and abs(out["config"]["loss"]) < 1e4      # finite
     assert out["allreduce_ms"] is not None and out["allreduce_exposed_ms"] is not None
     assert out["allreduce_bytes"] > 0 and "vae_encode" in out["config"]

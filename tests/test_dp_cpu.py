@@ -144,7 +144,50 @@ def test_bench_launcher_spawns_two_ranks_over_gloo():
     assert out["cores_per_rank"] >= 1
     # the whole control flow ran on BOTH ranks: warm-up + K timed steps + the instrumented replay (each step holds a
     # collective, so a replay on rank 0 only would have left this subprocess hanging) + the closing barrier
-    assert out["steps_run_per_rank"] == 3 + 2 + 2 and out["replay"] == {"replayed_steps": 2}
+    # (+ 3 local-only steps: the single-GPU-equivalent block between two barriers, as in the GPU run)
+    assert out["steps_run_per_rank"] == 3 + 2 + 3 + 2 and out["replay"] == {"replayed_steps": 2}
+    # the N-rank line's schema (bench.NRANK_KEYS; the GPU line asserts the same keys): control plane on gloo, and what a CPU
+    # run can measure of the collective
+    sys.path.insert(0, ROOT)
+    import bench
+    for k in bench.NRANK_KEYS:
+        assert k in out, k
+    assert out["control_plane"] == "gloo" and out["rccl_ranks"] == 0 and "gloo" in out["collective"]
+    assert out["allreduce_ms"] > 0 and out["allreduce_bytes"] == 16 * 64 * 4
+    assert out["single_gpu_equivalent"]["ms_per_step"] >= 0
+
+
+@pytest.mark.parametrize("kind,code", [("error", 4), ("timeout", 5)])
+def test_bench_native_comm_failure_is_fatal_with_its_own_exit_code(kind, code):
+    """--collective native: a communicator that cannot be built (or whose rendezvous times out) stops every rank with exit
+    code 4 (5) -- never a silent fall-back to another collective -- and the launcher relays that code, names the failed
+    ranks and prints no result line.  The failure is injected behind the gloo rendezvous of the dry run (the GPU run
+    reaches the same comm_failure_exit() from NativeComm.from_env())."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--dry-run-collective",
+                        "--inject-comm-failure", kind], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == code, (r.returncode, r.stderr[-1500:])
+    assert not r.stdout.strip()
+    assert "native RCCL communicator" in r.stderr and "--collective native makes this fatal" in r.stderr
+    assert ("rendezvous timed out" in r.stderr) == (kind == "timeout")
+
+
+def test_control_plane_rendezvous_is_bounded():
+    """a rank whose peers never arrive leaves init_control_plane() with an exception after the timeout (gloo's store),
+    it does not hang: WORLD_SIZE=2 with only rank 1 started (rank 0 would host the store)"""
+    import subprocess
+    code = ("import sys, time; sys.path.insert(0, %r)\n"
+            "from pea_diffusion_amd import dist as pdist\n"
+            "t0 = time.time()\n"
+            "try:\n"
+            "    pdist.init_control_plane(timeout_s=3.0)\n"
+            "except Exception as e:\n"
+            "    print('RAISED', type(e).__name__, round(time.time() - t0, 1)); sys.exit(7)\n"
+            "sys.exit(0)\n" % ROOT)
+    env = dict(os.environ, RANK="1", LOCAL_RANK="1", WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120, env=env)
+    assert r.returncode == 7 and "RAISED" in r.stdout, (r.returncode, r.stdout, r.stderr[-800:])
 
 
 def test_bench_launcher_kills_hung_ranks_at_the_deadline(tmp_path):
