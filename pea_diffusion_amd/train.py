@@ -52,6 +52,7 @@ class PEATrainer:
         self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
         self.warmup_steps, self.total_steps, self.lr_end = warmup_steps, total_steps, lr_end
         self.global_step = 0
+        self.consumed_samples = 0                          # Lightning's `global_samples` (train_sdxl_zh.py:456): samples seen by ALL ranks
         self._m = torch.zeros_like(adapter.flat_param)
         self._v = torch.zeros_like(adapter.flat_param)
         self.comm: Optional[pdist.NativeComm] = None      # RCCL communicator + comm stream inside libpea_hip.so
@@ -106,6 +107,7 @@ class PEATrainer:
                                    ptr(tp), ptr(tid), 1.0, ptr(self.adapter.flat_grad), 0, ptr(self.losses),
                                    stream_ptr()))
         self._keep = (b, ts, pm, zh, tp, tid)
+        self.consumed_samples += int(b["latents"].shape[0]) * (self.comm.world if self.comm is not None else world)
         if (self.comm is not None or world > 1) and not self.local_only:
             self.all_reduce_grads_async()   # launched right behind the adapter wgrad
             if not async_allreduce:
@@ -195,13 +197,78 @@ class PEATrainer:
         self.adapter.flat_param._version  # noqa: B018  (in-place op below bumps the version counter)
         self.adapter.mark_updated()
 
-    def save_adapter(self, root: str):
+    def save_adapter(self, root: str, optimizer_state: bool = True):
         """`torch.save(self.proj.state_dict(), f"{root}/proj_{global_step}/pytorch_model.bin")`
-        (train_sdxl_zh.py:443-448)"""
+        (train_sdxl_zh.py:443-448) -- the file the reference's `proj.load_state_dict(torch.load(...))` reads
+        (tests/test_sdxl_zh.py:153) -- and, beside it, `trainer_state.pt`: what Lightning + DeepSpeed keep in THEIR
+        checkpoint so that training resumes where it stopped (`on_load_checkpoint` restores `global_step` and
+        `global_samples`, train_sdxl_zh.py:454-458; the engine restores the fp32 master weights and both Adam
+        moments): the flat fp32 parameters (the adapter's `state_dict` is what the reference saves -- fp16 there,
+        a rounded copy of the masters), m, v, the step counter, consumed samples and the schedule's constants."""
         d = os.path.join(root, f"proj_{self.global_step}")
         os.makedirs(d, exist_ok=True)
         torch.save({k: v.detach().cpu().clone() for k, v in self.adapter.state_dict().items()},
                    os.path.join(d, "pytorch_model.bin"))
+        if optimizer_state:
+            self.join_grads()
+            torch.cuda.current_stream().synchronize()
+            torch.save(self.state_dict(), os.path.join(d, "trainer_state.pt"))
+        return d
+
+    TRAINER_STATE_VERSION = 1
+
+    def state_dict(self) -> Dict[str, object]:
+        """everything `optimizer_step` reads besides the gradient (host copies): a fresh trainer that loads this continues
+        the run bit for bit (tests/test_model_gpu.py::test_checkpoint_resume_is_bit_exact)"""
+        return {"version": self.TRAINER_STATE_VERSION, "global_step": int(self.global_step),
+                "consumed_samples": int(getattr(self, "consumed_samples", 0)),
+                "flat_param": self.adapter.flat_param.detach().cpu().clone(),
+                "exp_avg": self._m.detach().cpu().clone(), "exp_avg_sq": self._v.detach().cpu().clone(),
+                "param_names": [n for n, _ in self.adapter.named_parameters()],
+                "param_numel": [int(p.numel()) for p in self.adapter._plist()],
+                "hparams": {"lr": self.lr, "betas": tuple(self.betas), "eps": self.eps, "weight_decay": self.weight_decay,
+                            "warmup_steps": self.warmup_steps, "total_steps": self.total_steps, "lr_end": self.lr_end}}
+
+    def load_state_dict(self, st: Dict[str, object], load_hparams: bool = True):
+        if int(st.get("version", 0)) != self.TRAINER_STATE_VERSION:
+            raise PeaError(f"trainer state version {st.get('version')} (this build reads {self.TRAINER_STATE_VERSION})")
+        numel = [int(p.numel()) for p in self.adapter._plist()]
+        if list(st["param_numel"]) != numel or st["flat_param"].numel() != self.adapter.flat_param.numel():
+            raise PeaError(f"trainer state is for an adapter with parameter sizes {list(st['param_numel'])}, this one has {numel}")
+        self.join_grads()
+        with torch.no_grad():
+            self.adapter.flat_param.copy_(st["flat_param"].to(self.adapter.flat_param.device))
+            self._m.copy_(st["exp_avg"].to(self._m.device))
+            self._v.copy_(st["exp_avg_sq"].to(self._v.device))
+        self.adapter.mark_updated()
+        self.global_step = int(st["global_step"])
+        self.consumed_samples = int(st.get("consumed_samples", 0))
+        if load_hparams:
+            h = st["hparams"]
+            self.lr, self.betas, self.eps, self.weight_decay = h["lr"], tuple(h["betas"]), h["eps"], h["weight_decay"]
+            self.warmup_steps, self.total_steps, self.lr_end = h["warmup_steps"], h["total_steps"], h["lr_end"]
+
+    def resume(self, root: str, step: Optional[int] = None) -> str:
+        """load `root/proj_{step}/trainer_state.pt` (default: the highest step that has one); returns the directory.
+        A directory that only holds the reference's `pytorch_model.bin` restores the weights and nothing else (the
+        moments start from zero, as they do when the reference loads `proj_0_{id}`: train_sdxl_zh.py:145)."""
+        if step is None:
+            steps = []
+            for n in os.listdir(root):
+                if n.startswith("proj_") and n[5:].isdigit() and os.path.exists(os.path.join(root, n, "pytorch_model.bin")):
+                    steps.append(int(n[5:]))
+            if not steps:
+                raise PeaError(f"resume: no proj_<step>/pytorch_model.bin under {root}")
+            step = max(steps)
+        d = os.path.join(root, f"proj_{step}")
+        ts = os.path.join(d, "trainer_state.pt")
+        if os.path.exists(ts):
+            self.load_state_dict(torch.load(ts, map_location="cpu", weights_only=False))
+        else:
+            self.join_grads()
+            self.adapter.load_state_dict(torch.load(os.path.join(d, "pytorch_model.bin"), map_location="cpu"))
+            self.adapter.mark_updated()
+            self.global_step = int(step)
         return d
 
 

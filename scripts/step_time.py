@@ -5,4 +5,5 @@ r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--no-cpu-ba
                    capture_output=True, text=True)
 d = json.loads(r.stdout.strip().splitlines()[-1])
 g = d.get("gpu") or {}
-print(f"ms_per_step median {d['ms_per_step']:.2f} mean {d['ms_per_step_mean']:.2f} min/max {d['ms_per_step_min_max']} | sclk {g.get('sclk_mhz_median')} MHz, {g.get('power_w_median')} W", flush=True)
+print(f"ms_per_step median {d['ms_per_step']:.2f} mean {d['ms_per_step_mean']:.2f} min/max {d['ms_per_step_min_max']} | sclk {g.get('sclk_mhz_median')} MHz, "
+      f"{g.get('power_w_mean')} W mean | {d.get('energy_j_per_step')} J/step", flush=True)

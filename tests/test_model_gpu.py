@@ -530,6 +530,59 @@ def test_training_trajectory_vs_oracle(gpu):
         assert lh[last] < lh[first], (j, lh)                # (... the HIP path does as well)
 
 
+def test_checkpoint_resume_is_bit_exact(gpu, tmp_path):
+    """Optimizer-state checkpoint + resume (train_sdxl_zh.py:443-448 writes `proj_{step}/pytorch_model.bin`; Lightning +
+    DeepSpeed keep global_step / global_samples and the Adam moments in their own checkpoint, `on_load_checkpoint` :454-458,
+    utils/universal.py:24-26): 10 steps, save, 10 more steps -- against a FRESH adapter (other initial weights) + fresh trainer
+    that resumes from the directory and runs the same 10 batches: every loss, the parameters and both moments bit for bit."""
+    import os
+    from oracle.step_ref import synthetic_batch
+    from pea_diffusion_amd.adapter import PEAAdapter
+    from pea_diffusion_amd.train import PEATrainer
+    B, L = 2, 12
+    cfg, us, ut, _, ad, hs, ht, _, tr = _train_pair(B, L)
+    hp = dict(lr=1e-3, warmup_steps=4, total_steps=500, lr_end=1e-6)
+    for k, v in hp.items():
+        setattr(tr, k, v)
+    batches = [synthetic_batch(cfg, B, L=L, enc_dim=128, seed=70 + j) for j in range(4)]
+
+    def run(trainer, lo, hi):
+        out = []
+        for i in range(lo, hi):
+            o = trainer.training_step(batches[i % 4], i)
+            trainer.optimizer_step()
+            out.append(o["loss"])
+        torch.cuda.synchronize()
+        return torch.stack(out).cpu()
+
+    run(tr, 0, 10)
+    d = tr.save_adapter(str(tmp_path))
+    assert os.path.basename(d) == "proj_10" and sorted(os.listdir(d)) == ["pytorch_model.bin", "trainer_state.pt"]
+    la = run(tr, 10, 20)
+    wa, ma, va = ad.flat_param.clone(), tr._m.clone(), tr._v.clone()
+    assert tr.global_step == 20 and tr.consumed_samples == 20 * B
+    del tr
+    torch.manual_seed(999)
+    ad2 = PEAAdapter(128, cfg.pooled_dim, 192, cfg.cross_attention_dim, False).cuda()     # other weights: resume must replace them
+    tr2 = PEATrainer(ad2, hs, ht)                                                         # default hyper-parameters: resume restores them
+    assert tr2.resume(str(tmp_path)) == d
+    assert tr2.global_step == 10 and tr2.consumed_samples == 10 * B and tr2.lr == hp["lr"] and tr2.warmup_steps == 4
+    assert abs(tr2.current_lr() - tr2.lr_end - (hp["lr"] - hp["lr_end"]) * (1 - 6 / 496)) < 1e-12
+    lb = run(tr2, 10, 20)
+    assert torch.equal(la, lb), (la, lb)
+    assert torch.equal(wa, ad2.flat_param) and torch.equal(ma, tr2._m) and torch.equal(va, tr2._v)
+    # the presented parameters (what `proj.state_dict()` hands to torch.save) follow the restored masters
+    sd = torch.load(os.path.join(d, "pytorch_model.bin"))
+    tr3 = PEATrainer(PEAAdapter(128, cfg.pooled_dim, 192, cfg.cross_attention_dim, False).cuda(), hs, ht)
+    os.remove(os.path.join(d, "trainer_state.pt"))                   # a reference-style directory: weights only
+    tr3.resume(str(tmp_path), 10)
+    assert tr3.global_step == 10 and float(tr3._m.abs().max()) == 0.0
+    for k, v in tr3.adapter.state_dict().items():
+        assert torch.equal(v.cpu(), sd[k]), k
+    with pytest.raises(Exception):
+        tr3.load_state_dict(dict(tr2.state_dict(), version=99))
+
+
 def test_adamw_and_checkpoint_round_trip(gpu, tmp_path):
     """fused AdamW over the flat adapter buffer against torch.optim.AdamW (the reference's
     FusedAdam adam_w_mode, utils/model_utils.py:59-67), and the checkpoint writer of train_sdxl_zh.py:443-448:
