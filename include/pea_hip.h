@@ -354,6 +354,9 @@ int pea_unet_num_taps(void* unet);
 /* hook name of tap k: "d<i>" (down_blocks[i], the hidden state of its (hidden, res_samples) tuple), "m" (mid_block;
  * absent when the config has no mid block), "u<i>" (up_blocks[i])                                     */
 int pea_unet_tap_name(void* unet, int k, char* name, int name_len);
+/* shape of tap k and (optionally) its raw storage pointers.  A tap that is stored depth-to-space (pea_unet_tap_layout == 1)
+ * hands out raw pointers only after pea_unet_tap_layout has been called on this context (PEA_E_STATE otherwise): the
+ * shape alone does not reveal the storage order.                                                                   */
 int pea_unet_tap_info(void* unet, int k, void** data, void** grad, int* B, int* H, int* W, int* C);
 int pea_unet_tap_export_nchw(void* unet, int k, int grad, float* out, void* stream);
 /* Storage layout behind pea_unet_tap_info's pointers: 0 = NHWC [B][H][W][C]; 1 = depth-to-space [B][H/2][W/2][(y&1)*2+(x&1)][C]

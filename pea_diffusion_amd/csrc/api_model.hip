@@ -440,6 +440,13 @@ int pea_unet_tap_info(void* h, int k, void** data, void** grad, int* B, int* H, 
   }
   { int rc = u->ensure_acts(); if (rc != PEA_OK) return rc; }
   const Tn& t = u->tn[u->taps[k]];
+  // raw pointers of a depth-to-space tap: B / H / W / C do not reveal the storage order, so a caller that has never asked
+  // for the layout would read (and seed) permuted pixels without any error -- refuse until it has
+  if ((data || grad) && t.d2s && !u->tap_layout_queried) {
+    pea_set_error("pea_unet_tap_info: tap %d is stored depth-to-space ([B][H/2][W/2][(y&1)*2+(x&1)][C]); call "
+                  "pea_unet_tap_layout first (or use pea_unet_tap_export_nchw / pea_unet_tap_import_grad_nchw)", k);
+    return PEA_E_STATE;
+  }
   if (data) *data = t.d;
   if (grad) *grad = t.g;
   if (B) *B = t.B;
@@ -465,6 +472,7 @@ int pea_unet_tap_export_nchw(void* h, int k, int grad, float* out, void* stream)
 int pea_unet_tap_layout(void* h, int k) {
   Tape* u = (Tape*)h;
   if (!u || k < 0 || k >= (int)u->taps.size()) return -1;
+  u->tap_layout_queried = true;
   return u->tn[u->taps[k]].d2s ? 1 : 0;
 }
 int pea_unet_tap_import_grad_nchw(void* h, int k, const float* src, void* stream) {

@@ -156,6 +156,7 @@ struct Tape {
   std::vector<LnFold> folds;      // LayerNorm -> Linear folds; their W' / s / t live in the weight arena of the owner
   bool fold_dirty = true;         // a weight was (re)loaded since the folds were last computed (owner only)
   Tape* weights_owner = nullptr;  // set by share_weights_from
+  bool tap_layout_queried = false;   // pea_unet_tap_layout was called: raw pointers of depth-to-space taps may be handed out
   int ensure_folded(hipStream_t s);
   std::vector<int> taps;          // tensor ids: d0.., m, u0..
   std::vector<std::string> tap_names;   // "d0".., "m" (absent without a mid block), "u0"..
@@ -201,6 +202,7 @@ struct Tape {
   WSeq* wseq_cur = nullptr;
   void wseq_begin(WSeq& q) { wseq_cur = &q; q.pos = 0; if (!q.ready) q.w.clear(); }
   void wseq_end() { if (wseq_cur && !wseq_cur->ready && !wseq_cur->w.empty()) wseq_cur->ready = true; wseq_cur = nullptr; }
+  void wseq_drop() { for (WSeq* q : {&wseq_fwd, &wseq_bwd}) { q->ready = false; q->w.clear(); q->pos = 0; } wseq_cur = nullptr; }
   int gemm(GemmP& p, hipStream_t s);   // launch_gemm with the prefetch target filled in
   Tape* arena_donor = nullptr;       // activation / gradient arenas borrowed from this (larger) tape: the two are never live at once
   bool arena_borrowed = false;

@@ -1015,25 +1015,25 @@ void Tape::drop_borrowed_scratch() {
 
 Tape::~Tape() {
   drop_borrowed_scratch();
-  if (owns_weights && warena) hipFree(warena);
-  if (tmp_f32) hipFree(tmp_f32);
-  if (aarena && !arena_borrowed) hipFree(aarena);
-  if (garena && !arena_borrowed) hipFree(garena);
-  if (gn_scratch) hipFree(gn_scratch);
-  if (delta) hipFree(delta);
-  if (ups_tmp) hipFree(ups_tmp);
-  if (tproj_grad) hipFree(tproj_grad);
-  if (cs_scratch) hipFree(cs_scratch);
-  if (attn_part) hipFree(attn_part);
-  if (kv_part) hipFree(kv_part);
-  if (geglu_tmp) hipFree(geglu_tmp);
-  if (am_scores) hipFree(am_scores);
-  if (am_vt) hipFree(am_vt);
-  if (vae_h) hipFree(vae_h);
-  if (kvlen) hipFree(kvlen);
-  if (rel_bias) hipFree(rel_bias);
-  if (rel_bucket) hipFree(rel_bucket);
-  if (cross_kvlen) hipFree(cross_kvlen);
+  if (owns_weights && warena) (void)hipFree(warena);
+  if (tmp_f32) (void)hipFree(tmp_f32);
+  if (aarena && !arena_borrowed) (void)hipFree(aarena);
+  if (garena && !arena_borrowed) (void)hipFree(garena);
+  if (gn_scratch) (void)hipFree(gn_scratch);
+  if (delta) (void)hipFree(delta);
+  if (ups_tmp) (void)hipFree(ups_tmp);
+  if (tproj_grad) (void)hipFree(tproj_grad);
+  if (cs_scratch) (void)hipFree(cs_scratch);
+  if (attn_part) (void)hipFree(attn_part);
+  if (kv_part) (void)hipFree(kv_part);
+  if (geglu_tmp) (void)hipFree(geglu_tmp);
+  if (am_scores) (void)hipFree(am_scores);
+  if (am_vt) (void)hipFree(am_vt);
+  if (vae_h) (void)hipFree(vae_h);
+  if (kvlen) (void)hipFree(kvlen);
+  if (rel_bias) (void)hipFree(rel_bias);
+  if (rel_bucket) (void)hipFree(rel_bucket);
+  if (cross_kvlen) (void)hipFree(cross_kvlen);
 }
 
 int Tape::load_weight(const char* name, const float* src, long long numel, hipStream_t s) {
@@ -1124,6 +1124,11 @@ int Tape::share_weights_from(const Tape& src) {
     WSlot& b = slots[i];
     SHAPECHK(a.name == b.name && a.numel == b.numel, "unet: weight tables differ at %s", a.name.c_str());
     SHAPECHK(!b.need_wt || a.wt, "unet: source lacks the dgrad layout of %s", a.name.c_str());
+    // the packed layout of a conv slot is decided when its tape is built (sub-pixel form of the upsampler convs: [4][Co][4 Ci]
+    // against [Co][9 Ci]; padded head / channel widths): a borrower built with the other form would read the other layout
+    SHAPECHK(a.subpix == b.subpix && a.pad_dp == b.pad_dp && a.pad_d == b.pad_d && a.pad_mode == b.pad_mode,
+             "unet: packed weight layout of %s differs between the two contexts (sub-pixel %d/%d, padding %d/%d)", a.name.c_str(),
+             (int)a.subpix, (int)b.subpix, a.pad_dp, b.pad_dp);
     b.f32 = a.f32; b.w = a.w; b.ldw = a.ldw; b.wt = a.wt; b.ldwt = a.ldwt; b.loaded = a.loaded;
   }
   for (size_t i = 0; i < fused.size(); ++i) {
@@ -1132,6 +1137,7 @@ int Tape::share_weights_from(const Tape& src) {
   SHAPECHK(src.folds.size() == folds.size(), "unet: LayerNorm folds differ");
   for (size_t i = 0; i < folds.size(); ++i) { folds[i].wf = src.folds[i].wf; folds[i].s = src.folds[i].s; folds[i].t = src.folds[i].t; }
   weights_owner = src.weights_owner ? src.weights_owner : const_cast<Tape*>(&src);
+  wseq_drop();          // the recorded weight sequences name the OLD tables' matrices: the next pass records again
   return PEA_OK;
 }
 
@@ -1609,7 +1615,7 @@ int Tape::backward(const float* deps, hipStream_t s) {
 // Forward GEMMs use the fused GELU epilogue (pre-activation stashed for the backward);
 // backward = dgrad (transposed bf16 copies) + wgrad (fp32 accumulation into the flat grad buffer).
 Adapter::~Adapter() {
-  if (arena) hipFree(arena);
+  if (arena) (void)hipFree(arena);
 }
 
 int Adapter::prepare(int B2_, int L_) {
@@ -1620,7 +1626,7 @@ int Adapter::prepare(int B2_, int L_) {
   off_lnw = 0; off_lnb = in_dim; off_w0 = off_lnb + in_dim; off_w1 = off_w0 + (long long)hidden * in_dim;
   off_w2 = off_w1 + (long long)hidden * hidden; off_fcw = off_w2 + (long long)out_dim * hidden;
   off_fcb = off_fcw + (long long)out1 * out_dim; nparam = off_fcb + out1;
-  if (arena) { hipFree(arena); arena = nullptr; }
+  if (arena) { (void)hipFree(arena); arena = nullptr; }
   size_t off = 0;
   std::vector<std::pair<bf16**, size_t>> req;
   auto want = [&](bf16** p, size_t elems) { req.push_back({p, off}); off += al256(elems * 2); };
@@ -1732,10 +1738,10 @@ Trainer::~Trainer() {
   if (side) { (void)hipStreamDestroy(side); (void)hipEventDestroy(ev_fork); (void)hipEventDestroy(ev_join); }
   for (void* p : {(void*)xt, (void*)eps_s, (void*)eps_t, (void*)deps, (void*)ac, (void*)t_ehs_sel, (void*)dehs_full, (void*)t_f32,
                   (void*)losses, (void*)kd_ws, (void*)tehs_c, (void*)tehs_n, (void*)xt2, (void*)eps2, (void*)t2, (void*)tid2})
-    if (p) hipFree(p);
+    if (p) (void)hipFree(p);
   for (auto& kv : merged_n) delete kv.second;           // (their arenas are borrowed from `merged`: freed below)
-  if (tmap_d) hipFree(tmap_d);
-  if (tpool_c) hipFree(tpool_c);
+  if (tmap_d) (void)hipFree(tmap_d);
+  if (tpool_c) (void)hipFree(tpool_c);
   delete merged;
 }
 

@@ -49,6 +49,7 @@ void pea_set_error(const char* fmt, ...);
 typedef __attribute__((ext_vector_type(4))) unsigned pea_u32x4;
 template <bool WT>
 __device__ __forceinline__ void store16(void* ptr, bf16x8 v) {
+#if defined(__gfx950__) || defined(__gfx942__) || !defined(__HIP_DEVICE_COMPILE__)
   if constexpr (WT) {
     union { bf16x8 h; pea_u32x4 u; } c;
     c.h = v;
@@ -59,6 +60,9 @@ __device__ __forceinline__ void store16(void* ptr, bf16x8 v) {
   } else {
     *(bf16x8*)ptr = v;
   }
+#else      // `make ARCH=...` for another target: the sc1 cache-policy bit and the wait-state count are gfx94x / gfx950 forms
+  *(bf16x8*)ptr = v;
+#endif
 }
 
 // erf by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7, i.e. fp32-epsilon level; every consumer rounds to bf16):

@@ -235,11 +235,14 @@ class HipUNet:
         return int(lib().pea_unet_tap_layout(self._h, k))
 
     def tap_pointers(self, k: int):
+        """-> (data ptr, grad ptr, (B, H, W, C), layout); layout as `tap_layout` -- the pointers of a depth-to-space tap are
+        only handed out once the layout has been asked for (pea_unet_tap_info)"""
+        layout = self.tap_layout(k)
         d, g = ctypes.c_void_p(), ctypes.c_void_p()
         B, H, W, C = ctypes.c_int(), ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
         check(lib().pea_unet_tap_info(self._h, k, ctypes.byref(d), ctypes.byref(g), ctypes.byref(B), ctypes.byref(H),
                                       ctypes.byref(W), ctypes.byref(C)))
-        return d.value, g.value, (B.value, H.value, W.value, C.value)
+        return d.value, g.value, (B.value, H.value, W.value, C.value), layout
 
     # ---------------------------------------------------------------- backward (data gradients only)
     def backward(self, d_eps: Optional[torch.Tensor], tap_seed_mask: int = 0):

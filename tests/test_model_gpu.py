@@ -231,10 +231,23 @@ def test_unet_forward_tiny(gpu, B, L):
     import os
     subpixel = os.environ.get("PEA_UPCONV_SUBPIXEL", "1") != "0"
     names = tap_names(cfg)
+    if subpixel:
+        # raw pointers of a depth-to-space tap are refused until the caller has asked for the layout (the shape alone does not
+        # reveal the storage order); shapes without pointers, and NHWC taps, are always served
+        import ctypes
+        from pea_diffusion_amd._lib import lib
+        d, Bc = ctypes.c_void_p(), ctypes.c_int()
+        iu = names.index("u0")
+        assert lib().pea_unet_tap_info(hip._h, iu, ctypes.byref(d), None, ctypes.byref(Bc), None, None, None) == -4
+        assert b"depth-to-space" in lib().pea_last_error()
+        assert lib().pea_unet_tap_info(hip._h, iu, None, None, ctypes.byref(Bc), None, None, None) == 0 and Bc.value == B
+        assert lib().pea_unet_tap_info(hip._h, names.index("d0"), ctypes.byref(d), None, None, None, None, None) == 0 and d.value
     for i, k in enumerate(names):
         ends_in_upsampler = k.startswith("u") and int(k[1:]) != n - 1
         assert hip.tap_layout(i) == (1 if (ends_in_upsampler and subpixel) else 0), (k, hip.tap_layout(i))
     assert hip.tap_layout(len(names)) == -1
+    dptr, gptr, shape, layout = hip.tap_pointers(names.index("u0"))     # (asks for the layout itself)
+    assert dptr and shape[0] == B and layout == (1 if subpixel else 0)
 
 
 @pytest.mark.parametrize("geglu_bwd_fused", [1, 0])
