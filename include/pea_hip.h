@@ -489,6 +489,8 @@ void pea_debug_set_attn_tr(int v);
 void pea_debug_set_attn_fused_bwd(int v);
 /* 0: cross-attention backward (<= 128 keys, head_dim 64) on the general kernels instead of the one-pass kernel (A/B) */
 void pea_debug_set_attn_xattn(int v);
+/* 0: cross-attention backward with 33..96 keys on the round-3 one-pass kernel instead of the specialised-wave kernel (A/B) */
+void pea_debug_set_xattn_bwd_v2(int v);
 /* A/B aid: 1 = GEGLU backward inside the FF output projection's dgrad GEMM (default), 0 = its own kernel */
 void pea_debug_set_geglu_bwd_fused(int v);
 /* benchmark aid: force GEMM tile variant (>= 0) or restore the shape-based choice (-1) */

@@ -23,6 +23,12 @@
 #ifndef PEA_ATTN_WT
 #define PEA_ATTN_WT 0     // experiment: O / dQ rows leave as write-through (sc1) stores (see norm.hip: PEA_LN_WT)
 #endif
+#ifndef PEA_ATTN_DQ_READS_DELTA
+#define PEA_ATTN_DQ_READS_DELTA 1   // fused backward: the dQ role reads (-delta, -lse log2 e) from attn_delta_kernel's output instead of recomputing delta from O
+#endif
+#ifndef PEA_ATTN_DKV_LDS_EPI
+#define PEA_ATTN_DKV_LDS_EPI 1      // dK / dV leave through a per-wave LDS image as whole 128-byte rows (16 bytes per lane) instead of 8-byte pieces over 32 lines
+#endif
 #ifndef PEA_ATTN_BWD_PREFETCH
 #define PEA_ATTN_BWD_PREFETCH 0   // 1: backward roles request each batch of LDS fragments one phase ahead of its MFMAs (A/B: 1 % slower, +40 registers)
 #endif
@@ -247,24 +253,32 @@ __device__ __forceinline__ void attn_q_body(const AttnP& p, char* smem, int blk_
       for (int s = 0; s < 4; ++s)
         dof[nd][s] = *(const bf16x8*)(dOb + (long long)qrow * p.lddo + nd * 64 + 16 * s + 8 * fh);
     const long long li = ((long long)b * p.H + head) * p.Sq + qrow;
-    lse2 = p.lse[li] * LOG2E;
-    // delta[q] = sum_d dO[q][d] * O[q][d], computed here from the dO fragments already in registers (one extra read of
-    // the O row) instead of a separate kernel; the dK/dV kernel, launched after this one, reads it from p.delta
-    const bf16* Ob = p.O + (long long)b * p.Sq * p.ldo + head * 64 * ND;
-    float dsum = 0.f;
+    if (!WRITE_DELTA && PEA_ATTN_DQ_READS_DELTA) {
+      // fused launch: attn_delta_kernel ran in front of this grid and left -delta[q] and -lse[q] * log2(e) for the dK/dV role;
+      // the dQ role takes the same two floats instead of re-reading its O row (4 x 16 bytes per lane over 32 lines per
+      // instruction) and redoing the 64 multiply-adds -- bit-identical inputs for both roles
+      dlt = -p.delta[li];
+      lse2 = -p.delta[(long long)p.B * p.H * p.Sq + li];
+    } else {
+      lse2 = p.lse[li] * LOG2E;
+      // delta[q] = sum_d dO[q][d] * O[q][d], computed here from the dO fragments already in registers (one extra read of
+      // the O row) instead of a separate kernel; the dK/dV kernel, launched after this one, reads it from p.delta
+      const bf16* Ob = p.O + (long long)b * p.Sq * p.ldo + head * 64 * ND;
+      float dsum = 0.f;
 #pragma unroll
-    for (int nd = 0; nd < ND; ++nd)
+      for (int nd = 0; nd < ND; ++nd)
 #pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        const bf16x8 o = *(const bf16x8*)(Ob + (long long)qrow * p.ldo + nd * 64 + 16 * s + 8 * fh);
+        for (int s = 0; s < 4; ++s) {
+          const bf16x8 o = *(const bf16x8*)(Ob + (long long)qrow * p.ldo + nd * 64 + 16 * s + 8 * fh);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) dsum += (float)dof[nd][s][j] * (float)o[j];
+          for (int j = 0; j < 8; ++j) dsum += (float)dof[nd][s][j] * (float)o[j];
+        }
+      { float da = dsum, db = dsum; swap_halves32(da, db); dsum = da + db; }
+      dlt = dsum;
+      if (WRITE_DELTA && qvalid && fh == 0 && chunk == 0) {       // row constants of the dK/dV kernel (see attn_delta_kernel)
+        p.delta[li] = -dsum;
+        p.delta[(long long)p.B * p.H * p.Sq + li] = -lse2;
       }
-    { float da = dsum, db = dsum; swap_halves32(da, db); dsum = da + db; }
-    dlt = dsum;
-    if (WRITE_DELTA && qvalid && fh == 0 && chunk == 0) {       // row constants of the dK/dV kernel (see attn_delta_kernel)
-      p.delta[li] = -dsum;
-      p.delta[(long long)p.B * p.H * p.Sq + li] = -lse2;
     }
   }
   // dP^T accumulates ON TOP OF -delta[q] (the MFMA's C operand: this lane's query, the same value in all 16 registers, for
@@ -778,7 +792,9 @@ __device__ __forceinline__ void attn_dkv_body(const AttnP& p, char* smem, int bl
     WAIT_VM0();
     __syncthreads();
   }
-  if (!kstored) return;
+  // (whole waves store rows there: ragged lanes stay; an accumulating store keeps the direct form -- fp32 sum, ONE rounding)
+  const bool lds_epi = PEA_ATTN_DKV_LDS_EPI && p.nsplit <= 1 && !p.accum_dkv;
+  if (lds_epi ? !wave_active : !kstored) return;
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -797,6 +813,44 @@ __device__ __forceinline__ void attn_dkv_body(const AttnP& p, char* smem, int bl
         *(f32x4*)(pr + d) = a;
         *(f32x4*)(pr + D + d) = cc;
       }
+    return;
+  }
+  if (lds_epi) {
+    // The accumulator layout has a key row per lane: written straight out that is sixteen 8-byte stores per lane, each
+    // touching 32 different 128-byte lines (store-issue-bound: ~9 k cycles per workgroup, paid once per 16 query tiles at
+    // 1024 tokens).  Each wave's 32 x 64 blocks of dK, then dV, go through its own 4.5 KiB LDS image (the ring is free
+    // behind the loop's last barrier; 144-byte pitch) and leave as whole rows, 16 bytes per lane, eight rows per instruction.
+    char* const ost = smem + wave * (32 * 144);
+    const int r8 = lane >> 3, ch = lane & 7;
+#pragma unroll
+    for (int which = 0; which < 2; ++which) {
+      f32x16* acc = which ? dv : dk;
+#pragma unroll
+      for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          bf16x4 o;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) o[j] = (bf16)acc[db][4 * g + j];
+          *(bf16x4*)(ost + frow * 144 + (db * 32 + 8 * g + 4 * fh) * 2) = o;
+        }
+      bf16* base = (which ? p.dV : p.dK) + (long long)b * p.Skv * (which ? p.lddv : p.lddk) + head * D + chunk * 64 + ch * 8;
+      const int ld_ = which ? p.lddv : p.lddk;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int row = i * 8 + r8;
+        if (k0 + row < p.Skv) {
+          bf16x8 v = *(const bf16x8*)(ost + row * 144 + ch * 16);
+          bf16* dst = base + (long long)(k0 + row) * ld_;
+          if (p.accum_dkv) {
+            const bf16x8 old = *(const bf16x8*)dst;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = (bf16)((float)v[j] + (float)old[j]);
+          }
+          *(bf16x8*)dst = v;
+        }
+      }
+    }
     return;
   }
   bf16* dKr = p.dK + ((long long)b * p.Skv + krow) * p.lddk + head * D + chunk * 64;
@@ -837,15 +891,32 @@ __global__ __launch_bounds__(256, (ND == 1 ? 2 : 1)) void attn_dkv_kernel(const 
 // then dK/dV blocks -- and XCD x owns a contiguous range of heads, so a head's Q / K / V / dO are read into one L2 once
 // for both roles.  delta comes from attn_delta_kernel (the roles run concurrently, so the dQ role cannot hand it over).
 template <bool USE_TR, int ND>
-__global__ __launch_bounds__(256, (ND == 1 ? 2 : 1)) void attn_bwd_fused_kernel(const AttnP p, int n_dq, int n_dkv) {
+__global__ __launch_bounds__(256, (ND == 1 ? 2 : 1)) void attn_bwd_fused_kernel(const AttnP p, int n_dq, int n_dkv, int heavy_first) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const unsigned total = gridDim.x;
   unsigned lin = blockIdx.x;
+  const int per_head = n_dq + n_dkv;
   if (p.xcd_remap) {
     const unsigned q = total >> 3, r = total & 7, xcd = lin & 7, j = lin >> 3;
-    lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+    const unsigned start = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q, cnt = q + (xcd < r ? 1u : 0u);
+    if (heavy_first && r == 0 && cnt % per_head == 0) {
+      // Dispatch order inside an XCD's range of heads: ALL dK/dV workgroups (4 products per tile) of those heads first, then
+      // all dQ workgroups (3 products).  The grid is 2.5 rounds of the chip's slots (1024 tokens, B * H = 80); the hardware
+      // hands a free slot the next workgroup in order, so what is left for the last, partly filled round should be the
+      // lighter role, and the heavy ones must not start last.  A head's operands then meet one L2 twice instead of once:
+      // the loops do not care (profiles/EXPERIMENTS.md: cache-resident operands are worth 2 % to self-attention).
+      const unsigned nh = cnt / per_head, first_bh = start / per_head;
+      unsigned bh_l, rem;
+      if (j < nh * (unsigned)n_dkv) { bh_l = j / n_dkv; rem = j - bh_l * n_dkv; }
+      else { const unsigned j2 = j - nh * n_dkv; bh_l = j2 / n_dq; rem = n_dkv + (j2 - bh_l * n_dq); }
+      const int bh = (int)(first_bh + bh_l);
+      const int b = bh / p.H, head = bh - b * p.H;
+      if ((int)rem < n_dkv) attn_dkv_body<USE_TR, ND>(p, smem, (int)rem, head, b);
+      else attn_q_body<1, USE_TR, ND, false, false>(p, smem, (int)rem - n_dkv, head, b);
+      return;
+    }
+    lin = start + j;
   }
-  const int per_head = n_dq + n_dkv;
   const int bh = (int)(lin / per_head), rem = (int)(lin - (unsigned)bh * per_head);
   const int b = bh / p.H, head = bh - b * p.H;
   if (rem < n_dkv) attn_dkv_body<USE_TR, ND>(p, smem, rem, head, b);          // heavier role (4 products) first
@@ -1311,34 +1382,453 @@ __global__ __launch_bounds__(256, 2) void xattn_bwd_kernel(const AttnP p, int up
     }
 }
 
-// row constants of the backward kernels: delta[0][b][h][q] = -sum_d dO[q][h*D+d] * O[q][h*D+d], delta[1][b][h][q] = -lse * log2(e);
-// 8 lanes per (row, head), each sums D/8 elements
-__global__ __launch_bounds__(256) void attn_delta_kernel(const AttnP p) {
-  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;   // one thread per (b, q, head, 8-lane slot)
-  const long long total = (long long)p.B * p.Sq * p.H * 8;
-  const int sub = (int)(idx & 7);
-  const int D = 64 * p.nd;
-  float s = 0.f, lse = 0.f;
-  long long row = idx >> 3, li = 0;
-  if (idx < total) {
-    const int head = (int)(row % p.H);
-    const long long bq = row / p.H;
-    const int b = (int)(bq / p.Sq), q = (int)(bq % p.Sq);
-    li = ((long long)b * p.H + head) * p.Sq + q;
-    if (sub == 0) lse = p.lse[li];                             // requested with the rows (behind the reduction: a second round trip)
-    for (int nd = 0; nd < p.nd; ++nd) {
-      const bf16x8 a = *(const bf16x8*)(p.dO + bq * p.lddo + head * D + nd * 64 + sub * 8);
-      const bf16x8 o = *(const bf16x8*)(p.O + bq * p.ldo + head * D + nd * 64 + sub * 8);
+// ============================================================================= cross-attention backward, v2 (round 6)
+// The one-pass kernel above runs BOTH orientations on every wave, one after the other, off a single-buffered 128-query
+// stage: per unit a wave walks LDS read -> MFMA -> exp -> MFMA chains of 100 MFMAs with nothing beside it on its SIMD but
+// the other workgroup's wave, and the DMA of the next unit starts only when the unit is done (30 us for 42 MB of traffic).
+// Here the unit is 64 queries, the stage is double buffered (the next unit's Q / dO / lse fly under this unit's work) and
+// the waves SPECIALISE, so the two orientations run side by side on different SIMDs:
+//   waves 0, 1  query on the lane: S^T, dP^T -> dS^T -> dQ^T = K^T dS^T of 32 queries each; dQ leaves through a per-wave
+//               LDS image as whole 128-byte rows (the row-per-lane accumulator layout is sixteen 8-byte pieces over 32 lines)
+//   waves 2, 3  key on the lane: S, dP -> P, dS -> dV^T += dO^T P, dK^T += Q^T dS.  KB = 3 key blocks x 2 query blocks
+//               = 6 tasks of 16 MFMAs: wave 2 takes (kb 0, both query blocks) + (kb 2, queries 0..31), wave 3 takes
+//               (kb 1, both) + (kb 2, queries 32..63) -- 48 MFMAs each against 36 on the dQ waves; the two partial sums
+//               of key block 2 meet through LDS behind the loop, (wave 2) + (wave 3), a fixed order.
+// LDS: K | V images (2 x 16 KB) + 2 stages x (Q tile | dO tile | lse | delta = 16.5 KB) + 2 x 4.5 KB dQ images = 74 KB:
+// two workgroups per CU.  KB = 2 (<= 64 keys: the 52-token student context un-merged) and KB = 3 (77 keys); other key
+// counts keep the kernel above.  PRE (Q prescaled by its projection, the product path): the scores leave the MFMA in the
+// log2 domain with -lse log2(e) as the C operand, p = exp2(acc) with no per-score FMA.
+template <int KB, bool PRE>
+__global__ __launch_bounds__(256, 2) void xattn_bwd2_kernel(const AttnP p, int upw) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int STG = 2 * TILE_BYTES + 512;
+  char* const Ksm = smem;
+  char* const Vsm = smem + 2 * TILE_BYTES;
+  char* const St = smem + 4 * TILE_BYTES;            // [2 stages][Q tile | dO tile | lse[64] | delta[64]]
+  char* const Ost = St + 2 * STG;                    // [2 waves][32 rows x 144 bytes]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int frow = lane & 31, fh = lane >> 5;
+  int split, head, b;
+  attn_block_coords(p.xcd_remap, split, head, b);
+  const int nu = (p.Sq + 63) >> 6;
+  const int u_begin = split * upw, u_end = min(nu, u_begin + upw);
+  const float c = PRE ? 1.f : p.scale * LOG2E;
+  const bf16* Qb = p.Q + (long long)b * p.Sq * p.ldq + head * 64;
+  const bf16* dOb = p.dO + (long long)b * p.Sq * p.lddo + head * 64;
+  const bf16* Ob = p.O + (long long)b * p.Sq * p.ldo + head * 64;
+  const bf16* Kb = p.K + (long long)b * p.Skv * p.ldk + head * 64;
+  const bf16* Vb = p.V + (long long)b * p.Skv * p.ldv + head * 64;
+  const float* lseb = p.lse + ((long long)b * p.H + head) * p.Sq;
+  const int skv_b = __builtin_amdgcn_readfirstlane(p.kv_len ? p.kv_len[b] : p.Skv);
+
+  const TileSrc qsrc = tile_src(Qb, p.ldq, p.Sq, wave, lane), dosrc = tile_src(dOb, p.lddo, p.Sq, wave, lane);
+  auto stage_unit = [&](int u, int st) {
+    char* const S0 = St + st * STG;
+    const int r0 = u * 64;
+    stage_tile(qsrc, r0, S0, wave);
+    stage_tile(dosrc, r0, S0 + TILE_BYTES, wave);
+    if (wave == 0) {
+      int r = r0 + lane;
+      r = r < p.Sq ? r : p.Sq - 1;
+      lds_dma4(lseb + r, S0 + 2 * TILE_BYTES);
+    }
+  };
+  // delta = rowsum(dO * O): thread = (query of the unit, quarter of the head dimension); O fetched one unit ahead
+  const int dq_l = tid >> 2, dqt = tid & 3;
+  bf16x8 o_pf[2];
+  auto fetch_o = [&](int u) {
+    int r = u * 64 + dq_l;
+    r = r < p.Sq ? r : p.Sq - 1;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) s += (float)a[j] * (float)o[j];
+    for (int i = 0; i < 2; ++i) o_pf[i] = *(const bf16x8*)(Ob + (long long)r * p.ldo + dqt * 16 + 8 * i);
+  };
+  {
+    const TileSrc ksrc = tile_src(Kb, p.ldk, p.Skv, wave, lane), vsrc = tile_src(Vb, p.ldv, p.Skv, wave, lane);
+    stage_tile(ksrc, 0, Ksm, wave);
+    stage_tile(vsrc, 0, Vsm, wave);
+    if (KB > 2) {
+      stage_tile(ksrc, 64, Ksm + TILE_BYTES, wave);
+      stage_tile(vsrc, 64, Vsm + TILE_BYTES, wave);
     }
   }
-  s += dpp_move<0xB1>(s);                                      // xor 1, xor 2, xor 4 over the 8 lanes of a row: DPP moves, no LDS
-  s += dpp_move<0x4E>(s);
-  s += dpp_move<0x141>(s);
-  if (idx < total && sub == 0) {
-    p.delta[li] = -s;                                                    // C operand of the dP products
-    p.delta[(long long)p.B * p.H * p.Sq + li] = -lse * LOG2E;            // addend of the exp2 argument
+  if (u_begin < u_end) {
+    stage_unit(u_begin, 0);
+    fetch_o(u_begin);
+  }
+  const bool key_wave = wave >= 2;
+  // the shared head of a unit, executed by every wave: wait for the unit's tiles, start the next unit's, form delta.
+  // Both role loops below call it once per unit, so every wave passes the same sequence of workgroup barriers.
+  auto unit_head = [&](int u) -> char* {
+    const int cur = (u - u_begin) & 1;
+    char* const S0 = St + cur * STG;
+    float* const rc = (float*)(S0 + 2 * TILE_BYTES);           // [0..63] lse -> -lse log2(e); [64..127] -delta
+    WAIT_VM0();
+    __syncthreads();                                           // unit u landed; every wave has left unit u - 1
+    if (u + 1 < u_end) stage_unit(u + 1, cur ^ 1);             // flies under this unit's work
+    {
+      const char* dt = S0 + TILE_BYTES;
+      float dsum = 0.f;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const bf16x8 d = *(const bf16x8*)(dt + dq_l * 128 + (((dqt * 2 + i) ^ swz_x(dq_l)) << 4));
+#pragma unroll
+        for (int j = 0; j < 8; ++j) dsum += (float)d[j] * (float)o_pf[i][j];
+      }
+      dsum += dpp_move<0xB1>(dsum);                            // lanes ^ 1, ^ 2: the four quarters of a query
+      dsum += dpp_move<0x4E>(dsum);
+      if (dqt == 0) {
+        const bool rv = u * 64 + dq_l < p.Sq;                  // rows past Sq (ragged last unit): P = exp2(-inf) = 0
+        rc[64 + dq_l] = rv ? -dsum : 0.f;
+        rc[dq_l] = rv ? -rc[dq_l] * LOG2E : -INFINITY;
+      }
+    }
+    if (u + 1 < u_end) fetch_o(u + 1);
+    __syncthreads();
+    return S0;
+  };
+
+  if (!key_wave) {
+    // ================= waves 0, 1: query on the lane -- dQ of queries 32 wave .. 32 wave + 31 of every unit
+    for (int u = u_begin; u < u_end; ++u) {
+      const char* const S0 = unit_head(u);
+      const char* const Qt = S0;
+      const char* const dOt = S0 + TILE_BYTES;
+      const float* const rc = (const float*)(S0 + 2 * TILE_BYTES);
+      const int rb0 = wave * 32;
+      const int qg = u * 64 + rb0;
+      bf16x8 qf[4], dof[4];
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        qf[s] = read_row_frag(Qt, rb0 + frow, s, fh);
+        dof[s] = read_row_frag(dOt, rb0 + frow, s, fh);
+      }
+      const float nlse2 = rc[rb0 + frow], ndlt = rc[64 + rb0 + frow];
+      f32x16 negd, rowc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { negd[r] = ndlt; rowc[r] = PRE ? nlse2 : 0.f; }
+      f32x16 oacc[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[i][r] = 0.f;
+#pragma unroll 1
+      for (int kb = 0; kb < KB; ++kb) {
+        const char* Kt = Ksm + (kb >> 1) * TILE_BYTES;
+        const char* Vt = Vsm + (kb >> 1) * TILE_BYTES;
+        const int kr0 = (kb & 1) * 32;
+        f32x16 sacc, dpacc;
+        {
+          bf16x8 kfr[4], vfr[4];
+#pragma unroll
+          for (int s = 0; s < 4; ++s) {
+            kfr[s] = read_row_frag(Kt, kr0 + frow, s, fh);
+            vfr[s] = read_row_frag(Vt, kr0 + frow, s, fh);
+          }
+          sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr[0], qf[0], rowc, 0, 0, 0);
+          dpacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfr[0], dof[0], negd, 0, 0, 0);
+#pragma unroll
+          for (int s = 1; s < 4; ++s) {
+            sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr[s], qf[s], sacc, 0, 0, 0);
+            dpacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfr[s], dof[s], dpacc, 0, 0, 0);
+          }
+        }
+        bf16x8 tfr[2][2];
+#pragma unroll
+        for (int k2 = 0; k2 < 2; ++k2)
+#pragma unroll
+          for (int db = 0; db < 2; ++db) tfr[k2][db] = read_transposed_frag<true>(Kt, kr0 + k2 * 16, db * 32, lane);
+        bf16x8 pf[2];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float pr = PRE ? fast_exp2(sacc[r]) : fast_exp2(fmaf(sacc[r], c, nlse2));
+          if (kb * 32 + 32 > skv_b)                               // uniform: only the key block that holds padding keys
+            pr = kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh < skv_b ? pr : 0.f;
+          pf[r >> 3][r & 7] = (bf16)(pr * dpacc[r]);
+        }
+#pragma unroll
+        for (int k2 = 0; k2 < 2; ++k2)
+#pragma unroll
+          for (int db = 0; db < 2; ++db)
+            oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tfr[k2][db], pf[k2], oacc[db], 0, 0, 0);
+      }
+      // dQ^T[d][q] -> LDS image [q][d] -> whole rows, 16 bytes per lane
+      char* const ost = Ost + wave * (32 * 144);
+#pragma unroll
+      for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          bf16x4 o;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) o[j] = (bf16)(oacc[db][4 * g + j] * p.scale);
+          *(bf16x4*)(ost + frow * 144 + (db * 32 + 8 * g + 4 * fh) * 2) = o;
+        }
+      const int r8 = lane >> 3, ch = lane & 7;
+      bf16* dQb = p.dQ + (long long)b * p.Sq * p.lddq + head * 64 + ch * 8;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int row = i * 8 + r8;
+        if (qg + row < p.Sq) {
+          bf16x8 v = *(const bf16x8*)(ost + row * 144 + ch * 16);
+          bf16* dst = dQb + (long long)(qg + row) * p.lddq;
+          if (p.accum_dq) {
+            const bf16x8 old = *(const bf16x8*)dst;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = (bf16)((float)v[j] + (float)old[j]);
+          }
+          *(bf16x8*)dst = v;
+        }
+      }
+    }
+    if (KB > 2) {                                                // the two barriers of the key waves' hand-over below
+      __syncthreads();
+      __syncthreads();
+    }
+    return;
+  }
+
+  // ================= waves 2, 3: key on the lane.  Accumulator slots: 0 = the wave's own key block (wave 2: kb 0, wave 3:
+  // kb 1), 1 = its half of kb 2.  (The role loops are separate code paths so that these 128 registers are not live across
+  // the dQ role's code: as one loop with a branch per unit the kernel needed 312 registers and spilled 110.)
+  constexpr int NS = KB > 2 ? 2 : 1;
+  f32x16 dk[NS][2], dv[NS][2];
+#pragma unroll
+  for (int sl = 0; sl < NS; ++sl)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dk[sl][i][r] = dv[sl][i][r] = 0.f;
+  const int kw = wave - 2;                                        // 0 / 1
+  for (int u = u_begin; u < u_end; ++u) {
+    const char* const S0 = unit_head(u);
+    const char* const Qt = S0;
+    const char* const dOt = S0 + TILE_BYTES;
+    const float* const rc = (const float*)(S0 + 2 * TILE_BYTES);
+    // three (key block, query block) tasks per wave (two when KB == 2); phases fenced (sched_barrier) so that hipcc does not
+    // hoist the next phase's fragment reads over the MFMAs beside the 128 accumulator registers
+    auto key_task = [&](const int kb, const int qb, f32x16 (&dkt)[2], f32x16 (&dvt)[2]) {
+      if (kb * 32 >= p.Skv) return;                             // uniform
+      const char* Kmine = Ksm + (kb >> 1) * TILE_BYTES;
+      const char* Vmine = Vsm + (kb >> 1) * TILE_BYTES;
+      const int kmine_row = (kb & 1) * 32 + frow;
+      const bool kvalid = kb * 32 + frow < skv_b;
+      const bool blk_pad = kb * 32 + 32 > skv_b;                // uniform: this key block holds padding keys
+      const int rb0 = qb * 32;
+      f32x16 sacc, dpacc;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {                            // rows = queries: the staged row constants ARE the C operands
+        const f32x4 d4 = *(const f32x4*)(rc + 64 + rb0 + 8 * g + 4 * fh);
+        const f32x4 l4 = *(const f32x4*)(rc + rb0 + 8 * g + 4 * fh);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          dpacc[4 * g + j] = d4[j];
+          sacc[4 * g + j] = PRE ? l4[j] : 0.f;
+        }
+      }
+      {
+        bf16x8 qfr[4], kf[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          qfr[s] = read_row_frag(Qt, rb0 + frow, s, fh);
+          kf[s] = read_row_frag(Kmine, kmine_row, s, fh);
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s) sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qfr[s], kf[s], sacc, 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      {
+        bf16x8 dfr[4], vf[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          dfr[s] = read_row_frag(dOt, rb0 + frow, s, fh);
+          vf[s] = read_row_frag(Vmine, kmine_row, s, fh);
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s) dpacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dfr[s], vf[s], dpacc, 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      bf16x8 pfr[2], dsfr[2];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        f32x4 l4 = {0.f, 0.f, 0.f, 0.f};
+        if (!PRE) l4 = *(const f32x4*)(rc + rb0 + 8 * g + 4 * fh);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int r = 4 * g + j;
+          float pr = PRE ? fast_exp2(sacc[r]) : fast_exp2(fmaf(sacc[r], c, l4[j]));
+          if (blk_pad) pr = kvalid ? pr : 0.f;
+          const float ds = pr * dpacc[r];
+          pfr[g >> 1][(g & 1) * 4 + j] = (bf16)pr;
+          dsfr[g >> 1][(g & 1) * 4 + j] = (bf16)ds;
+        }
+      }
+#pragma unroll
+      for (int k2 = 0; k2 < 2; ++k2) {
+        __builtin_amdgcn_sched_barrier(0);
+        bf16x8 dot[2], qt[2];
+#pragma unroll
+        for (int db = 0; db < 2; ++db) {
+          dot[db] = read_transposed_frag<true>(dOt, rb0 + k2 * 16, db * 32, lane);
+          qt[db] = read_transposed_frag<true>(Qt, rb0 + k2 * 16, db * 32, lane);
+        }
+#pragma unroll
+        for (int db = 0; db < 2; ++db) {
+          dvt[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dot[db], pfr[k2], dvt[db], 0, 0, 0);
+          dkt[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qt[db], dsfr[k2], dkt[db], 0, 0, 0);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    key_task(kw, 0, dk[0], dv[0]);
+    key_task(kw, 1, dk[0], dv[0]);
+    if (KB > 2) key_task(2, kw, dk[NS - 1], dv[NS - 1]);
+  }
+  // ---- dK / dV out.  KB == 3: wave 3 hands its half of key block 2 to wave 2 through LDS (lane-private 16-byte slots:
+  // both waves hold the same (key, d) elements on the same lanes); (wave 2) + (wave 3), always in that order.
+  if (KB > 2) {
+    __syncthreads();                                             // every wave is done with the stages
+    float* const X = (float*)St;                                 // 16 slots x 64 lanes x 16 bytes = 16 KB
+    if (wave == 3) {
+#pragma unroll
+      for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          f32x4 a, cc;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { a[j] = dk[NS - 1][db][4 * g + j]; cc[j] = dv[NS - 1][db][4 * g + j]; }
+          *(f32x4*)(X + ((db * 4 + g) * 2 + 0) * 256 + lane * 4) = a;
+          *(f32x4*)(X + ((db * 4 + g) * 2 + 1) * 256 + lane * 4) = cc;
+        }
+    }
+    __syncthreads();
+    if (wave == 2) {
+#pragma unroll
+      for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const f32x4 a = *(const f32x4*)(X + ((db * 4 + g) * 2 + 0) * 256 + lane * 4);
+          const f32x4 cc = *(const f32x4*)(X + ((db * 4 + g) * 2 + 1) * 256 + lane * 4);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { dk[NS - 1][db][4 * g + j] += a[j]; dv[NS - 1][db][4 * g + j] += cc[j]; }
+        }
+    }
+  }
+  const float dks = PRE ? 0.6931471805599453f : p.scale;         // dS^T Q' = scale log2(e) dS^T Q
+#pragma unroll
+  for (int sl = 0; sl < NS; ++sl) {
+    if (sl == 1 && wave != 2) break;                              // the shared block leaves from wave 2
+    const int kb = sl == 0 ? wave - 2 : 2;
+    const int krow = kb * 32 + frow;
+    if (krow >= p.Skv) continue;
+    if (p.nsplit > 1) {
+      float* pr = p.dkv_part + ((((long long)split * p.B + b) * p.H + head) * p.Skv + krow) * 128;
+#pragma unroll
+      for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int d = db * 32 + 8 * g + 4 * fh;
+          f32x4 a, cc;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { a[j] = dk[sl][db][4 * g + j] * dks; cc[j] = dv[sl][db][4 * g + j]; }
+          *(f32x4*)(pr + d) = a;
+          *(f32x4*)(pr + 64 + d) = cc;
+        }
+    } else {
+      bf16* dKr = p.dK + ((long long)b * p.Skv + krow) * p.lddk + head * 64;
+      bf16* dVr = p.dV + ((long long)b * p.Skv + krow) * p.lddv + head * 64;
+#pragma unroll
+      for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int d = db * 32 + 8 * g + 4 * fh;
+          bf16x4 ok, ov;
+          if (p.accum_dkv) {
+            ok = *(const bf16x4*)(dKr + d);
+            ov = *(const bf16x4*)(dVr + d);
+          }
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            ok[j] = (bf16)(dk[sl][db][4 * g + j] * dks + (p.accum_dkv ? (float)ok[j] : 0.f));
+            ov[j] = (bf16)(dv[sl][db][4 * g + j] + (p.accum_dkv ? (float)ov[j] : 0.f));
+          }
+          *(bf16x4*)(dKr + d) = ok;
+          *(bf16x4*)(dVr + d) = ov;
+        }
+    }
+  }
+}
+
+// row constants of the backward kernels: delta[0][b][h][q] = -sum_d dO[q][h*D+d] * O[q][h*D+d], delta[1][b][h][q] = -lse * log2(e);
+// 8 lanes per (row, head), each sums D/8 elements
+#ifndef PEA_ATTN_DELTA_ROWS
+#define PEA_ATTN_DELTA_ROWS 4      // (row, head) slots per thread, all requested before the first use: a thread with ONE pair of 16-byte loads in
+                                   // flight left the kernel latency-bound (9.6 us for 21 MB); 1 restores that form
+#endif
+__global__ __launch_bounds__(256) void attn_delta_kernel(const AttnP p) {
+  constexpr int NR = PEA_ATTN_DELTA_ROWS;
+  const long long total = (long long)p.B * p.Sq * p.H * 8;            // one lane per (b, q, head, 8-lane slot)
+  const long long stride = (long long)gridDim.x * 256;                // slot r of a thread: idx + r * stride (coalesced per r)
+  const long long idx0 = (long long)blockIdx.x * 256 + threadIdx.x;
+  const int D = 64 * p.nd;
+  bf16x8 a[NR], o[NR];
+  float lse[NR];
+  long long li[NR];
+  bool ok[NR];
+  if (p.nd == 1) {
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+      const long long idx = idx0 + r * stride;
+      ok[r] = idx < total;
+      const int sub = (int)(idx & 7);
+      const long long row = (ok[r] ? idx : 0) >> 3;
+      const int head = (int)(row % p.H);
+      const long long bq = row / p.H;
+      const int b = (int)(bq / p.Sq), q = (int)(bq % p.Sq);
+      li[r] = ((long long)b * p.H + head) * p.Sq + q;
+      a[r] = *(const bf16x8*)(p.dO + bq * p.lddo + head * D + sub * 8);
+      o[r] = *(const bf16x8*)(p.O + bq * p.ldo + head * D + sub * 8);
+      lse[r] = p.lse[li[r]];
+    }
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+      float s = 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s += (float)a[r][j] * (float)o[r][j];
+      s += dpp_move<0xB1>(s);                                  // xor 1, xor 2, xor 4 over the 8 lanes of a row: DPP moves, no LDS
+      s += dpp_move<0x4E>(s);
+      s += dpp_move<0x141>(s);
+      if (ok[r] && ((idx0 + r * stride) & 7) == 0) {
+        p.delta[li[r]] = -s;                                                     // C operand of the dP products
+        p.delta[(long long)p.B * p.H * p.Sq + li[r]] = -lse[r] * LOG2E;          // addend of the exp2 argument
+      }
+    }
+    return;
+  }
+  for (int r = 0; r < NR; ++r) {                                // padded head widths (text towers, SD1.5): the plain loop
+    const long long idx = idx0 + r * stride;
+    const int sub = (int)(idx & 7);
+    float s = 0.f, l = 0.f;
+    long long row = idx >> 3, lin = 0;
+    if (idx < total) {
+      const int head = (int)(row % p.H);
+      const long long bq = row / p.H;
+      const int b = (int)(bq / p.Sq), q = (int)(bq % p.Sq);
+      lin = ((long long)b * p.H + head) * p.Sq + q;
+      if (sub == 0) l = p.lse[lin];
+      for (int nd = 0; nd < p.nd; ++nd) {
+        const bf16x8 av = *(const bf16x8*)(p.dO + bq * p.lddo + head * D + nd * 64 + sub * 8);
+        const bf16x8 ov = *(const bf16x8*)(p.O + bq * p.ldo + head * D + nd * 64 + sub * 8);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s += (float)av[j] * (float)ov[j];
+      }
+    }
+    s += dpp_move<0xB1>(s);
+    s += dpp_move<0x4E>(s);
+    s += dpp_move<0x141>(s);
+    if (idx < total && sub == 0) {
+      p.delta[lin] = -s;
+      p.delta[(long long)p.B * p.H * p.Sq + lin] = -l * LOG2E;
+    }
   }
 }
 
@@ -1374,16 +1864,21 @@ __global__ void attn_dkv_reduce_kernel(const AttnP p) {
 // 128-query units of one (batch, head); pick the u that minimises (rounds of 512 workgroups: two per CU) x u, then the
 // split count (fp32 partials per split).  1024 tokens, B*H = 80: u = 2 -> 320 workgroups, 4 splits; 4096 tokens, 40:
 // u = 3 -> 440 workgroups, 11 splits.
+// v2 of the one-pass cross-attention backward (xattn_bwd2_kernel: 64-query units, specialised waves): 33 .. 96 keys
+static int g_xattn_v2 = getenv("PEA_XATTN_BWD_V1") ? 0 : 1;              // PEA_XATTN_BWD_V1=1: the round-3 kernel for every key count (A/B)
+extern "C" void pea_debug_set_xattn_bwd_v2(int v) { g_xattn_v2 = v; }
+static bool xattn_v2_keys(int Skv) { return g_xattn_v2 && Skv > 32 && Skv <= 96; }
 int attention_bwd_nsplit(int B, int H, int Sq, int Skv) {
   if (Skv > 128 || Sq < 512) return 1;
-  const int nu = (Sq + 127) / 128;
+  const int uq = xattn_v2_keys(Skv) ? 64 : 128;                          // queries per unit
+  const int nu = (Sq + uq - 1) / uq;
   const long long bh = (long long)B * H;
   long long best = -1;
   int best_ns = 1;
   for (int u = 1; u <= nu; ++u) {
     const int ns = (nu + u - 1) / u;
     const long long rounds = (bh * ns + 511) / 512;
-    const long long cost = rounds * u * 64 + ns;
+    const long long cost = rounds * u * (uq / 2) + ns;
     if (best < 0 || cost < best) { best = cost; best_ns = ns; }
   }
   return best_ns;
@@ -1485,13 +1980,34 @@ static int attn_bwd_nd(const AttnP& p, hipStream_t s) {
         HIPCHK(hipFuncSetAttribute((const void*)xattn_bwd_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         attr = true;
       }
-      const int ns = p.nsplit > 1 ? p.nsplit : 1, nu = cdiv(p.Sq, 128), upw = cdiv(nu, ns);
+      const int ns = p.nsplit > 1 ? p.nsplit : 1;
       const dim3 grid(ns, p.H, p.B);
       const int kb = cdiv(p.Skv, 32);
+      if (xattn_v2_keys(p.Skv)) {
+        constexpr int lds2 = 4 * TILE_BYTES + 2 * (2 * TILE_BYTES + 512) + 2 * 32 * 144;
+        static bool attr2 = false;
+        if (!attr2) {
+          HIPCHK(hipFuncSetAttribute((const void*)xattn_bwd2_kernel<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds2));
+          HIPCHK(hipFuncSetAttribute((const void*)xattn_bwd2_kernel<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds2));
+          HIPCHK(hipFuncSetAttribute((const void*)xattn_bwd2_kernel<3, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds2));
+          HIPCHK(hipFuncSetAttribute((const void*)xattn_bwd2_kernel<3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds2));
+          attr2 = true;
+        }
+        const int upw2 = cdiv(cdiv(p.Sq, 64), ns);
+        if (kb == 2) {
+          if (p.q_prescaled) hipLaunchKernelGGL((xattn_bwd2_kernel<2, true>), grid, dim3(256), lds2, s, p, upw2);
+          else hipLaunchKernelGGL((xattn_bwd2_kernel<2, false>), grid, dim3(256), lds2, s, p, upw2);
+        } else {
+          if (p.q_prescaled) hipLaunchKernelGGL((xattn_bwd2_kernel<3, true>), grid, dim3(256), lds2, s, p, upw2);
+          else hipLaunchKernelGGL((xattn_bwd2_kernel<3, false>), grid, dim3(256), lds2, s, p, upw2);
+        }
+      } else {
+      const int nu = cdiv(p.Sq, 128), upw = cdiv(nu, ns);
       if (kb == 1) hipLaunchKernelGGL(xattn_bwd_kernel<1>, grid, dim3(256), lds, s, p, upw);
       else if (kb == 2) hipLaunchKernelGGL(xattn_bwd_kernel<2>, grid, dim3(256), lds, s, p, upw);
       else if (kb == 3) hipLaunchKernelGGL(xattn_bwd_kernel<3>, grid, dim3(256), lds, s, p, upw);
       else hipLaunchKernelGGL(xattn_bwd_kernel<4>, grid, dim3(256), lds, s, p, upw);
+      }
       if (p.nsplit > 1) {
         const long long total = (long long)p.B * p.H * p.Skv * 2 * 16;
         hipLaunchKernelGGL(attn_dkv_reduce_kernel, dim3((unsigned)cdivl(total, 256)), dim3(256), 0, s, p);
@@ -1509,8 +2025,9 @@ static int attn_bwd_nd(const AttnP& p, hipStream_t s) {
     }
     const int n_dq = cdiv(p.Sq, 128) * ND, n_dkv = cdiv(p.Skv, 128) * (p.nsplit > 1 ? p.nsplit : 1) * ND;
     const dim3 grid((unsigned)((n_dq + n_dkv) * p.H * p.B));
-    if (g_attn_use_tr) hipLaunchKernelGGL((attn_bwd_fused_kernel<true, ND>), grid, dim3(256), lds, s, p, n_dq, n_dkv);
-    else hipLaunchKernelGGL((attn_bwd_fused_kernel<false, ND>), grid, dim3(256), lds, s, p, n_dq, n_dkv);
+    static const int heavy_first = getenv("PEA_ATTN_BWD_HEAVY_FIRST") ? atoi(getenv("PEA_ATTN_BWD_HEAVY_FIRST")) : 0;
+    if (g_attn_use_tr) hipLaunchKernelGGL((attn_bwd_fused_kernel<true, ND>), grid, dim3(256), lds, s, p, n_dq, n_dkv, heavy_first);
+    else hipLaunchKernelGGL((attn_bwd_fused_kernel<false, ND>), grid, dim3(256), lds, s, p, n_dq, n_dkv, heavy_first);
     if (p.nsplit > 1) {
       const long long total = (long long)p.B * p.H * p.Skv * 2 * 16 * ND;
       hipLaunchKernelGGL(attn_dkv_reduce_kernel, dim3((unsigned)cdivl(total, 256)), dim3(256), 0, s, p);
@@ -1564,7 +2081,7 @@ int launch_attention_bwd(const AttnP& p0, hipStream_t s) {
   // delta: its own (memory-bound) kernel for the fused launch and for dK/dV-only calls; the two-launch form computes it
   // inside the dQ pass
   if (!attn_use_xattn(p) && (!p.dQ || (p.dK && p.dV && g_attn_fused_bwd)))
-    hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)cdivl(total, 256)), dim3(256), 0, s, p);
+    hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)cdivl(total, 256 * PEA_ATTN_DELTA_ROWS)), dim3(256), 0, s, p);
   rc = p.nd == 1 ? attn_bwd_nd<1>(p, s) : p.nd == 2 ? attn_bwd_nd<2>(p, s) : attn_bwd_nd<3>(p, s);
   PROF_END(s);
   if (rc) return rc;

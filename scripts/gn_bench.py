@@ -16,7 +16,7 @@ def timeit(fn, iters=50):
 
 print("PEA_GN_UNFUSED =", os.environ.get("PEA_GN_UNFUSED"))
 for (B, HW, C) in [(8, 1024, 1280), (8, 1024, 2560), (8, 1024, 1920), (8, 4096, 640), (8, 4096, 1280), (8, 4096, 1920), (8, 4096, 960),
-                   (8, 16384, 320), (8, 16384, 640), (4, 1024, 1280), (4, 1024, 2560), (4, 4096, 640), (4, 4096, 1280)]:
+                   (8, 16384, 320), (8, 16384, 640), (4, 1024, 1280), (4, 1024, 2560), (4, 4096, 640), (4, 4096, 1280), (4, 16384, 320), (4, 16384, 640), (4, 4096, 1920)]:
     x = torch.randn(B, HW, C, device="cuda").bfloat16(); dy = torch.randn_like(x)
     gamma = torch.ones(C, device="cuda"); beta = torch.zeros(C, device="cuda")
     y, stats = ops.groupnorm_fwd(x, gamma, beta, 32, 1e-5, True)

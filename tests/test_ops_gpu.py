@@ -494,6 +494,58 @@ def test_attention_fwd_bwd(ops, use_tr, B, H, Sq, Skv, prescaled):
 
 
 @pytest.mark.parametrize("prescaled", [True, False])
+@pytest.mark.parametrize("B,H,Sq,Skv", [(2, 3, 1024, 77), (1, 2, 4096, 77), (2, 2, 1000, 52), (1, 2, 2048, 64), (1, 1, 192, 77),
+                                        (1, 2, 576, 96), (3, 2, 640, 40)])
+def test_cross_attention_bwd_specialised_waves(ops, B, H, Sq, Skv, prescaled):
+    """xattn_bwd2_kernel (round 6: 64-query units, double-buffered stage, waves 0-1 = dQ role, waves 2-3 = dK/dV role, the
+    third key block split between the two key waves and summed through LDS) against the fp32 reference AND against the round-3
+    one-pass kernel it replaces (pea_debug_set_xattn_bwd_v2(0)) on the same inputs: 2 and 3 key blocks, whole and ragged
+    query counts (1000 = 15 units + 40 rows), 1..16 query splits, the accumulate-into form of dQ / dK / dV (+=, as a tensor
+    with a second consumer gets it), plain and prescaled Q.  Bit-reproducible: two launches agree exactly."""
+    import ctypes
+    from pea_diffusion_amd._lib import check, lib, ptr, stream_ptr
+    L = lib()
+    q, k, v = bfr(B, Sq, H * 64, seed=11), bfr(B, Skv, H * 64, seed=12), bfr(B, Skv, H * 64, seed=13)
+    if prescaled:
+        q = (q.float() * ALPHA).to(BF)
+    qr = (q.float() / ALPHA if prescaled else q.float()).requires_grad_(True)
+    kr, vr = [t.float().requires_grad_(True) for t in (k, v)]
+    oref, _ = _attn_ref(qr, kr, vr, H)
+    do = bfr(B, Sq, H * 64, seed=14)
+    oref.backward(do.float())
+    qc, kc, vc, doc = q.cuda(), k.cuda(), v.cuda(), do.cuda()
+    o, lse = ops.attention_fwd(qc, kc, vc, H, q_prescaled=prescaled)
+    tag = f"xattn-bwd2 pre{int(prescaled)} B{B} H{H} Sq{Sq} Skv{Skv}"
+    try:
+        got = {}
+        for ver in (1, 0, 1):
+            L.pea_debug_set_xattn_bwd_v2(ver)
+            g = ops.attention_bwd(qc, kc, vc, o, doc, lse, H, q_prescaled=prescaled)
+            torch.cuda.synchronize()
+            if ver in got:
+                assert all(torch.equal(a, b_) for a, b_ in zip(got[ver], g)), tag + ": two launches differ"
+            got[ver] = g
+        for name, a, r in zip(("dQ", "dK", "dV"), got[1], (qr.grad, kr.grad, vr.grad)):
+            close_bf16(f"{tag} {name}", a, r, ulps=4.0)
+        for name, a, b_ in zip(("dQ", "dK", "dV"), got[1], got[0]):       # the two kernels: same algorithm, other summation order
+            close_bf16(f"{tag} {name} v2-vs-v1", a, b_.float().cpu(), ulps=2.0)
+        # accumulate-into: dX = X0 + gradient (direct bf16 form when there is no query split, i.e. without the scratch)
+        L.pea_debug_set_xattn_bwd_v2(1)
+        C = H * 64
+        x0 = [bfr(*t.shape, seed=20 + i).cuda() for i, t in enumerate((q, k, v))]
+        acc = [t.clone() for t in x0]
+        delta = torch.empty(2, B, H, Sq, device="cuda", dtype=torch.float32)
+        fn = L.pea_op_attention_bwd_prescaled if prescaled else L.pea_op_attention_bwd
+        check(fn(ptr(qc), C, ptr(kc), C, ptr(vc), C, ptr(o), C, ptr(doc), C, ptr(lse), ptr(delta), ptr(acc[0]), C, ptr(acc[1]), C,
+                 ptr(acc[2]), C, B, H, Sq, Skv, 0.125, 1, 1, 1, None, stream_ptr()))
+        torch.cuda.synchronize()
+        for name, a, x, r in zip(("dQ", "dK", "dV"), acc, x0, (qr.grad, kr.grad, vr.grad)):
+            close_bf16(f"{tag} {name} accumulate", a, x.float().cpu() + r, ulps=4.0)
+    finally:
+        L.pea_debug_set_xattn_bwd_v2(1)
+
+
+@pytest.mark.parametrize("prescaled", [True, False])
 @pytest.mark.parametrize("spike,tile_key", [(4.0, 200), (4.0, 70), (0.6, 200), (1.0, 1000)])
 def test_attention_softmax_spike(ops, prescaled, spike, tile_key):
     """Forces (spike 4: +46 in log2 units) or just avoids (0.6: below ATTN_MOVE_THR) a late jump of one query's score offset --
