@@ -489,7 +489,9 @@ void pea_debug_set_attn_tr(int v);
 void pea_debug_set_attn_fused_bwd(int v);
 /* 0: cross-attention backward (<= 128 keys, head_dim 64) on the general kernels instead of the one-pass kernel (A/B) */
 void pea_debug_set_attn_xattn(int v);
-/* 0: cross-attention backward with 33..96 keys on the round-3 one-pass kernel instead of the specialised-wave kernel (A/B) */
+/* which one-pass cross-attention backward kernel (A/B, parity tests): 0 = the round-3 kernel for every key count; 2 = the
+ * specialised-wave kernel (33..96 keys, 7 products); 1 or 3 = the newest that applies (default): the five-product kernel for
+ * 33..80 keys, the specialised-wave kernel for 81..96 */
 void pea_debug_set_xattn_bwd_v2(int v);
 /* A/B aid: 1 = GEGLU backward inside the FF output projection's dgrad GEMM (default), 0 = its own kernel */
 void pea_debug_set_geglu_bwd_fused(int v);

@@ -1382,6 +1382,30 @@ __global__ __launch_bounds__(256, 2) void xattn_bwd_kernel(const AttnP p, int up
     }
 }
 
+// one 16-byte element of the split reduce (head_dim 64): out[b][key][h*64+d] (+)= sum_split part[split][b][h][key][{dK,dV}][d],
+// splits added in order.  Shared by attn_dkv_reduce_kernel's nd == 1 case in spirit; used by xattn_bwd2_kernel's prologue.
+__device__ __forceinline__ void dkv_reduce_elem64(const float* __restrict__ part, bf16* dK, bf16* dV, int lddk, int lddv, int ns,
+                                                  int B, int H, int Skv, int accum, long long idx) {
+  const int d4 = (int)(idx & 15) * 4;
+  long long r = idx >> 4;
+  const int which = (int)(r & 1); r >>= 1;
+  const int key = (int)(r % Skv); r /= Skv;
+  const int head = (int)(r % H);
+  const int b = (int)(r / H);
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  for (int s = 0; s < ns; ++s) {
+    const f32x4 v = *(const f32x4*)(part + ((((long long)s * B + b) * H + head) * Skv + key) * 128 + which * 64 + d4);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[j] += v[j];
+  }
+  bf16* dst = which ? dV + ((long long)b * Skv + key) * lddv + head * 64 + d4 : dK + ((long long)b * Skv + key) * lddk + head * 64 + d4;
+  bf16x4 o;
+  if (accum) o = *(const bf16x4*)dst;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) o[j] = (bf16)(acc[j] + (accum ? (float)o[j] : 0.f));
+  *(bf16x4*)dst = o;
+}
+
 // ============================================================================= cross-attention backward, v2 (round 6)
 // The one-pass kernel above runs BOTH orientations on every wave, one after the other, off a single-buffered 128-query
 // stage: per unit a wave walks LDS read -> MFMA -> exp -> MFMA chains of 100 MFMAs with nothing beside it on its SIMD but
@@ -1455,6 +1479,16 @@ __global__ __launch_bounds__(256, 2) void xattn_bwd2_kernel(const AttnP p, int u
   if (u_begin < u_end) {
     stage_unit(u_begin, 0);
     fetch_o(u_begin);
+  }
+  // Deferred split reduce of ANOTHER launch (the previous cross-attention layer of the backward pass: AttnP::red_*): every
+  // workgroup adds up its share of those partials while its own K / V / first unit are in flight -- 70 launches of a 5.8 us
+  // kernel per step otherwise.  Nothing here depends on this workgroup's own data.
+  if (p.red_part) {
+    const long long total = (long long)p.red_B * p.red_H * p.red_Skv * 32;
+    const long long nthr = (long long)gridDim.x * gridDim.y * gridDim.z * 256;
+    const long long first = ((long long)blockIdx.x + gridDim.x * (blockIdx.y + (long long)gridDim.y * blockIdx.z)) * 256 + tid;
+    for (long long idx = first; idx < total; idx += nthr)
+      dkv_reduce_elem64(p.red_part, p.red_dK, p.red_dV, p.red_lddk, p.red_lddv, p.red_nsplit, p.red_B, p.red_H, p.red_Skv, p.red_accum, idx);
   }
   const bool key_wave = wave >= 2;
   // the shared head of a unit, executed by every wave: wait for the unit's tiles, start the next unit's, form delta.
@@ -1758,6 +1792,321 @@ __global__ __launch_bounds__(256, 2) void xattn_bwd2_kernel(const AttnP p, int u
   }
 }
 
+// ============================================================================= cross-attention backward, v3: FIVE products
+// v2 above still computes S and dP twice (once per orientation): 7 matrix products and two exponentials per score for an
+// algorithm that has 5 and one.  With <= 80 keys the whole key range of a (batch, head) sits in one workgroup, so dQ needs no
+// sum across workgroups and the two orientations can share one evaluation: the KEY waves (key on the lane) compute S, dP ->
+// P, dS once, feed dV^T += dO^T P and dK^T += Q^T dS from their accumulators as before, and drop dS (bf16) into an LDS
+// image [key][query]; the dQ wave reads it back through the transpose read as the B operand of dQ^T = K^T dS^T (the same
+// k-permutation as its A operand, the transposed K fragment), one unit behind the key waves.
+//   wave 0 = dQ of all 64 queries of the previous unit (KB = 3: 20 MFMAs -- the sixth 16-key slice, keys 80..95, is padding
+//   and skipped), waves 1 .. KB = key blocks 0 .. KB - 1 (32 MFMAs each); KB = 2 (33..64 keys) leaves wave 3 idle.
+// 120 MFMAs and 96 exponentials per 64-query unit instead of 168 and 192, no accumulator hand-over behind the loop.
+// LDS: K | V images of 96 rows (24 KB) + 2 stages x 16.5 KB + 2 dS images of 80 key rows (20 KB) = 77 KB: two workgroups
+// per CU; the dQ wave's output image reuses the dS image it has just read into registers.
+template <int KB, bool PRE>
+__global__ __launch_bounds__(256, 2) void xattn_bwd3_kernel(const AttnP p, int upw) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int STG = 2 * TILE_BYTES + 512;
+  constexpr int KV_IMG = TILE_BYTES + TILE_BYTES / 2;            // 96 rows
+  constexpr int DS_IMG = TILE_BYTES + 2048;                      // 80 key rows x 128 bytes (64 queries)
+  char* const Ksm = smem;
+  char* const Vsm = smem + KV_IMG;
+  char* const St = smem + 2 * KV_IMG;                            // [2 stages][Q tile | dO tile | lse[64] | delta[64]]
+  char* const Dsm = St + 2 * STG;                                // [2][80 keys][64 queries] bf16, tile format
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int frow = lane & 31, fh = lane >> 5;
+  int split, head, b;
+  attn_block_coords(p.xcd_remap, split, head, b);
+  const int nu = (p.Sq + 63) >> 6;
+  const int u_begin = split * upw, u_end = min(nu, u_begin + upw);
+  const float c = PRE ? 1.f : p.scale * LOG2E;
+  const bf16* Qb = p.Q + (long long)b * p.Sq * p.ldq + head * 64;
+  const bf16* dOb = p.dO + (long long)b * p.Sq * p.lddo + head * 64;
+  const bf16* Ob = p.O + (long long)b * p.Sq * p.ldo + head * 64;
+  const bf16* Kb = p.K + (long long)b * p.Skv * p.ldk + head * 64;
+  const bf16* Vb = p.V + (long long)b * p.Skv * p.ldv + head * 64;
+  const float* lseb = p.lse + ((long long)b * p.H + head) * p.Sq;
+  const int skv_b = __builtin_amdgcn_readfirstlane(p.kv_len ? p.kv_len[b] : p.Skv);
+
+  const TileSrc qsrc = tile_src(Qb, p.ldq, p.Sq, wave, lane), dosrc = tile_src(dOb, p.lddo, p.Sq, wave, lane);
+  auto stage_unit = [&](int u, int st) {
+    char* const S0 = St + st * STG;
+    const int r0 = u * 64;
+    stage_tile(qsrc, r0, S0, wave);
+    stage_tile(dosrc, r0, S0 + TILE_BYTES, wave);
+    if (wave == 0) {
+      int r = r0 + lane;
+      r = r < p.Sq ? r : p.Sq - 1;
+      lds_dma4(lseb + r, S0 + 2 * TILE_BYTES);
+    }
+  };
+  const int dq_l = tid >> 2, dqt = tid & 3;                       // delta: thread = (query of the unit, quarter of the head dim)
+  bf16x8 o_pf[2];
+  auto fetch_o = [&](int u) {
+    int r = u * 64 + dq_l;
+    r = r < p.Sq ? r : p.Sq - 1;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) o_pf[i] = *(const bf16x8*)(Ob + (long long)r * p.ldo + dqt * 16 + 8 * i);
+  };
+  {
+    const TileSrc ksrc = tile_src(Kb, p.ldk, p.Skv, wave, lane), vsrc = tile_src(Vb, p.ldv, p.Skv, wave, lane);
+    stage_tile(ksrc, 0, Ksm, wave);
+    stage_tile(vsrc, 0, Vsm, wave);
+    if (KB > 2 && wave < 2) {                                     // rows 64..95: the first four 1 KiB pieces of the second tile
+      stage_tile(ksrc, 64, Ksm + TILE_BYTES, wave);
+      stage_tile(vsrc, 64, Vsm + TILE_BYTES, wave);
+    }
+  }
+  if (u_begin < u_end) {
+    stage_unit(u_begin, 0);
+    fetch_o(u_begin);
+  }
+  if (p.red_part) {                                               // deferred split reduce of another launch (see xattn_bwd2_kernel)
+    const long long total = (long long)p.red_B * p.red_H * p.red_Skv * 32;
+    const long long nthr = (long long)gridDim.x * gridDim.y * gridDim.z * 256;
+    const long long first = ((long long)blockIdx.x + gridDim.x * (blockIdx.y + (long long)gridDim.y * blockIdx.z)) * 256 + tid;
+    for (long long idx = first; idx < total; idx += nthr)
+      dkv_reduce_elem64(p.red_part, p.red_dK, p.red_dV, p.red_lddk, p.red_lddv, p.red_nsplit, p.red_B, p.red_H, p.red_Skv, p.red_accum, idx);
+  }
+  // wave roles
+  const bool key_wave = wave >= 1 && wave <= KB;
+  const bool dq_wave = wave == 0;
+  const int my_kb = wave - 1;                                     // key waves
+
+  auto unit_head = [&](int u) -> char* {                          // (as in xattn_bwd2_kernel)
+    const int cur = (u - u_begin) & 1;
+    char* const S0 = St + cur * STG;
+    float* const rc = (float*)(S0 + 2 * TILE_BYTES);
+    WAIT_VM0();
+    __syncthreads();                                              // unit u landed; unit u - 1 is complete (its dS image too)
+    if (u + 1 < u_end) stage_unit(u + 1, cur ^ 1);
+    {
+      const char* dt = S0 + TILE_BYTES;
+      float dsum = 0.f;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const bf16x8 d = *(const bf16x8*)(dt + dq_l * 128 + (((dqt * 2 + i) ^ swz_x(dq_l)) << 4));
+#pragma unroll
+        for (int j = 0; j < 8; ++j) dsum += (float)d[j] * (float)o_pf[i][j];
+      }
+      dsum += dpp_move<0xB1>(dsum);
+      dsum += dpp_move<0x4E>(dsum);
+      if (dqt == 0) {
+        const bool rv = u * 64 + dq_l < p.Sq;
+        rc[64 + dq_l] = rv ? -dsum : 0.f;
+        rc[dq_l] = rv ? -rc[dq_l] * LOG2E : -INFINITY;
+      }
+    }
+    if (u + 1 < u_end) fetch_o(u + 1);
+    __syncthreads();
+    return S0;
+  };
+
+  if (!key_wave) {
+    // ================= dQ wave (and, with KB == 2, an idle wave that only keeps the barriers' count):
+    // dQ^T[d][q] = K^T[d][key] dS^T[key][q] of the PREVIOUS unit, from its dS image
+    auto dq_unit = [&](int u) {                                   // u: the unit whose dS image is complete
+      char* const img = Dsm + ((u - u_begin) & 1) * DS_IMG;
+      constexpr int NSL = KB > 2 ? 5 : 4;                         // 16-key slices that hold keys (< 80)
+      f32x16 oacc[2][2];
+#pragma unroll
+      for (int q2 = 0; q2 < 2; ++q2)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) oacc[q2][i][r] = 0.f;
+      // all dS fragments first: the image is then free and becomes this wave's output image
+      bf16x8 dsf[2][NSL];
+#pragma unroll
+      for (int q2 = 0; q2 < 2; ++q2)
+#pragma unroll
+        for (int sl = 0; sl < NSL; ++sl)
+          dsf[q2][sl] = read_transposed_frag<true>(img + (sl >> 2) * TILE_BYTES, (sl & 3) * 16, q2 * 32, lane);
+#pragma unroll
+      for (int sl = 0; sl < NSL; ++sl) {
+        bf16x8 kt[2];
+#pragma unroll
+        for (int db = 0; db < 2; ++db) kt[db] = read_transposed_frag<true>(Ksm + (sl >> 2) * TILE_BYTES, (sl & 3) * 16, db * 32, lane);
+#pragma unroll
+        for (int q2 = 0; q2 < 2; ++q2)
+#pragma unroll
+          for (int db = 0; db < 2; ++db)
+            oacc[q2][db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kt[db], dsf[q2][sl], oacc[q2][db], 0, 0, 0);
+      }
+      const int r8 = lane >> 3, ch = lane & 7;
+      bf16* dQb = p.dQ + (long long)b * p.Sq * p.lddq + head * 64 + ch * 8;
+#pragma unroll
+      for (int q2 = 0; q2 < 2; ++q2) {
+        char* const o2 = img + q2 * (32 * 144);                   // (2 x 4.5 KiB <= the 10 KiB image)
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            bf16x4 o;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] = (bf16)(oacc[q2][db][4 * g + j] * p.scale);
+            *(bf16x4*)(o2 + frow * 144 + (db * 32 + 8 * g + 4 * fh) * 2) = o;
+          }
+        const int qg = u * 64 + q2 * 32;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int row = i * 8 + r8;
+          if (qg + row < p.Sq) {
+            bf16x8 v = *(const bf16x8*)(o2 + row * 144 + ch * 16);
+            bf16* dst = dQb + (long long)(qg + row) * p.lddq;
+            if (p.accum_dq) {
+              const bf16x8 old = *(const bf16x8*)dst;
+#pragma unroll
+              for (int j = 0; j < 8; ++j) v[j] = (bf16)((float)v[j] + (float)old[j]);
+            }
+            *(bf16x8*)dst = v;
+          }
+        }
+      }
+    };
+    for (int u = u_begin; u < u_end; ++u) {
+      (void)unit_head(u);
+      if (dq_wave && u > u_begin) dq_unit(u - 1);
+    }
+    if (u_begin < u_end) {
+      __syncthreads();                                            // the key waves have finished the last unit's dS image
+      if (dq_wave) dq_unit(u_end - 1);
+    }
+    return;
+  }
+
+  // ================= key waves: one key block each, S / dP / P / dS ONCE per (key block, query block)
+  f32x16 dk[2], dv[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dk[i][r] = dv[i][r] = 0.f;
+  const int kb = my_kb;
+  const bool blk_live = kb * 32 < p.Skv;                          // uniform
+  const char* const Kmine = Ksm + (kb >> 1) * TILE_BYTES;
+  const char* const Vmine = Vsm + (kb >> 1) * TILE_BYTES;
+  const int kmine_row = (kb & 1) * 32 + frow;
+  const int key = kb * 32 + frow;
+  const bool kvalid = key < skv_b;
+  const bool blk_pad = kb * 32 + 32 > skv_b;                      // uniform: this key block holds padding keys
+  for (int u = u_begin; u < u_end; ++u) {
+    const char* const S0 = unit_head(u);
+    const char* const Qt = S0;
+    const char* const dOt = S0 + TILE_BYTES;
+    const float* const rc = (const float*)(S0 + 2 * TILE_BYTES);
+    char* const img = Dsm + ((u - u_begin) & 1) * DS_IMG;
+#pragma unroll 1
+    for (int qb = 0; qb < 2; ++qb) {
+      const int rb0 = qb * 32;
+      f32x16 sacc, dpacc;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const f32x4 d4 = *(const f32x4*)(rc + 64 + rb0 + 8 * g + 4 * fh);
+        const f32x4 l4 = *(const f32x4*)(rc + rb0 + 8 * g + 4 * fh);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          dpacc[4 * g + j] = d4[j];
+          sacc[4 * g + j] = PRE ? l4[j] : 0.f;
+        }
+      }
+      {
+        bf16x8 qfr[4], kf[4], dfr[4], vf[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          qfr[s] = read_row_frag(Qt, rb0 + frow, s, fh);
+          kf[s] = read_row_frag(Kmine, kmine_row, s, fh);
+          dfr[s] = read_row_frag(dOt, rb0 + frow, s, fh);
+          vf[s] = read_row_frag(Vmine, kmine_row, s, fh);
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {                             // two independent accumulation chains, interleaved
+          sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qfr[s], kf[s], sacc, 0, 0, 0);
+          dpacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dfr[s], vf[s], dpacc, 0, 0, 0);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      bf16x8 pfr[2], dsfr[2];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        f32x4 l4 = {0.f, 0.f, 0.f, 0.f};
+        if (!PRE) l4 = *(const f32x4*)(rc + rb0 + 8 * g + 4 * fh);
+        bf16x4 ds4;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int r = 4 * g + j;
+          float pr = PRE ? fast_exp2(sacc[r]) : fast_exp2(fmaf(sacc[r], c, l4[j]));
+          if (blk_pad) pr = kvalid ? pr : 0.f;
+          const float ds = pr * dpacc[r];
+          pfr[g >> 1][(g & 1) * 4 + j] = (bf16)pr;
+          dsfr[g >> 1][(g & 1) * 4 + j] = (bf16)ds;
+          ds4[j] = (bf16)ds;
+        }
+        // dS[key][q = rb0 + 8 g + 4 fh .. + 3] -> the image row of this lane's key (keys >= 80 have no row: they are padding)
+        if (key < 80) *(bf16x4*)(img + (kb >> 1) * TILE_BYTES + swz_rc(kmine_row, rb0 + 8 * g + 4 * fh)) = ds4;
+      }
+      if (blk_live) {
+#pragma unroll
+        for (int k2 = 0; k2 < 2; ++k2) {
+          __builtin_amdgcn_sched_barrier(0);
+          bf16x8 dot[2], qt[2];
+#pragma unroll
+          for (int db = 0; db < 2; ++db) {
+            dot[db] = read_transposed_frag<true>(dOt, rb0 + k2 * 16, db * 32, lane);
+            qt[db] = read_transposed_frag<true>(Qt, rb0 + k2 * 16, db * 32, lane);
+          }
+#pragma unroll
+          for (int db = 0; db < 2; ++db) {
+            dv[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dot[db], pfr[k2], dv[db], 0, 0, 0);
+            dk[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qt[db], dsfr[k2], dk[db], 0, 0, 0);
+          }
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  if (u_begin < u_end) __syncthreads();                           // (the dQ waves' last hand-over)
+  const int krow = kb * 32 + frow;
+  if (krow >= p.Skv) return;
+  const float dks = PRE ? 0.6931471805599453f : p.scale;
+  if (p.nsplit > 1) {
+    float* pr = p.dkv_part + ((((long long)split * p.B + b) * p.H + head) * p.Skv + krow) * 128;
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int d = db * 32 + 8 * g + 4 * fh;
+        f32x4 a, cc;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { a[j] = dk[db][4 * g + j] * dks; cc[j] = dv[db][4 * g + j]; }
+        *(f32x4*)(pr + d) = a;
+        *(f32x4*)(pr + 64 + d) = cc;
+      }
+  } else {
+    bf16* dKr = p.dK + ((long long)b * p.Skv + krow) * p.lddk + head * 64;
+    bf16* dVr = p.dV + ((long long)b * p.Skv + krow) * p.lddv + head * 64;
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int d = db * 32 + 8 * g + 4 * fh;
+        bf16x4 ok, ov;
+        if (p.accum_dkv) {
+          ok = *(const bf16x4*)(dKr + d);
+          ov = *(const bf16x4*)(dVr + d);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          ok[j] = (bf16)(dk[db][4 * g + j] * dks + (p.accum_dkv ? (float)ok[j] : 0.f));
+          ov[j] = (bf16)(dv[db][4 * g + j] + (p.accum_dkv ? (float)ov[j] : 0.f));
+        }
+        *(bf16x4*)(dKr + d) = ok;
+        *(bf16x4*)(dVr + d) = ov;
+      }
+  }
+}
+
 // row constants of the backward kernels: delta[0][b][h][q] = -sum_d dO[q][h*D+d] * O[q][h*D+d], delta[1][b][h][q] = -lse * log2(e);
 // 8 lanes per (row, head), each sums D/8 elements
 #ifndef PEA_ATTN_DELTA_ROWS
@@ -1865,12 +2214,21 @@ __global__ void attn_dkv_reduce_kernel(const AttnP p) {
 // split count (fp32 partials per split).  1024 tokens, B*H = 80: u = 2 -> 320 workgroups, 4 splits; 4096 tokens, 40:
 // u = 3 -> 440 workgroups, 11 splits.
 // v2 of the one-pass cross-attention backward (xattn_bwd2_kernel: 64-query units, specialised waves): 33 .. 96 keys
-static int g_xattn_v2 = getenv("PEA_XATTN_BWD_V1") ? 0 : 1;              // PEA_XATTN_BWD_V1=1: the round-3 kernel for every key count (A/B)
+// which one-pass kernel: 0 = round 3 (xattn_bwd_kernel) for every key count; 2 = xattn_bwd2_kernel where it applies (33..96
+// keys); 1 / 3 (default) = the newest that applies: xattn_bwd3_kernel for 33..80 keys, xattn_bwd2_kernel for 81..96.
+// PEA_XATTN_BWD_V1=1 / PEA_XATTN_BWD_VER=n in the environment, pea_debug_set_xattn_bwd_v2(n) at run time (A/B, parity tests).
+static int g_xattn_v2 = getenv("PEA_XATTN_BWD_V1") ? 0 : (getenv("PEA_XATTN_BWD_VER") ? atoi(getenv("PEA_XATTN_BWD_VER")) : 3);
 extern "C" void pea_debug_set_xattn_bwd_v2(int v) { g_xattn_v2 = v; }
-static bool xattn_v2_keys(int Skv) { return g_xattn_v2 && Skv > 32 && Skv <= 96; }
+static bool xattn_v2_keys(int Skv) { return g_xattn_v2 && Skv > 32 && Skv <= 96; }     // v2 OR v3: 64-query units, deferrable reduce
+static bool xattn_v3_keys(int Skv) { return g_xattn_v2 != 0 && g_xattn_v2 != 2 && Skv > 32 && Skv <= 80; }
 int attention_bwd_nsplit(int B, int H, int Sq, int Skv) {
   if (Skv > 128 || Sq < 512) return 1;
-  const int uq = xattn_v2_keys(Skv) ? 64 : 128;                          // queries per unit
+  const bool v2 = xattn_v2_keys(Skv);
+  const int uq = v2 ? 64 : 128;                                          // queries per unit
+  // v2: a workgroup's fixed part (K / V staging, the first unit's flight, the hand-over and the partial stores) is worth
+  // about two of its 64-query units; without it the rule cut B * H = 160 (per-GPU batch 8) into 2560 one-unit workgroups:
+  // 57.8 us against the 41.2 us of the round-3 kernel.  (v1 keeps the rule it was tuned with.)
+  const int fixed = v2 ? 2 : 0;
   const int nu = (Sq + uq - 1) / uq;
   const long long bh = (long long)B * H;
   long long best = -1;
@@ -1878,7 +2236,7 @@ int attention_bwd_nsplit(int B, int H, int Sq, int Skv) {
   for (int u = 1; u <= nu; ++u) {
     const int ns = (nu + u - 1) / u;
     const long long rounds = (bh * ns + 511) / 512;
-    const long long cost = rounds * u * (uq / 2) + ns;
+    const long long cost = rounds * (u + fixed) * (uq / 2) + ns;
     if (best < 0 || cost < best) { best = cost; best_ns = ns; }
   }
   return best_ns;
@@ -1965,6 +2323,32 @@ static bool attn_use_xattn(const AttnP& p) {
   return g_attn_xattn && g_attn_use_tr && p.nd == 1 && p.Skv <= 128 && p.dQ && p.dK && p.dV && (p.nsplit <= 1 || p.dkv_part);
 }
 extern "C" void pea_debug_set_attn_fused_bwd(int v) { g_attn_fused_bwd = v; }
+// PEA_XATTN_DEFER=1: a cross-attention layer's split reduce rides in the next such launch's prologue instead of its own 5.8 us
+// launch.  Built for VERDICT r05 item 1a ("a single batched launch per step instead of 70"), parity-green (per-layer K / V
+// gradient checks of the full model), and worth NOTHING in the step: 99.86 / 99.76 ms with it, 99.78 / 99.87 without, alternating
+// processes on one box (profiles/r06_ab_defer_reduce.log) -- the prologue's extra loads cost what the launches did.  Off.
+static int g_xattn_defer = getenv("PEA_XATTN_DEFER") ? atoi(getenv("PEA_XATTN_DEFER")) : 0;
+int attention_bwd_defers(const AttnP& p0) {
+  AttnP p = p0;
+  if (p.nd == 0) p.nd = 1;
+  p.nsplit = p.dkv_part ? attention_bwd_nsplit(p.B, p.H, p.Sq, p.Skv) : 1;
+  return (g_xattn_defer && attn_use_xattn(p) && xattn_v2_keys(p.Skv) && p.nsplit > 1) ? 1 : 0;
+}
+void attention_set_deferred(AttnP& cur, const AttnP& pend) {
+  cur.red_part = pend.dkv_part; cur.red_dK = pend.dK; cur.red_dV = pend.dV; cur.red_lddk = pend.lddk; cur.red_lddv = pend.lddv;
+  cur.red_nsplit = attention_bwd_nsplit(pend.B, pend.H, pend.Sq, pend.Skv);
+  cur.red_B = pend.B; cur.red_H = pend.H; cur.red_Skv = pend.Skv; cur.red_accum = pend.accum_dkv;
+}
+int launch_attention_dkv_reduce(const AttnP& pend, hipStream_t s) {
+  AttnP p = pend;
+  if (p.nd == 0) p.nd = 1;
+  p.nsplit = attention_bwd_nsplit(p.B, p.H, p.Sq, p.Skv);
+  SHAPECHK(p.dkv_part && p.nsplit > 1 && p.dK && p.dV, "attention: nothing to reduce");
+  const long long total = (long long)p.B * p.H * p.Skv * 2 * 16 * p.nd;
+  hipLaunchKernelGGL(attn_dkv_reduce_kernel, dim3((unsigned)cdivl(total, 256)), dim3(256), 0, s, p);
+  HIPCHK(hipGetLastError());
+  return PEA_OK;
+}
 template <int ND>
 static int attn_bwd_nd(const AttnP& p, hipStream_t s) {
   int rc = attn_set_lds_attr<ND>();
@@ -1994,7 +2378,24 @@ static int attn_bwd_nd(const AttnP& p, hipStream_t s) {
           attr2 = true;
         }
         const int upw2 = cdiv(cdiv(p.Sq, 64), ns);
-        if (kb == 2) {
+        if (xattn_v3_keys(p.Skv)) {
+          constexpr int lds3 = 2 * (TILE_BYTES + TILE_BYTES / 2) + 2 * (2 * TILE_BYTES + 512) + 2 * (TILE_BYTES + 2048);
+          static bool attr3 = false;
+          if (!attr3) {
+            HIPCHK(hipFuncSetAttribute((const void*)xattn_bwd3_kernel<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds3));
+            HIPCHK(hipFuncSetAttribute((const void*)xattn_bwd3_kernel<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds3));
+            HIPCHK(hipFuncSetAttribute((const void*)xattn_bwd3_kernel<3, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds3));
+            HIPCHK(hipFuncSetAttribute((const void*)xattn_bwd3_kernel<3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds3));
+            attr3 = true;
+          }
+          if (kb == 2) {
+            if (p.q_prescaled) hipLaunchKernelGGL((xattn_bwd3_kernel<2, true>), grid, dim3(256), lds3, s, p, upw2);
+            else hipLaunchKernelGGL((xattn_bwd3_kernel<2, false>), grid, dim3(256), lds3, s, p, upw2);
+          } else {
+            if (p.q_prescaled) hipLaunchKernelGGL((xattn_bwd3_kernel<3, true>), grid, dim3(256), lds3, s, p, upw2);
+            else hipLaunchKernelGGL((xattn_bwd3_kernel<3, false>), grid, dim3(256), lds3, s, p, upw2);
+          }
+        } else if (kb == 2) {
           if (p.q_prescaled) hipLaunchKernelGGL((xattn_bwd2_kernel<2, true>), grid, dim3(256), lds2, s, p, upw2);
           else hipLaunchKernelGGL((xattn_bwd2_kernel<2, false>), grid, dim3(256), lds2, s, p, upw2);
         } else {
@@ -2008,7 +2409,7 @@ static int attn_bwd_nd(const AttnP& p, hipStream_t s) {
       else if (kb == 3) hipLaunchKernelGGL(xattn_bwd_kernel<3>, grid, dim3(256), lds, s, p, upw);
       else hipLaunchKernelGGL(xattn_bwd_kernel<4>, grid, dim3(256), lds, s, p, upw);
       }
-      if (p.nsplit > 1) {
+      if (p.nsplit > 1 && !(p.defer_reduce && xattn_v2_keys(p.Skv))) {
         const long long total = (long long)p.B * p.H * p.Skv * 2 * 16;
         hipLaunchKernelGGL(attn_dkv_reduce_kernel, dim3((unsigned)cdivl(total, 256)), dim3(256), 0, s, p);
       }

@@ -204,6 +204,14 @@ struct Tape {
   void wseq_end() { if (wseq_cur && !wseq_cur->ready && !wseq_cur->w.empty()) wseq_cur->ready = true; wseq_cur = nullptr; }
   void wseq_drop() { for (WSeq* q : {&wseq_fwd, &wseq_bwd}) { q->ready = false; q->w.clear(); q->pos = 0; } wseq_cur = nullptr; }
   int gemm(GemmP& p, hipStream_t s);   // launch_gemm with the prefetch target filled in
+  // Deferred split reduce of the cross-attention backward (AttnP::defer_reduce): the partials of the last deferrable launch wait
+  // in one half of attn_part for the next cross-attention launch (whose workgroups add them up in their prologue) or for the
+  // flush in front of the stacked K|V dgrad GEMM / at the end of the pass
+  AttnP pend_red{};
+  bool pend_red_valid = false;
+  int part_toggle = 0;
+  size_t part_half_elems = 0;        // floats per half of attn_part (scratch_needs doubles the partial buffer)
+  int flush_pending_reduce(hipStream_t s);
   Tape* arena_donor = nullptr;       // activation / gradient arenas borrowed from this (larger) tape: the two are never live at once
   bool arena_borrowed = false;
   // bytes of each scratch buffer (ensure_acts) and which of them are the donor's (bit order: gn, cs, delta, ups, geglu, attn_part,

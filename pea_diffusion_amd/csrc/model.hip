@@ -890,7 +890,8 @@ void Tape::scratch_needs(size_t need[8]) {
   need[2] = delta_elems * 4 * 2;               // two row constants per (b, h, q): -delta, -lse*log2e
   need[3] = ups_elems * 2;
   need[4] = geglu_elems * 2;
-  need[5] = part_bytes;
+  need[5] = 2 * part_bytes;                    // two halves: a launch writes one while the previous layer's half is being reduced
+  part_half_elems = part_bytes / sizeof(float);
   if (t_ehs >= 0 && kvall_total > 0) {
     const int ksteps = kvall_total / 64;
     kv_nsplit = std::max(1, std::min(32, ksteps / 128));
@@ -1382,6 +1383,7 @@ static int g_geglu_bwd_fused = getenv("PEA_GEGLU_BWD_UNFUSED") ? 0 : 1;
 extern "C" void pea_debug_set_geglu_bwd_fused(int v) { g_geglu_bwd_fused = v; }
 void Tape::begin_backward() {
   for (Tn& t : tn) { t.gw = false; t.gpend = nullptr; }
+  pend_red_valid = false;                      // (a pass that failed half-way leaves nothing behind)
 }
 
 int Tape::backward(const float* deps, hipStream_t s) {
@@ -1446,6 +1448,7 @@ int Tape::backward(const float* deps, hipStream_t s) {
       case OP_LINEAR: {
         Tn& a = tn[o.a];
         if (a.rg && o.p3 == 2) {          // stacked K|V projection: M = B*L rows, K = sum(2C) -> split-K + ordered reduce
+          RC(flush_pending_reduce(s));     // the last cross-attention layer's dK / dV partials -> out.g
           FusedMat& f = fused[o.fused];
           GemmP p; fill_gemm(p);
           p.A = out.g; p.lda = out.cols; p.M = (int)rb(out); p.K = out.cols; p.N = a.cols;
@@ -1585,7 +1588,19 @@ int Tape::backward(const float* deps, hipStream_t s) {
         SHAPECHK(!q.gw && !q.gpend && !k.gpend && (!k.gw || o.b == t_kvall), "unet: attention operand gradient written twice");
         if (q.rg) { p.dQ = q.g + o.acol; p.lddq = q.cols; }
         if (k.rg) { p.dK = k.g + o.bcol; p.lddk = k.cols; p.dV = v.g + o.ccol; p.lddv = v.cols; }
-        RC(launch_attention_bwd(p, s));
+        if (o.b == t_kvall && attention_bwd_defers(p)) {
+          // cross-attention layer on the specialised-wave kernel: its split reduce rides in the NEXT such launch's prologue
+          // (d(K|V) of t_kvall is read by nothing before the stacked K|V dgrad GEMM at the end of the pass)
+          p.dkv_part = attn_part + (part_toggle ? part_half_elems : 0);
+          p.defer_reduce = 1;
+          if (pend_red_valid) attention_set_deferred(p, pend_red);
+          RC(launch_attention_bwd(p, s));
+          pend_red = p;
+          pend_red_valid = true;
+          part_toggle ^= 1;
+        } else {
+          RC(launch_attention_bwd(p, s));
+        }
         if (q.rg) q.gw = true;
         if (k.rg) { k.gw = true; v.gw = true; }
         break;
@@ -1603,10 +1618,17 @@ int Tape::backward(const float* deps, hipStream_t s) {
         break;
     }
   }
+  RC(flush_pending_reduce(s));                 // (a graph without the stacked projection op)
   for (Tn& t : tn)
     if (t.rg) RC(materialize(t));              // graph inputs that only ever received a passed-on gradient
   wscope.ok = true;
   return PEA_OK;
+}
+
+int Tape::flush_pending_reduce(hipStream_t s) {
+  if (!pend_red_valid) return PEA_OK;
+  pend_red_valid = false;
+  return launch_attention_dkv_reduce(pend_red, s);
 }
 
 // ============================================================================ adapter

@@ -116,8 +116,17 @@ struct AttnP {
   int q_prescaled;                 // Q already holds q * scale * log2(e) (GemmP::qscale in the producing projection): scores leave the
                                    // MFMA in the log2 domain with no further rounding; dQ is still the gradient w.r.t. the UNSCALED q
   const float* bias;               // forward, masked instance only: additive score bias [H][Sq][Skv] in the LOG2 domain (T5 relative positions), may be null
+  // Deferred split reduce (cross-attention backward, xattn_bwd2_kernel).  defer_reduce = 1: this launch leaves its fp32 dK / dV
+  // partials in dkv_part and does NOT launch attn_dkv_reduce_kernel; the caller hands them to a LATER launch (red_* below,
+  // filled by attention_set_deferred) whose workgroups add them up while their own first tiles are in flight, or flushes them
+  // with launch_attention_dkv_reduce.  The splits are added in the same fixed order either way.
+  int defer_reduce;
+  const float* red_part; bf16 *red_dK, *red_dV; int red_lddk, red_lddv, red_nsplit, red_B, red_H, red_Skv, red_accum;
 };
 int attention_bwd_nsplit(int B, int H, int Sq, int Skv);
+int attention_bwd_defers(const AttnP& p);                                   // 1: launch_attention_bwd honours p.defer_reduce for this problem
+void attention_set_deferred(AttnP& cur, const AttnP& pending);              // cur's launch reduces pending's partials
+int launch_attention_dkv_reduce(const AttnP& pending, hipStream_t s);       // flush: the stand-alone reduce of a deferred launch
 size_t attention_bwd_scratch_bytes(int B, int H, int Sq, int Skv, int nd = 1);
 int launch_attention_fwd(const AttnP& p, hipStream_t s);
 int launch_attention_bwd(const AttnP& p, hipStream_t s);

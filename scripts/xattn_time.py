@@ -19,11 +19,11 @@ for (B, H, Sq, Skv) in [(4, 20, 1024, 77), (4, 10, 4096, 77), (8, 20, 1024, 77),
     o, lse = ops.attention_fwd(q, k, v, H, q_prescaled=True)
     do = torch.randn_like(o)
     tf = min(timeit(lambda: ops.attention_fwd(q, k, v, H, q_prescaled=True)) for _ in range(3))
-    tb = {0: 1e9, 1: 1e9}
+    tb = {0: 1e9, 2: 1e9, 3: 1e9}
     for _ in range(3):
-        for ver in (0, 1):
+        for ver in (0, 2, 3):
             lib().pea_debug_set_xattn_bwd_v2(ver)
             tb[ver] = min(tb[ver], timeit(lambda: ops.attention_bwd(q, k, v, o, do, lse, H, q_prescaled=True)))
-    lib().pea_debug_set_xattn_bwd_v2(1)
+    lib().pea_debug_set_xattn_bwd_v2(3)
     mb = 2.0 * B * Sq * C * 4 / 1e6
-    print(f"xattn B{B} H{H} Sq{Sq}: fwd {tf:6.1f} us | bwd (+reduce) v1 {tb[0]:6.1f} us, v2 {tb[1]:6.1f} us | Q,dO,O,dQ = {mb:.0f} MB -> {mb / 5e3 * 1e3 / 1e3:.1f} us at 5 TB/s", flush=True)
+    print(f"xattn B{B} H{H} Sq{Sq}: fwd {tf:6.1f} us | bwd (+reduce) v1 {tb[0]:6.1f} us, v2 {tb[2]:6.1f} us, v3 {tb[3]:6.1f} us | Q,dO,O,dQ = {mb:.0f} MB -> {mb / 5e3 * 1e3 / 1e3:.1f} us at 5 TB/s", flush=True)

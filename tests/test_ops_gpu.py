@@ -497,9 +497,10 @@ def test_attention_fwd_bwd(ops, use_tr, B, H, Sq, Skv, prescaled):
 @pytest.mark.parametrize("B,H,Sq,Skv", [(2, 3, 1024, 77), (1, 2, 4096, 77), (2, 2, 1000, 52), (1, 2, 2048, 64), (1, 1, 192, 77),
                                         (1, 2, 576, 96), (3, 2, 640, 40)])
 def test_cross_attention_bwd_specialised_waves(ops, B, H, Sq, Skv, prescaled):
-    """xattn_bwd2_kernel (round 6: 64-query units, double-buffered stage, waves 0-1 = dQ role, waves 2-3 = dK/dV role, the
-    third key block split between the two key waves and summed through LDS) against the fp32 reference AND against the round-3
-    one-pass kernel it replaces (pea_debug_set_xattn_bwd_v2(0)) on the same inputs: 2 and 3 key blocks, whole and ragged
+    """The round-6 cross-attention backward kernels -- xattn_bwd3_kernel (<= 80 keys: S / dP / P / dS evaluated ONCE by the key
+    waves, dS handed to the dQ wave through an LDS image: 5 products) and xattn_bwd2_kernel (<= 96 keys: 64-query units,
+    double-buffered stage, waves 0-1 = dQ role, waves 2-3 = dK/dV role, 7 products) -- against the fp32 reference AND against the
+    round-3 one-pass kernel (pea_debug_set_xattn_bwd_v2(0)) on the same inputs: 2 and 3 key blocks, whole and ragged
     query counts (1000 = 15 units + 40 rows), 1..16 query splits, the accumulate-into form of dQ / dK / dV (+=, as a tensor
     with a second consumer gets it), plain and prescaled Q.  Bit-reproducible: two launches agree exactly."""
     import ctypes
@@ -518,19 +519,20 @@ def test_cross_attention_bwd_specialised_waves(ops, B, H, Sq, Skv, prescaled):
     tag = f"xattn-bwd2 pre{int(prescaled)} B{B} H{H} Sq{Sq} Skv{Skv}"
     try:
         got = {}
-        for ver in (1, 0, 1):
+        for ver in (3, 0, 2, 3):           # newest that applies (five-product kernel up to 80 keys) / round-3 kernel / specialised waves
             L.pea_debug_set_xattn_bwd_v2(ver)
             g = ops.attention_bwd(qc, kc, vc, o, doc, lse, H, q_prescaled=prescaled)
             torch.cuda.synchronize()
             if ver in got:
                 assert all(torch.equal(a, b_) for a, b_ in zip(got[ver], g)), tag + ": two launches differ"
             got[ver] = g
-        for name, a, r in zip(("dQ", "dK", "dV"), got[1], (qr.grad, kr.grad, vr.grad)):
-            close_bf16(f"{tag} {name}", a, r, ulps=4.0)
-        for name, a, b_ in zip(("dQ", "dK", "dV"), got[1], got[0]):       # the two kernels: same algorithm, other summation order
-            close_bf16(f"{tag} {name} v2-vs-v1", a, b_.float().cpu(), ulps=2.0)
+        for ver in (3, 2):
+            for name, a, r in zip(("dQ", "dK", "dV"), got[ver], (qr.grad, kr.grad, vr.grad)):
+                close_bf16(f"{tag} v{ver} {name}", a, r, ulps=4.0)
+            for name, a, b_ in zip(("dQ", "dK", "dV"), got[ver], got[0]):       # same algorithm, other summation order
+                close_bf16(f"{tag} {name} v{ver}-vs-v1", a, b_.float().cpu(), ulps=2.0)
         # accumulate-into: dX = X0 + gradient (direct bf16 form when there is no query split, i.e. without the scratch)
-        L.pea_debug_set_xattn_bwd_v2(1)
+        L.pea_debug_set_xattn_bwd_v2(3)
         C = H * 64
         x0 = [bfr(*t.shape, seed=20 + i).cuda() for i, t in enumerate((q, k, v))]
         acc = [t.clone() for t in x0]
@@ -542,7 +544,7 @@ def test_cross_attention_bwd_specialised_waves(ops, B, H, Sq, Skv, prescaled):
         for name, a, x, r in zip(("dQ", "dK", "dV"), acc, x0, (qr.grad, kr.grad, vr.grad)):
             close_bf16(f"{tag} {name} accumulate", a, x.float().cpu() + r, ulps=4.0)
     finally:
-        L.pea_debug_set_xattn_bwd_v2(1)
+        L.pea_debug_set_xattn_bwd_v2(3)
 
 
 @pytest.mark.parametrize("prescaled", [True, False])
