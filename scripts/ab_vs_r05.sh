@@ -1,0 +1,12 @@
+#!/bin/bash
+# same-box A/B of the whole step: the round-5 tree (.ab_r05/: commit 8bb53a6, built from its own sources) against this tree,
+# alternating processes; prints ms / MHz / W / J per step of each run
+cd $GRAFT_REPO_ROOT
+N=${1:-3}
+B="--steps 16 --warmup 3 --no-cpu-baseline --no-roofline --no-dead-row-line"
+for i in $(seq $N); do
+  for t in r05 r06; do
+    if [ $t = r05 ]; then d=.ab_r05; else d=.; fi
+    python $d/bench.py $B 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); g=d['gpu']; pw=g.get('power_w_mean') or g['power_w_median']; print('$t', d['ms_per_step'], 'ms', g['sclk_mhz_median'], 'MHz', pw, 'W', round(pw*d['ms_per_step_mean']*1e-3,2), 'J/step', d['value'], 'images/s')"
+  done
+done
