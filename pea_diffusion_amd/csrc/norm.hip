@@ -473,22 +473,13 @@ static void gn_fused_launch(const GnFused& f, int blocks, hipStream_t s, const b
 #undef GN_F
 }
 
-// pixels per thread of the three-kernel path: 16 when that still gives the chip >= GN_MIN_BLOCKS workgroups, else 8, else 4.
-// The backward runs over the differentiated half of the merged batch: with 16 pixels per thread its grids were 2.7
-// workgroups per CU of 4 waves (two 16-byte loads per pixel in flight) and the sums pass ran at 3.6 TB/s where the forward's
-// statistics pass, on twice the workgroups, reads at 5.4.
-#ifndef GN_MIN_BLOCKS
-#define GN_MIN_BLOCKS 1024
-#endif
-static int gn_geometry(int B, int HW, int C, int* threads, int* ppblk, int* nblk, size_t* lds) {
+static int gn_geometry(int HW, int C, int* threads, int* ppblk, int* nblk, size_t* lds) {
   const int nchunk = C / 8;
   if (nchunk > 1024) return -1;
   int ppb = 256 / nchunk;
   if (ppb < 1) ppb = 1;
   *threads = nchunk * ppb;
-  int ppt = 16;
-  while (ppt > 4 && (long long)B * cdiv(HW, ppb * ppt) < GN_MIN_BLOCKS) ppt >>= 1;
-  int per = ppb * ppt;
+  int per = ppb * 16;
   if (per > HW) per = HW;
   *ppblk = per;
   *nblk = cdiv(HW, per);
@@ -496,14 +487,11 @@ static int gn_geometry(int B, int HW, int C, int* threads, int* ppblk, int* nblk
   return 0;
 }
 
-// scratch layout (floats): partial [B][nblk][groups][2] | sums [B][groups][2]; sized for the finest split (4 pixels per
-// thread) so that a backward over fewer samples than the tape's batch fits whatever split it picks
+// scratch layout (floats): partial [B][nblk][groups][2] | sums [B][groups][2]
 size_t groupnorm_scratch_bytes(int B, int HW, int C, int groups) {
-  const int nchunk = C / 8;
-  if (nchunk > 1024 || nchunk < 1) return 0;
-  int ppb = 256 / nchunk;
-  if (ppb < 1) ppb = 1;
-  const int nblk = cdiv(HW, ppb * 4 > HW ? HW : ppb * 4);
+  int threads, ppblk, nblk;
+  size_t lds;
+  if (gn_geometry(HW, C, &threads, &ppblk, &nblk, &lds)) return 0;
   return ((size_t)B * nblk * groups * 2 + (size_t)B * groups * 2) * sizeof(float) + 256;
 }
 
@@ -512,7 +500,7 @@ int launch_groupnorm_fwd(const bf16* x, const float* gamma, const float* beta, b
   SHAPECHK(C % 8 == 0 && C % groups == 0 && groups <= GN_MAX_GROUPS, "groupnorm: C=%d groups=%d", C, groups);
   int threads, ppblk, nblk;
   size_t lds;
-  SHAPECHK(gn_geometry(B, HW, C, &threads, &ppblk, &nblk, &lds) == 0, "groupnorm: C=%d too wide", C);
+  SHAPECHK(gn_geometry(HW, C, &threads, &ppblk, &nblk, &lds) == 0, "groupnorm: C=%d too wide", C);
   SHAPECHK(threads >= groups, "groupnorm: C=%d too narrow for %d groups", C, groups);
   float* partial = (float*)scratch;
   PROF_BEGIN(4, 0.0, 2.0 * 2.0 * B * (double)HW * C, s);           // algorithmic: read x, write y
@@ -540,7 +528,7 @@ int launch_groupnorm_bwd(const bf16* x, const bf16* dy, const float* gamma, cons
   SHAPECHK(C % 8 == 0 && C % groups == 0 && groups <= GN_MAX_GROUPS, "groupnorm: C=%d groups=%d", C, groups);
   int threads, ppblk, nblk;
   size_t lds;
-  SHAPECHK(gn_geometry(B, HW, C, &threads, &ppblk, &nblk, &lds) == 0, "groupnorm: C=%d too wide", C);
+  SHAPECHK(gn_geometry(HW, C, &threads, &ppblk, &nblk, &lds) == 0, "groupnorm: C=%d too wide", C);
   SHAPECHK(threads >= groups, "groupnorm: C=%d too narrow for %d groups", C, groups);
   float* partial = (float*)scratch;
   float* sums = partial + (size_t)B * nblk * groups * 2;
