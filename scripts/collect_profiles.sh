@@ -3,7 +3,7 @@
 # per-family breakdown, rocprofv3 kernel stats of the same command, two PMC passes (FETCH_SIZE / WRITE_SIZE), the MFMA
 # utilisation pass, the per-launch profile and the GEMM / attention variant tables.  Everything lands in gpurun_out/ with the
 # round tag ($1, default r03); copy what should be judged into profiles/.
-T=${1:-r05}
+T=${1:-r06}
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out
 mkdir -p $O
@@ -20,5 +20,6 @@ python3 $R/scripts/pmc_mfma.py /tmp/prof_mfma > $O/${T}_pmc_mfma.json 2>> $O/pmc
 python3 $R/scripts/gemm_bench.py 24,25,27,28,29 > $O/${T}_gemm_variants.log 2>&1
 python3 $R/scripts/gemm_bench.py 24,25,27,28,29 merged > $O/${T}_gemm_variants_merged.log 2>&1
 python3 $R/scripts/attn_bench.py > $O/${T}_attn_bench.log 2>&1
+python3 $R/scripts/xattn_time.py > $O/${T}_xattn_time.log 2>&1
 tail -1 $O/${T}_bench_line.json | cut -c1-300
 cat $O/${T}_pmc_traffic.json $O/${T}_pmc_mfma.json
