@@ -817,13 +817,15 @@ def main():
                 "method": "hip events around every launch on the launch stream; instrumented single-stream replay of the timed "
                           "steps (the timed region overlaps teacher and student passes on two streams)",
                 "families": family_rooflines(fams, nprof, sustained),
-                "tolerances": "fp32-stored outputs rtol 1e-3 / atol 1e-4 vs the fp32 oracle; bf16-stored outputs 1 bf16 ulp "
+                "tolerances": "per kernel: fp32-stored outputs rtol 1e-3 / atol 1e-4 vs the fp32 oracle; bf16-stored outputs 1 bf16 ulp "
                               "(2-4 ulp for multi-product attention gradients and folded LN->Linear) + rms-scaled atol "
-                              "(tests/test_ops_gpu.py); end to end (hundreds of chained bf16-stored ops) relative L2: eps 6.8e-3 "
-                              "and flat adapter gradient 7.9e-3 at 1024x1024 vs the fp32 oracle (limits 1.5e-2 / 2e-2), every one of the "
-                              "140 cross-attention K / V projections and 17 time_emb_proj layers on its own (limit 2e-2), and an adaptive "
-                              "limit of 1.5 x the bf16-storage noise floor measured in the run (tests/test_model_gpu.py: "
-                              "check_against_storage_floor; measured ratio 0.97-1.06 at full SDXL size)",
+                              "(tests/test_ops_gpu.py).  END TO END the path is ON the bf16-storage noise floor, not within rtol 1e-3: "
+                              "relative L2 vs the fp32 oracle 6.8e-3 (eps) and 7.9e-3 (flat adapter gradient) at 1024x1024 = 0.97-1.06 x what "
+                              "bf16 storage alone does to the oracle in the same run (limit 1.5 x that floor; fixed limits 1.5e-2 / 2e-2), "
+                              "every one of the 140 cross-attention K / V projections and 17 time_emb_proj layers on its own (limit 2e-2).  "
+                              "That oracle comparison runs at batch 2 (tests/test_model_gpu.py::test_sdxl_full_model_step_vs_oracle_1024); "
+                              "THIS line's workload (batch 4) meets the oracle through properties only (idempotence, masks, per-sample "
+                              "independence, bit-reproducibility: tests/test_configs_gpu.py, test_model_gpu.py::test_full_size_properties)",
                 "adapter_golden_rel_l2": {"measured_in_this_run": adapter_golden_rel_l2(), "limit": 1e-2,
                                           "what": "HIP adapter forward (pooled, tokens) vs the reference MLP's own outputs, "
                                                   "tests/golden/mlp_sdxl_6M.npz (one bf16 rounding of weights and activations)"}}
