@@ -190,6 +190,24 @@ def test_control_plane_rendezvous_is_bounded():
     assert r.returncode == 7 and "RAISED" in r.stdout, (r.returncode, r.stdout, r.stderr[-800:])
 
 
+def test_bench_under_torch_distributed_run_as_the_driver_launches_it():
+    """the driver's N > 1 command line -- `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+    --master-port P bench.py --gpus N ...` -- on CPU: the ranks join the gloo control plane through torchrun's agent store
+    (TORCHELASTIC_USE_AGENT_STORE), run the protocol and rank 0's ONE line is the launcher's stdout"""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--dry-run-collective"], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["control_plane"] == "gloo" and out["allreduce_max_abs_err"] < 1e-5
+    assert out["steps_run_per_rank"] == 1 + 2 + 3 + 2
+
+
 def test_bench_launcher_kills_hung_ranks_at_the_deadline(tmp_path):
     """a rank that never exits (stuck in a collective) must not block the parent forever: launch_ranks() stops its own
     children at the deadline, names the ranks that were still alive and returns non-zero"""
