@@ -15,6 +15,12 @@
 // row-wise for S / dP and through the transpose read for the two gradient products.
 // K/V (or Q/dO) tiles are 64 x 64 bf16 (128-byte rows) staged by LDS-DMA into a 2-deep ring
 // with the same source-side XOR swizzle as gemm.hip.
+// Cross-attention (<= 128 keys: the 77-token text context) has its own kernels with K / V resident in LDS for a
+// workgroup's whole life: xattn_fwd_kernel; backward xattn_bwd3_kernel (<= 80 keys: S / dP / P / dS evaluated once by
+// key-on-the-lane waves, dS handed to a dQ wave through an LDS image -- five products), xattn_bwd2_kernel (<= 96 keys:
+// both orientations on specialised waves), xattn_bwd_kernel (round 3: any key count up to 128), each with an ordered
+// fp32 split reduce over query ranges (attn_dkv_reduce_kernel).  Every output tile (O, dQ, dK, dV) leaves through a
+// per-wave LDS image as whole 128-byte rows.
 #include <stdlib.h>
 
 #include "pea_kernels.h"
