@@ -1208,7 +1208,15 @@ int Tape::gemm(GemmP& p, hipStream_t s) {
       if (i >= q->w.size() || q->w[i].first != (const void*)p.W) { q->ready = false; q->w.clear(); wseq_cur = nullptr; }
       else {
         static const int dist = getenv("PEA_GEMM_PF_DIST") ? atoi(getenv("PEA_GEMM_PF_DIST")) : 1;     // experiment: launches ahead
-        if (i + dist < q->w.size()) { p.pf_ptr = q->w[i + dist].first; p.pf_bytes = q->w[i + dist].second; }
+        if (i + dist < q->w.size()) {
+          // armed only for a target inside the weights owner's arena: a recorded pointer that no longer is (a weights owner
+          // re-created behind a borrower's back) would send the DMA waves' touch loads to unmapped memory -- a GPU page fault
+          const Tape* ow = weights_owner ? weights_owner : this;
+          const char* t = (const char*)q->w[i + dist].first;
+          const long long nb = q->w[i + dist].second;
+          if (ow->warena && t >= ow->warena && t + nb <= ow->warena + ow->wbytes) { p.pf_ptr = t; p.pf_bytes = nb; }
+          else { q->ready = false; q->w.clear(); wseq_cur = nullptr; }
+        }
       }
     }
   }
